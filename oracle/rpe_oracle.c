@@ -1,0 +1,229 @@
+/*
+ * rpe_oracle.c -- CPU restatement of RPEFlow's hot-path operator arithmetic.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under rpeflow_amd/ may import, link or
+ * call this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker.
+ *
+ * Every function states, in explicit rounding order, what the reference's
+ * CPU/PyTorch fallback computes (reference paths are relative to
+ * /root/reference).  The explicit order matters: KNN and FPS are judged
+ * bit-exactly, and a BLAS call on another host may round differently
+ * (SURVEY.md H1), so no library arithmetic is used here.
+ *
+ * Parity pin: tests/golden/make_golden.py imports the reference in the build
+ * container and stores its outputs; tests/test_oracle_golden.py checks this
+ * file against them (bit patterns for squared_distance, index-exact for
+ * FPS, tie-aware exact for KNN, 1e-6 for the float ops).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mfma).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ---- known-answer self check: fmaf must be a single-rounding fma -------- */
+ORC_API int orc_selfcheck(void) {
+    volatile float a = 1.0f + 0x1p-12f, b = 1.0f - 0x1p-12f, c = -1.0f;
+    /* a*b = 1 - 2^-24 exactly; rounded product would be 1.0 -> 0.0 */
+    float r = fmaf(a, b, c);
+    return r == -0x1p-24f ? 0 : 1;
+}
+
+/* |v|^2 as torch.sum(v**2, -1) does it for D<=3: every square rounded,
+ * summed left to right (models/csrc/wrapper.py:50-51). */
+static inline float sqnorm(const float *v, int D) {
+    float s = v[0] * v[0];
+    for (int d = 1; d < D; ++d) {
+        float t = v[d] * v[d];
+        s = s + t;
+    }
+    return s;
+}
+
+/* One entry of squared_distance(xyz1=q, xyz2=p): models/csrc/wrapper.py:40-52
+ *   dist  = -2 * matmul(q, p^T)      dot = fma(q2,p2, fma(q1,p1, fl(q0*p0)))
+ *   dist += |q|^2                    (in place, rounded)
+ *   dist += |p|^2                    (in place, rounded)                    */
+static inline float pair_dist(const float *q, const float *p, int D, float qq, float pp) {
+    float dot = q[0] * p[0];
+    for (int d = 1; d < D; ++d) dot = fmaf(q[d], p[d], dot);
+    float t = -2.0f * dot; /* exact */
+    t = t + qq;
+    t = t + pp;
+    return t;
+}
+
+/* squared_distance: q [B,N1,D], p [B,N2,D] channel-last -> out [B,N1,N2] */
+ORC_API void orc_squared_distance(const float *q, const float *p, int B, int N1, int N2, int D,
+                                  float *out) {
+    float *pp = (float *)malloc(sizeof(float) * (size_t)N2);
+    for (int b = 0; b < B; ++b) {
+        const float *qb = q + (size_t)b * N1 * D, *pb = p + (size_t)b * N2 * D;
+        for (int j = 0; j < N2; ++j) pp[j] = sqnorm(pb + (size_t)j * D, D);
+        for (int i = 0; i < N1; ++i) {
+            float qq = sqnorm(qb + (size_t)i * D, D);
+            float *o = out + ((size_t)b * N1 + i) * N2;
+            for (int j = 0; j < N2; ++j) o[j] = pair_dist(qb + (size_t)i * D, pb + (size_t)j * D, D, qq, pp[j]);
+        }
+    }
+    free(pp);
+}
+
+/* k_nearest_neighbor, CPU fallback: models/csrc/wrapper.py:115-117
+ *   dists = squared_distance(query, input); topk(k, dim=2, largest=False)
+ * Ascending distance; torch.topk leaves the order inside a group of equal
+ * distances unspecified, the oracle fixes it to "lower input index first"
+ * (SURVEY.md H2).  NaN distances sort last, as topk treats them.
+ * input [B,M,D], query [B,Q,D] channel-last; idx [B,Q,k] int64; dist [B,Q,k]
+ * (dist may be NULL).  Requires k <= M (topk raises otherwise).             */
+ORC_API int orc_knn(const float *input, const float *query, int B, int M, int Q, int D, int k,
+                    int64_t *idx, float *dist) {
+    if (k > M || k <= 0) return 1;
+    float *pp = (float *)malloc(sizeof(float) * (size_t)M);
+    float *bd = (float *)malloc(sizeof(float) * (size_t)k);
+    int64_t *bi = (int64_t *)malloc(sizeof(int64_t) * (size_t)k);
+    for (int b = 0; b < B; ++b) {
+        const float *pb = input + (size_t)b * M * D, *qb = query + (size_t)b * Q * D;
+        for (int j = 0; j < M; ++j) pp[j] = sqnorm(pb + (size_t)j * D, D);
+        for (int i = 0; i < Q; ++i) {
+            const float *qv = qb + (size_t)i * D;
+            float qq = sqnorm(qv, D);
+            int n = 0;
+            for (int j = 0; j < M; ++j) {
+                float d = pair_dist(qv, pb + (size_t)j * D, D, qq, pp[j]);
+                if (d != d) d = INFINITY; /* NaN -> last */
+                if (n == k && !(d < bd[k - 1])) continue;
+                int pos = n < k ? n : k - 1;
+                while (pos > 0 && d < bd[pos - 1]) { /* strict: earlier index stays first */
+                    bd[pos] = bd[pos - 1];
+                    bi[pos] = bi[pos - 1];
+                    --pos;
+                }
+                bd[pos] = d;
+                bi[pos] = j;
+                if (n < k) ++n;
+            }
+            int64_t *oi = idx + ((size_t)b * Q + i) * k;
+            for (int t = 0; t < k; ++t) oi[t] = bi[t];
+            if (dist) {
+                float *od = dist + ((size_t)b * Q + i) * k;
+                for (int t = 0; t < k; ++t) od[t] = bd[t];
+            }
+        }
+    }
+    free(pp); free(bd); free(bi);
+    return 0;
+}
+
+/* furthest_point_sampling, CPU fallback: models/csrc/wrapper.py:83-96
+ *   start at index 0; distances = 1e10;
+ *   nd = sum((xyz - cur)**2, -1) = fl(fl(dx*dx + dy*dy) + dz*dz), each square rounded
+ *   distances = min(distances, nd) (strict <, :92-93); next = FIRST argmax (:94)
+ * xyz [B,N,3] channel-last; idx [B,S] int64.                                */
+ORC_API void orc_fps(const float *xyz, int B, int N, int S, int64_t *idx) {
+    float *dist = (float *)malloc(sizeof(float) * (size_t)N);
+    for (int b = 0; b < B; ++b) {
+        const float *pb = xyz + (size_t)b * N * 3;
+        for (int j = 0; j < N; ++j) dist[j] = 1e10f;
+        int64_t cur = 0;
+        for (int s = 0; s < S; ++s) {
+            idx[(size_t)b * S + s] = cur;
+            float cx = pb[cur * 3], cy = pb[cur * 3 + 1], cz = pb[cur * 3 + 2];
+            float best = -INFINITY;
+            int64_t arg = 0;
+            for (int j = 0; j < N; ++j) {
+                float dx = pb[j * 3] - cx, dy = pb[j * 3 + 1] - cy, dz = pb[j * 3 + 2] - cz;
+                float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                float nd = xx + yy;
+                nd = nd + zz;
+                if (nd < dist[j]) dist[j] = nd;
+                if (dist[j] > best) { best = dist[j]; arg = j; }
+            }
+            cur = arg;
+        }
+    }
+    free(dist);
+}
+
+/* correlation2d, CPU fallback (_correlation_py): models/csrc/wrapper.py:56-65
+ *   zero-pad in2 by md; plane i*(2md+1)+j = mean_c(in1 * in2_pad[i:i+H, j:j+W])
+ *   i walks rows (dy=i-md), j walks columns (dx=j-md).
+ * Sum over c in channel order, then one division by C.  torch.mean may
+ * associate the sum differently; the op is judged at 1e-6 mean-abs
+ * (correlation_test.cpp:82-83), not bitwise.
+ * in1,in2 [B,C,H,W]; out [B,(2md+1)^2,H,W]                                  */
+ORC_API void orc_correlation2d(const float *in1, const float *in2, int B, int C, int H, int W, int md,
+                               float *out) {
+    int Dn = 2 * md + 1;
+    size_t HW = (size_t)H * W;
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < Dn; ++i)
+            for (int j = 0; j < Dn; ++j) {
+                float *o = out + (((size_t)b * Dn * Dn) + (size_t)i * Dn + j) * HW;
+                int dy = i - md, dx = j - md;
+                for (int y = 0; y < H; ++y)
+                    for (int x = 0; x < W; ++x) {
+                        int y2 = y + dy, x2 = x + dx;
+                        float s = 0.0f;
+                        if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) {
+                            const float *a = in1 + (size_t)b * C * HW + (size_t)y * W + x;
+                            const float *c2 = in2 + (size_t)b * C * HW + (size_t)y2 * W + x2;
+                            for (int c = 0; c < C; ++c) s += a[(size_t)c * HW] * c2[(size_t)c * HW];
+                        }
+                        o[(size_t)y * W + x] = s / (float)C;
+                    }
+            }
+}
+
+/* Bilinear sampling of feat[B,C,H,W] at pixel coordinates (px,py)[B,P],
+ * following torch.nn.functional.grid_sample(mode='bilinear',
+ * align_corners=True) on CPU after the callers' normalisation round trip:
+ *   models/utils.py:186-198 (backwarp_2d, padding 'border', border=1)
+ *   models/utils.py:288-294 (grid_sample_wrapper, padding 'zeros', border=0)
+ *   gn = 2*g/(S-1) - 1 ; u = (gn+1)*((S-1)/2) ; border: clip to [0,S-1]
+ *   w = u-floor(u), e = 1-w, n = v-floor(v), s = 1-n; weights nw=s*e, ne=s*w,
+ *   sw=n*e, se=n*w; a corner outside the image contributes 0;
+ *   out = ((nw_v*nw + ne_v*ne) + sw_v*sw) + se_v*se.
+ * out [B,C,P]                                                               */
+static inline float unnorm(float g, int S, int border) {
+    float gn = 2.0f * g / (float)(S - 1) - 1.0f;
+    float u = (gn + 1.0f) * ((float)(S - 1) / 2.0f); /* ATen CPU: (coord+1) * ((size-1)/2) */
+    if (border) {
+        if (!(u > 0.0f)) u = 0.0f; /* clip_coordinates: min(S-1, max(u, 0)); NaN -> 0 */
+        if (u > (float)(S - 1)) u = (float)(S - 1);
+    }
+    return u;
+}
+
+ORC_API void orc_bilinear_sample(const float *feat, int B, int C, int H, int W, const float *px,
+                                 const float *py, int P, int border, float *out) {
+    size_t HW = (size_t)H * W;
+    for (int b = 0; b < B; ++b)
+        for (int p = 0; p < P; ++p) {
+            float u = unnorm(px[(size_t)b * P + p], W, border);
+            float v = unnorm(py[(size_t)b * P + p], H, border);
+            float fx = floorf(u), fy = floorf(v);
+            float w = u - fx, e = 1.0f - w, n = v - fy, s = 1.0f - n;
+            float w_nw = s * e, w_ne = s * w, w_sw = n * e, w_se = n * w;
+            /* out-of-range (and NaN/inf) coordinates: every corner test fails */
+            long ix = (fx >= -2.0f && fx <= (float)W + 1.0f) ? (long)fx : -2;
+            long iy = (fy >= -2.0f && fy <= (float)H + 1.0f) ? (long)fy : -2;
+            int in_w = ix >= 0 && ix < W, in_e = ix + 1 >= 0 && ix + 1 < W;
+            int in_n = iy >= 0 && iy < H, in_s = iy + 1 >= 0 && iy + 1 < H;
+            for (int c = 0; c < C; ++c) {
+                const float *f = feat + ((size_t)b * C + c) * HW;
+                float v_nw = (in_n && in_w) ? f[(size_t)iy * W + ix] : 0.0f;
+                float v_ne = (in_n && in_e) ? f[(size_t)iy * W + ix + 1] : 0.0f;
+                float v_sw = (in_s && in_w) ? f[(size_t)(iy + 1) * W + ix] : 0.0f;
+                float v_se = (in_s && in_e) ? f[(size_t)(iy + 1) * W + ix + 1] : 0.0f;
+                float acc = v_nw * w_nw + v_ne * w_ne;
+                acc = acc + v_sw * w_sw;
+                acc = acc + v_se * w_se;
+                out[((size_t)b * C + c) * P + p] = acc;
+            }
+        }
+}

@@ -1,0 +1,129 @@
+"""Golden-vector case table: one place that says which seeded inputs each
+tests/golden/*.npz was generated from.  Used by tests/golden/make_golden.py
+(with the reference) and by the parity tests (without it)."""
+import numpy as np
+
+from . import inputs as I
+
+# name -> (coord generator, B, M, Q, D, k, seed)
+KNN_CASES = {
+    "knn3d_k16_ids_2x1024x777": ("ids", 2, 1024, 777, 3, 16, 101),
+    "knn3d_k3_ids_2x1024x777": ("ids", 2, 1024, 777, 3, 3, 102),
+    "knn3d_k16_unit_2x1024x777": ("unit", 2, 1024, 777, 3, 16, 103),
+    "knn3d_k16_ids_1x4096x4096": ("ids", 1, 4096, 4096, 3, 16, 104),
+    "knn3d_k3_unit_1x4096x4096": ("unit", 1, 4096, 4096, 3, 3, 105),
+    "knn2d_k1_pix_2x1024x60x36": ("pix", 2, 1024, (36, 60), 2, 1, 106),
+    "knn2d_k1_pix_1x4096x240x144": ("pix", 1, 4096, (144, 240), 2, 1, 107),
+    "knn3d_k32_unit_1x300x200": ("unit", 1, 300, 200, 3, 32, 108),
+    "knn3d_k1_ids_1x70x130": ("ids", 1, 70, 130, 3, 1, 109),
+}
+
+
+def knn_inputs(name):
+    kind, B, M, Q, D, k, seed = KNN_CASES[name]
+    r = I.rng(seed)
+    if kind == "pix":
+        H, W = Q
+        inp = I.pixel_cloud(r, B, M, H, W)
+        qry = I.pixel_grid(B, H, W)
+    elif kind == "ids":
+        inp = I.ids_cloud(r, B, M, D)
+        qry = I.ids_cloud(r, B, Q, D)
+    else:
+        inp = I.unit_cloud(r, B, M, D)
+        qry = I.unit_cloud(r, B, Q, D)
+    return inp, qry, k
+
+
+# name -> (kind, B, N, S, seed)
+FPS_CASES = {
+    "fps_ids_2x2048_512": ("ids", 2, 2048, 512, 201),
+    "fps_ids_1x8192_4096": ("ids", 1, 8192, 4096, 202),
+    "fps_unit_3x1000_333": ("unit", 3, 1000, 333, 203),
+    "fps_dup_1x512_256": ("dup", 1, 512, 256, 204),
+}
+
+
+def fps_inputs(name):
+    kind, B, N, S, seed = FPS_CASES[name]
+    r = I.rng(seed)
+    if kind == "ids":
+        xyz = I.ids_cloud(r, B, N)
+    elif kind == "unit":
+        xyz = I.unit_cloud(r, B, N)
+    else:  # every point appears twice: exercises the first-maximum tie rule
+        half = I.unit_cloud(r, B, N // 2)
+        xyz = np.concatenate([half, half], axis=1)
+    return xyz, S
+
+
+# name -> (B, N1, N2, D, kind, seed)
+SQDIST_CASES = {
+    "sqdist_ids_2x200x300x3": (2, 200, 300, 3, "ids", 301),
+    "sqdist_unit_2x200x300x2": (2, 200, 300, 2, "unit", 302),
+}
+
+
+def sqdist_inputs(name):
+    B, N1, N2, D, kind, seed = SQDIST_CASES[name]
+    r = I.rng(seed)
+    gen = I.ids_cloud if kind == "ids" else I.unit_cloud
+    return gen(r, B, N1, D), gen(r, B, N2, D)
+
+
+# name -> (B, C, H, W, md, seed)
+CORR_CASES = {
+    "corr_2x24x20x28_md4": (2, 24, 20, 28, 4, 401),
+    "corr_1x32x36x60_md4": (1, 32, 36, 60, 4, 402),
+    "corr_1x7x9x15_md4": (1, 7, 9, 15, 4, 403),
+    "corr_1x5x11x13_md2": (1, 5, 11, 13, 2, 404),
+}
+
+
+def corr_inputs(name):
+    B, C, H, W, md, seed = CORR_CASES[name]
+    r = I.rng(seed)
+    return I.feature_map(r, B, C, H, W), I.feature_map(r, B, C, H, W), md
+
+
+# glue ops: one small case each (B, C2, C3, H, W, N, seed)
+GLUE = dict(B=2, C2=12, C3=10, H=18, W=30, N=200, M=97, seed=501)
+
+
+def glue_inputs():
+    g = GLUE
+    r = I.rng(g["seed"])
+    d = {}
+    d["feat_2d"] = I.feature_map(r, g["B"], g["C2"], g["H"], g["W"])
+    d["flow"] = I.flow_field(r, g["B"], g["H"], g["W"], std=4.0)
+    d["feat_3d"] = r.standard_normal((g["B"], g["C3"], g["N"]), dtype=np.float32)
+    d["xy"] = np.ascontiguousarray(I.pixel_cloud(r, g["B"], g["N"], g["H"], g["W"]).transpose(0, 2, 1))
+    d["xyz"] = np.ascontiguousarray(I.ids_cloud(r, g["B"], g["N"]).transpose(0, 2, 1))
+    d["xyz_q"] = np.ascontiguousarray(I.ids_cloud(r, g["B"], g["M"]).transpose(0, 2, 1))
+    d["flow3"] = (r.standard_normal((g["B"], 3, g["N"]), dtype=np.float32) * np.float32(0.3))
+    d["idx"] = r.integers(0, g["N"], (g["B"], g["M"], 5)).astype(np.int64)
+    return d
+
+
+# 3-D blocks: name -> dict
+BLOCK_CASES = {
+    "pointconv_down": dict(B=2, M=300, Q=120, C=13, Cout=20, k=16, norm="batch_norm", seed=601),
+    "pointconv_nosample": dict(B=2, M=150, Q=150, C=29, Cout=17, k=16, norm=None, seed=602),
+    "correlation3d": dict(B=2, N=140, C=12, k=16, seed=603),
+}
+
+
+def block_inputs(name):
+    c = BLOCK_CASES[name]
+    r = I.rng(c["seed"])
+    cl = lambda a: np.ascontiguousarray(a.transpose(0, 2, 1))
+    if name.startswith("pointconv"):
+        xyz = cl(I.ids_cloud(r, c["B"], c["M"]))
+        feat = r.standard_normal((c["B"], c["C"], c["M"]), dtype=np.float32)
+        sampled = xyz[:, :, : c["Q"]].copy() if name == "pointconv_down" else None
+        return dict(xyz=xyz, feat=feat, sampled=sampled)
+    xyz1 = cl(I.ids_cloud(r, c["B"], c["N"]))
+    xyz2 = (xyz1 + r.standard_normal(xyz1.shape, dtype=np.float32) * np.float32(0.2)).astype(np.float32)
+    feat1 = r.standard_normal((c["B"], c["C"], c["N"]), dtype=np.float32)
+    feat2 = r.standard_normal((c["B"], c["C"], c["N"]), dtype=np.float32)
+    return dict(xyz1=xyz1, xyz2=xyz2, feat1=feat1, feat2=feat2)

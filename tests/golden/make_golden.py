@@ -1,0 +1,123 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own CPU/PyTorch path.
+
+Runs only in the build container, where /root/reference is mounted:
+
+    python -m tests.golden.make_golden            (from the repo root)
+
+It imports ``models`` from /root/reference (nothing is copied), feeds it the
+seeded inputs of tests/cases.py and stores the outputs.  The .npz files are
+data: reference outputs (and nothing of the reference's source).  The GPU box
+has no /root/reference; tests there read the committed .npz only.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("RPEFLOW_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+
+import contextlib, io  # noqa: E402
+
+with contextlib.redirect_stdout(io.StringIO()):  # "Failed to load CUDA extensions" notice
+    from models import csrc as ref_ops  # noqa: E402
+    from models import utils as ref_utils  # noqa: E402
+    from models import pointconv as ref_pc  # noqa: E402
+    from models import pwc3d_core as ref_3d  # noqa: E402
+
+from tests import cases as K  # noqa: E402
+from tests import inputs as I  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+T = torch.from_numpy
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def gen_knn():
+    for name in K.KNN_CASES:
+        inp, qry, k = K.knn_inputs(name)
+        d = ref_ops.squared_distance(T(qry), T(inp))
+        vals, idx = d.topk(k, dim=2, largest=False)
+        idx2 = ref_ops.k_nearest_neighbor(T(inp), T(qry), k)
+        assert torch.equal(idx, idx2)
+        # the (k+1)-th smallest distance tells the checker whether the k|k+1 boundary is a tie
+        kk = min(k + 1, inp.shape[1])
+        nxt = d.topk(kk, dim=2, largest=False).values[..., -1]
+        save(name, idx=idx.numpy().astype(np.int32), dist=vals.numpy(), next_dist=nxt.numpy())
+
+
+def gen_fps():
+    for name in K.FPS_CASES:
+        xyz, S = K.fps_inputs(name)
+        idx = ref_ops.furthest_point_sampling(T(xyz), S)
+        save(name, idx=idx.numpy().astype(np.int32))
+
+
+def gen_sqdist():
+    for name in K.SQDIST_CASES:
+        a, b = K.sqdist_inputs(name)
+        save(name, dist=ref_ops.squared_distance(T(a), T(b)).numpy())
+
+
+def gen_corr():
+    for name in K.CORR_CASES:
+        a, b, md = K.corr_inputs(name)
+        save(name, out=ref_ops.correlation2d(T(a), T(b), md).numpy())
+
+
+def gen_glue():
+    d = {k: T(v) for k, v in K.glue_inputs().items()}
+    out = {}
+    out["gather_cf"] = ref_utils.batch_indexing_channel_first(d["feat_3d"], d["idx"])
+    out["gather_cl"] = ref_utils.batch_indexing_channel_last(d["feat_3d"].transpose(1, 2).contiguous(), d["idx"])
+    out["backwarp_2d"] = ref_utils.backwarp_2d(d["feat_2d"], d["flow"], padding_mode="border")
+    out["grid_sample_wrapper"] = ref_utils.grid_sample_wrapper(d["feat_2d"], d["xy"])
+    out["knn_interp"] = ref_utils.knn_interpolation(d["xyz"], d["feat_3d"], d["xyz_q"], k=3)
+    out["backwarp_3d"] = ref_utils.backwarp_3d(d["xyz"], d["xyz"] + 0.1, d["flow3"], k=3)
+    ref_utils.mesh_grid_cache.clear()
+    out["project_feat"] = ref_utils.project_feat_with_nn_corr(d["xy"], d["feat_2d"], d["feat_3d"])
+    save("glue_ops", **{k: v.numpy() for k, v in out.items()})
+
+
+def load_params(module, seed):
+    shapes = [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+    params = I.fill_params(shapes, seed)
+    module.load_state_dict({k: T(v) for k, v in params.items()}, strict=True)
+    module.eval()
+    return params
+
+
+@torch.no_grad()
+def gen_blocks():
+    c = K.BLOCK_CASES["pointconv_down"]
+    m = ref_pc.PointConvDownSampling(c["C"], c["Cout"], norm=c["norm"], k=c["k"])
+    load_params(m, c["seed"] + 1000)
+    x = K.block_inputs("pointconv_down")
+    save("pointconv_down", out=m(T(x["xyz"]), T(x["feat"]), T(x["sampled"])).numpy())
+
+    c = K.BLOCK_CASES["pointconv_nosample"]
+    m = ref_pc.PointConvNoSampling(c["C"], c["Cout"], norm=c["norm"], k=c["k"])
+    load_params(m, c["seed"] + 1000)
+    x = K.block_inputs("pointconv_nosample")
+    save("pointconv_nosample", out=m(T(x["xyz"]), T(x["feat"])).numpy())
+
+    c = K.BLOCK_CASES["correlation3d"]
+    m = ref_3d.Correlation3D(c["C"], c["C"], k=c["k"])
+    load_params(m, c["seed"] + 1000)
+    x = K.block_inputs("correlation3d")
+    save("correlation3d", out=m(T(x["xyz1"]), T(x["feat1"]), T(x["xyz2"]), T(x["feat2"])).numpy())
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks"]
+    for w in which:
+        globals()["gen_" + w]()

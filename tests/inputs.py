@@ -1,0 +1,90 @@
+"""Seeded synthetic inputs shared by tests/golden/make_golden.py, the parity
+tests and bench.py.  Everything comes from numpy.random.default_rng(seed) so
+the golden generator (which runs next to the reference) and the tests (which
+run without it) rebuild identical arrays; goldens store outputs only."""
+import numpy as np
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+def unit_cloud(r, B, N, D=3):
+    """Points uniform in [0,1)^D, channel-last [B,N,D] (k_nearest_neighbor_test.cpp:31-32 style)."""
+    return r.random((B, N, D), dtype=np.float32)
+
+
+def ids_cloud(r, B, N, D=3):
+    """Points in the range the model's IDS transform produces:
+    x in +-14.5, y in +-8.5, z in 22..113; |p|^2 ~ 1e4 so fp32 distances tie often."""
+    x = r.uniform(-14.5, 14.5, (B, N)).astype(np.float32)
+    y = r.uniform(-8.5, 8.5, (B, N)).astype(np.float32)
+    z = r.uniform(22.0, 113.0, (B, N)).astype(np.float32)
+    return np.stack([x, y, z][:D], axis=-1)
+
+
+def pixel_cloud(r, B, N, H, W):
+    """2-D projected point positions, a little beyond the image, channel-last [B,N,2]."""
+    x = r.uniform(-2.0, W + 1.0, (B, N)).astype(np.float32)
+    y = r.uniform(-2.0, H + 1.0, (B, N)).astype(np.float32)
+    return np.stack([x, y], axis=-1)
+
+
+def pixel_grid(B, H, W):
+    """mesh_grid flattened, channel-last [B,H*W,2] (models/utils.py:172-183, 300-301)."""
+    gx = np.broadcast_to(np.arange(W, dtype=np.float32)[None, :], (H, W)).reshape(-1)
+    gy = np.broadcast_to(np.arange(H, dtype=np.float32)[:, None], (H, W)).reshape(-1)
+    return np.broadcast_to(np.stack([gx, gy], -1)[None], (B, H * W, 2)).copy()
+
+
+def feature_map(r, B, C, H, W):
+    return r.standard_normal((B, C, H, W), dtype=np.float32)
+
+
+def flow_field(r, B, H, W, std=3.0):
+    return (r.standard_normal((B, 2, H, W), dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+
+def fill_params(shapes, seed):
+    """Deterministic parameters for a module, in state-dict order.
+    ``shapes``: list of (key, shape).  Weights ~ N(0, 1/fan_in), biases ~ N(0, 0.1),
+    running_var in [0.5, 1.5), integer buffers (num_batches_tracked) zero."""
+    r = rng(seed)
+    out = {}
+    for key, shape in shapes:
+        shape = tuple(shape)
+        if key.endswith("num_batches_tracked"):
+            out[key] = np.zeros(shape, np.int64)
+        elif key.endswith("running_var"):
+            out[key] = r.uniform(0.5, 1.5, shape).astype(np.float32)
+        elif key.endswith("running_mean") or key.endswith("bias"):
+            out[key] = (r.standard_normal(shape) * 0.1).astype(np.float32)
+        elif key.endswith("norm_fn.weight"):
+            out[key] = r.uniform(0.5, 1.5, shape).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+            out[key] = (r.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
+    return out
+
+
+def frame_pair(seed, H=544, W=960, N=8192, f=1050.0):
+    """One synthetic evaluation sample, SURVEY.md section 8(d): uint8 RGB pair, 20-channel
+    event voxel, two back-projected clouds (pc2 = pc1 + N(0,0.05^2)), targets."""
+    r = rng(seed)
+    cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+    images = r.integers(0, 256, (6, H, W), dtype=np.uint8)
+    event_voxel = r.standard_normal((20, H, W), dtype=np.float32)
+    z = r.uniform(2.0, 35.0, N)
+    u = r.uniform(0.0, W - 1.0, N)
+    v = r.uniform(0.0, H - 1.0, N)
+    pc1 = np.stack([(u - cx) * z / f, (v - cy) * z / f, z]).astype(np.float32)
+    pc2 = (pc1 + r.standard_normal((3, N)) * 0.05).astype(np.float32)
+    flow_2d = np.concatenate([r.standard_normal((2, H, W)) * 5.0, np.ones((1, H, W))]).astype(np.float32)
+    flow_3d = (pc2 - pc1).astype(np.float32)
+    occ = (r.random(N) < 0.2).astype(np.float32)
+    return {
+        "images": images, "event_voxel": event_voxel,
+        "pcs": np.concatenate([pc1, pc2]).astype(np.float32),
+        "flow_2d": flow_2d, "flow_3d": flow_3d, "occ_mask_3d": occ,
+        "intrinsics": np.array([f, cx, cy], np.float32),
+    }

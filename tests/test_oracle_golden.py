@@ -1,0 +1,103 @@
+"""CPU: pin the oracle (oracle/) against the reference outputs in tests/golden/.
+This is what allows the GPU tests to use the oracle as the checker."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import cases as K
+from tests import inputs as I
+from tests.check import assert_bits_equal, assert_knn_tie_aware
+
+
+def G(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def test_oracle_selfcheck():
+    assert O.lib().orc_selfcheck() == 0
+
+
+@pytest.mark.parametrize("name", list(K.SQDIST_CASES))
+def test_squared_distance_bits(golden_dir, name):
+    a, b = K.sqdist_inputs(name)
+    assert_bits_equal(O.squared_distance(a, b), G(golden_dir, name)["dist"], name)
+
+
+@pytest.mark.parametrize("name", list(K.KNN_CASES))
+def test_knn(golden_dir, name):
+    inp, qry, k = K.knn_inputs(name)
+    g = G(golden_dir, name)
+    idx, dist = O.k_nearest_neighbor(inp, qry, k, return_dists=True)
+    assert_knn_tie_aware(idx, dist, g["idx"], g["dist"], g["next_dist"], name)
+
+
+def test_knn_channel_first_sniff():
+    inp, qry, k = K.knn_inputs("knn3d_k3_ids_2x1024x777")
+    a = O.k_nearest_neighbor(inp, qry, k)
+    b = O.k_nearest_neighbor(inp.transpose(0, 2, 1), qry.transpose(0, 2, 1), k)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name", list(K.FPS_CASES))
+def test_fps(golden_dir, name):
+    xyz, S = K.fps_inputs(name)
+    assert np.array_equal(O.furthest_point_sampling(xyz, S), G(golden_dir, name)["idx"]), name
+
+
+@pytest.mark.parametrize("name", list(K.CORR_CASES))
+def test_correlation2d(golden_dir, name):
+    a, b, md = K.corr_inputs(name)
+    out, ref = O.correlation2d(a, b, md), G(golden_dir, name)["out"]
+    assert out.shape == ref.shape
+    # correlation_test.cpp:82-83 accepts mean|diff| < 1e-6; also bound the worst element
+    assert np.abs(out - ref).mean() < 1e-6
+    assert np.abs(out - ref).max() < 2e-6
+
+
+def test_glue_ops(golden_dir):
+    d, g = K.glue_inputs(), G(golden_dir, "glue_ops")
+    assert np.array_equal(O.batch_indexing_channel_first(d["feat_3d"], d["idx"]), g["gather_cf"])
+    assert np.array_equal(O.batch_indexing_channel_last(d["feat_3d"].transpose(0, 2, 1), d["idx"]), g["gather_cl"])
+    tol = dict(rtol=0, atol=2e-6)
+    np.testing.assert_allclose(O.backwarp_2d(d["feat_2d"], d["flow"]), g["backwarp_2d"], **tol)
+    np.testing.assert_allclose(O.grid_sample_wrapper(d["feat_2d"], d["xy"]), g["grid_sample_wrapper"], **tol)
+    np.testing.assert_allclose(O.knn_interpolation(d["xyz"], d["feat_3d"], d["xyz_q"], 3), g["knn_interp"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(O.backwarp_3d(d["xyz"], d["xyz"] + np.float32(0.1), d["flow3"], 3), g["backwarp_3d"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(O.project_feat_with_nn_corr(d["xy"], d["feat_2d"], d["feat_3d"]), g["project_feat"], **tol)
+
+
+def _shapes_pointconv(C, Cout, norm):
+    s = [("weight_net.convs.0.conv_fn.weight", (8, 3, 1, 1)), ("weight_net.convs.0.conv_fn.bias", (8,)),
+         ("weight_net.convs.1.conv_fn.weight", (16, 8, 1, 1)), ("weight_net.convs.1.conv_fn.bias", (16,)),
+         ("linear.weight", (Cout, 16 * (C + 3))), ("linear.bias", (Cout,))]
+    if norm == "batch_norm":
+        s += [("norm_fn.weight", (Cout,)), ("norm_fn.bias", (Cout,)), ("norm_fn.running_mean", (Cout,)),
+              ("norm_fn.running_var", (Cout,)), ("norm_fn.num_batches_tracked", ())]
+    return s
+
+
+def _shapes_corr3d(C):
+    s = []
+    for i, (ci, co) in enumerate([(3 + 2 * C, C), (C, C)]):
+        s += [(f"cost_mlp.convs.{i}.conv_fn.weight", (co, ci, 1, 1)), (f"cost_mlp.convs.{i}.conv_fn.bias", (co,))]
+    for net in ("weight_net1", "weight_net2"):
+        for i, (ci, co) in enumerate([(3, 8), (8, 8), (8, C)]):
+            s += [(f"{net}.convs.{i}.conv_fn.weight", (co, ci, 1, 1)), (f"{net}.convs.{i}.conv_fn.bias", (co,))]
+    return s
+
+
+@pytest.mark.parametrize("name", ["pointconv_down", "pointconv_nosample"])
+def test_pointconv(golden_dir, name):
+    c, x = K.BLOCK_CASES[name], K.block_inputs(name)
+    p = I.fill_params(_shapes_pointconv(c["C"], c["Cout"], c["norm"]), c["seed"] + 1000)
+    out = O.pointconv(p, x["xyz"], x["feat"], sampled_xyz=x["sampled"], k=c["k"], norm=c["norm"])
+    np.testing.assert_allclose(out, G(golden_dir, name)["out"], rtol=1e-4, atol=1e-4)
+
+
+def test_correlation3d(golden_dir):
+    c, x = K.BLOCK_CASES["correlation3d"], K.block_inputs("correlation3d")
+    p = I.fill_params(_shapes_corr3d(c["C"]), c["seed"] + 1000)
+    out = O.correlation3d(p, x["xyz1"], x["feat1"], x["xyz2"], x["feat2"], k=c["k"])
+    np.testing.assert_allclose(out, G(golden_dir, "correlation3d")["out"], rtol=1e-4, atol=1e-4)
