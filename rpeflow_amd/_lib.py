@@ -1,0 +1,81 @@
+"""ctypes binding of librpeflow_hip.so (include/rpeflow_hip.h).
+
+The library is loaded on first use.  If it is missing the operators raise:
+there is no PyTorch or CPU fallback behind this boundary.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librpeflow_hip.so")
+
+_c_f32p = ctypes.c_void_p
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_c_ptr = ctypes.c_void_p
+
+# name -> argtypes, exactly the prototypes of include/rpeflow_hip.h
+_PROTOTYPES = {
+    "rpe_abi_version": [],
+    "rpe_knn": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
+                _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
+    "rpe_squared_distance": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
+                             _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
+    "rpe_fps": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
+    "rpe_correlation2d_forward": [_c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                  _c_float, _c_int, _c_ptr, _c_ptr],
+    "rpe_probe_mfma4x4": [_c_ptr, _c_ptr],
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -m rpeflow_amd.build` "
+                "(hipcc --offload-arch=gfx950). rpeflow_amd has no CPU/PyTorch fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in _PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = _c_int
+        handle.rpe_error_string.argtypes = [_c_int]
+        handle.rpe_error_string.restype = ctypes.c_char_p
+        if handle.rpe_abi_version() != 1:
+            raise RuntimeError("librpeflow_hip.so: ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().rpe_error_string(code).decode()
+        raise RuntimeError(f"{what}: {msg} (code {code})")
+
+
+def stream_of(t: torch.Tensor):
+    """The HIP stream PyTorch is currently issuing on for t's device."""
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def require_gpu(*tensors, op):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                f"{op}: rpeflow_amd operators run on the GPU only (got a {t.device} tensor); "
+                "there is no CPU fallback in this package")
+    dev = tensors[0].device
+    for t in tensors[1:]:
+        if t.device != dev:
+            raise RuntimeError(f"{op}: tensors on different devices ({dev} vs {t.device})")
+    return dev

@@ -1,0 +1,51 @@
+// Shared helpers for the gfx950 kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rpeflow_hip.h"
+
+#define RPE_API extern "C" __attribute__((visibility("default")))
+
+#define RPE_WAVE 64
+
+static inline int rpe_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+__device__ __forceinline__ int rpe_lane() { return (int)(threadIdx.x & (RPE_WAVE - 1)); }
+
+// wave-uniform value -> scalar register
+__device__ __forceinline__ float rpe_uniform(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ int rpe_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// value of lane `l` (l wave-uniform) -> scalar register
+__device__ __forceinline__ float rpe_readlane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ int rpe_readlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+// |v|^2 exactly as torch.sum(v**2,-1) rounds it for D<=3 (wrapper.py:50-51):
+// every square rounded, summed left to right, no fma (-ffp-contract=off).
+template <int D>
+__device__ __forceinline__ float rpe_sqnorm(const float (&v)[3]) {
+    float s = v[0] * v[0];
+    if (D > 1) { float t = v[1] * v[1]; s = s + t; }
+    if (D > 2) { float t = v[2] * v[2]; s = s + t; }
+    return s;
+}
+
+// One entry of squared_distance (wrapper.py:49-51).  qm2 = -2*q (exact), so the
+// fma chain yields fl(-2*dot) directly: scaling by -2 commutes with rounding.
+template <int D>
+__device__ __forceinline__ float rpe_pair_dist(const float (&qm2)[3], float qq, const float (&p)[3], float pp) {
+    float t = qm2[0] * p[0];
+    if (D > 1) t = __fmaf_rn(qm2[1], p[1], t);
+    if (D > 2) t = __fmaf_rn(qm2[2], p[2], t);
+    t = t + qq;
+    t = t + pp;
+    return t;
+}

@@ -1,0 +1,269 @@
+// k_nearest_neighbor + squared_distance for gfx950.
+//
+// Replaces k_nearest_neighbor_{2d,3d}_kernel (k_nearest_neighbor_kernel.cu:8-112:
+// one thread per query, 32-entry local arrays) with a wave-cooperative design:
+//
+//   * one wave owns QW queries; their coordinates are wave-uniform (SGPRs);
+//   * the 64 lanes sweep the input cloud 64 points at a time (coalesced loads,
+//     either point layout through strides);
+//   * k == 1: every lane keeps its own running minimum, one butterfly at the end;
+//   * k >= 2: the sorted top-k list of a query lives ACROSS the lanes (lane r holds
+//     rank r, so k <= 64); a tile's candidates are found with one ballot against
+//     the current k-th distance and inserted with a one-lane shift.
+//
+// Arithmetic and tie rule follow the CPU fallback (wrapper.py:40-52,115-117), see
+// common.h; equal distances are ordered by input index.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+template <int D>
+__device__ __forceinline__ void load_point(const float *base, int64_t sn, int64_t sd, int i, float (&p)[3]) {
+    const float *a = base + (int64_t)i * sn;
+    p[0] = a[0];
+    p[1] = D > 1 ? a[sd] : 0.f;
+    p[2] = D > 2 ? a[2 * sd] : 0.f;
+}
+
+template <int D, int QW>
+struct Queries {
+    float qm2[QW][3];
+    float qq[QW];
+    __device__ __forceinline__ void load(const float *qry, int64_t sn, int64_t sd, int qbase, int Q) {
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+            int qi = min(qbase + j, Q - 1);
+            float q[3];
+            load_point<D>(qry, sn, sd, qi, q);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) q[d] = rpe_uniform(q[d]);
+            qq[j] = rpe_sqnorm<D>(q);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) qm2[j][d] = -2.0f * q[d];
+        }
+    }
+};
+
+// ---- k >= 2: cross-lane sorted list ----------------------------------------
+template <int D, int QW>
+__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(
+    const float *__restrict__ inp, int64_t in_sb, int64_t in_sn, int64_t in_sd,
+    const float *__restrict__ qry, int64_t q_sb, int64_t q_sn, int64_t q_sd,
+    int M, int Q, int k, int64_t *__restrict__ idx, float *__restrict__ dist) {
+    const int lane = rpe_lane();
+    const int wave = rpe_uniform((int)(threadIdx.x >> 6));
+    const int b = blockIdx.y;
+    const int qbase = (blockIdx.x * kWavesPerBlock + wave) * QW;
+    if (qbase >= Q) return;
+    inp += (int64_t)b * in_sb;
+    qry += (int64_t)b * q_sb;
+
+    Queries<D, QW> qs;
+    qs.load(qry, q_sn, q_sd, qbase, Q);
+
+    float Ld[QW], tau[QW];
+    int Li[QW];
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+        Ld[j] = INFINITY;
+        Li[j] = 0;
+        tau[j] = INFINITY;
+    }
+
+    for (int base = 0; base < M; base += RPE_WAVE) {
+        const int pi = base + lane;
+        const bool valid = pi < M;
+        float p[3] = {0.f, 0.f, 0.f};
+        if (valid) load_point<D>(inp, in_sn, in_sd, pi, p);
+        const float pp = rpe_sqnorm<D>(p);
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+            float d = rpe_pair_dist<D>(qs.qm2[j], qs.qq[j], p, pp);
+            d = valid ? d : INFINITY;
+            unsigned long long m = __ballot(d < tau[j]);
+            while (m) {  // wave-uniform: candidates in index order
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const float nd = rpe_readlane(d, l);
+                if (nd < tau[j]) {
+                    const int ni = base + l;
+                    // every listed entry has a smaller index than ni, so "nd < entry"
+                    // (strict) keeps equal distances in index order
+                    const float upd = __shfl_up(Ld[j], 1);
+                    const int upi = __shfl_up(Li[j], 1);
+                    const bool gt = nd < Ld[j];
+                    const bool gtp = (lane > 0) && (nd < upd);
+                    Ld[j] = gt ? (gtp ? upd : nd) : Ld[j];
+                    Li[j] = gt ? (gtp ? upi : ni) : Li[j];
+                    tau[j] = rpe_readlane(Ld[j], k - 1);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+        const int qi = qbase + j;
+        if (qi < Q && lane < k) {
+            const int64_t o = ((int64_t)b * Q + qi) * k + lane;
+            idx[o] = (int64_t)Li[j];
+            if (dist) dist[o] = Ld[j];
+        }
+    }
+}
+
+// ---- k == 1: lane-local minimum ----------------------------------------------
+template <int D, int QW>
+__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_nearest_kernel(
+    const float *__restrict__ inp, int64_t in_sb, int64_t in_sn, int64_t in_sd,
+    const float *__restrict__ qry, int64_t q_sb, int64_t q_sn, int64_t q_sd,
+    int M, int Q, int64_t *__restrict__ idx, float *__restrict__ dist) {
+    const int lane = rpe_lane();
+    const int wave = rpe_uniform((int)(threadIdx.x >> 6));
+    const int b = blockIdx.y;
+    const int qbase = (blockIdx.x * kWavesPerBlock + wave) * QW;
+    if (qbase >= Q) return;
+    inp += (int64_t)b * in_sb;
+    qry += (int64_t)b * q_sb;
+
+    Queries<D, QW> qs;
+    qs.load(qry, q_sn, q_sd, qbase, Q);
+
+    float bd[QW];
+    int bi[QW];
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+        bd[j] = INFINITY;
+        bi[j] = 0x7fffffff;
+    }
+
+    for (int base = 0; base < M; base += RPE_WAVE) {
+        const int pi = base + lane;
+        const bool valid = pi < M;
+        float p[3] = {0.f, 0.f, 0.f};
+        if (valid) load_point<D>(inp, in_sn, in_sd, pi, p);
+        const float pp = rpe_sqnorm<D>(p);
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+            const float d = rpe_pair_dist<D>(qs.qm2[j], qs.qq[j], p, pp);
+            const bool take = valid && (d < bd[j]);  // strict: first index wins inside a lane
+            bd[j] = take ? d : bd[j];
+            bi[j] = take ? pi : bi[j];
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(bd[j], off);
+            const int oi = __shfl_xor(bi[j], off);
+            const bool take = (od < bd[j]) || (od == bd[j] && oi < bi[j]);
+            bd[j] = take ? od : bd[j];
+            bi[j] = take ? oi : bi[j];
+        }
+        const int qi = qbase + j;
+        if (qi < Q && lane == 0) {
+            const int64_t o = (int64_t)b * Q + qi;
+            idx[o] = bi[j] == 0x7fffffff ? 0 : (int64_t)bi[j];
+            if (dist) dist[o] = bd[j];
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void sqdist_kernel(const float *__restrict__ a, int64_t a_sb, int64_t a_sn, int64_t a_sd,
+                                                     const float *__restrict__ p2, int64_t b_sb, int64_t b_sn, int64_t b_sd,
+                                                     int N1, int N2, float *__restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    const int b = blockIdx.z;
+    if (j >= N2) return;
+    float q[3], p[3], qm2[3];
+    load_point<D>(a + (int64_t)b * a_sb, a_sn, a_sd, i, q);
+    load_point<D>(p2 + (int64_t)b * b_sb, b_sn, b_sd, j, p);
+    const float qq = rpe_sqnorm<D>(q);
+    const float pp = rpe_sqnorm<D>(p);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) qm2[d] = -2.0f * q[d];
+    out[((int64_t)b * N1 + i) * N2 + j] = rpe_pair_dist<D>(qm2, qq, p, pp);
+}
+
+int pick_qw(int B, int Q) {
+    const long target = 2048;  // waves wanted in flight: 256 CUs x 4 SIMDs x 2
+    for (int qw = 8; qw > 1; qw >>= 1)
+        if ((long)B * ((Q + qw - 1) / qw) >= target) return qw;
+    return 1;
+}
+
+template <int D, int QW>
+void launch_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,
+                int64_t q_sn, int64_t q_sd, int B, int M, int Q, int k, int64_t *idx, float *dist, hipStream_t st) {
+    const int per_block = kWavesPerBlock * QW;
+    dim3 grid((Q + per_block - 1) / per_block, B), block(kWavesPerBlock * RPE_WAVE);
+    if (k == 1)
+        hipLaunchKernelGGL((knn_nearest_kernel<D, QW>), grid, block, 0, st, input, in_sb, in_sn, in_sd, query, q_sb,
+                           q_sn, q_sd, M, Q, idx, dist);
+    else
+        hipLaunchKernelGGL((knn_select_kernel<D, QW>), grid, block, 0, st, input, in_sb, in_sn, in_sd, query, q_sb,
+                           q_sn, q_sd, M, Q, k, idx, dist);
+}
+
+template <int D>
+void launch_knn_d(int qw, const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query,
+                  int64_t q_sb, int64_t q_sn, int64_t q_sd, int B, int M, int Q, int k, int64_t *idx, float *dist,
+                  hipStream_t st) {
+#define RPE_KNN_CASE(W)                                                                                       \
+    case W:                                                                                                   \
+        launch_knn<D, W>(input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, B, M, Q, k, idx, dist, st);     \
+        break;
+    switch (qw) {
+        RPE_KNN_CASE(1)
+        RPE_KNN_CASE(2)
+        RPE_KNN_CASE(4)
+        RPE_KNN_CASE(8)
+    }
+#undef RPE_KNN_CASE
+}
+
+}  // namespace
+
+RPE_API int rpe_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,
+                    int64_t q_sn, int64_t q_sd, int B, int M, int Q, int D, int k, int64_t *idx, float *dist,
+                    rpe_stream_t stream) {
+    if (!input || !query || !idx || B < 0 || M <= 0 || Q < 0 || D < 1 || D > 3) return RPE_EINVAL;
+    if (k < 1 || k > M) return RPE_EINVAL;
+    if (k > RPE_WAVE) return RPE_EUNSUPPORTED;
+    if (B > 65535) return RPE_EUNSUPPORTED;
+    if (B == 0 || Q == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int qw = pick_qw(B, Q);
+    if (D == 3)
+        launch_knn_d<3>(qw, input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, B, M, Q, k, idx, dist, st);
+    else if (D == 2)
+        launch_knn_d<2>(qw, input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, B, M, Q, k, idx, dist, st);
+    else
+        launch_knn_d<1>(qw, input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, B, M, Q, k, idx, dist, st);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_squared_distance(const float *xyz1, int64_t a_sb, int64_t a_sn, int64_t a_sd, const float *xyz2,
+                                 int64_t b_sb, int64_t b_sn, int64_t b_sd, int B, int N1, int N2, int D, float *out,
+                                 rpe_stream_t stream) {
+    if (!xyz1 || !xyz2 || !out || B < 0 || N1 < 0 || N2 < 0 || D < 1 || D > 3) return RPE_EINVAL;
+    if (B > 65535 || N1 > 65535) return RPE_EUNSUPPORTED;
+    if (B == 0 || N1 == 0 || N2 == 0) return 0;
+    dim3 grid((N2 + 255) / 256, N1, B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 3)
+        hipLaunchKernelGGL(sqdist_kernel<3>, grid, block, 0, st, xyz1, a_sb, a_sn, a_sd, xyz2, b_sb, b_sn, b_sd, N1, N2, out);
+    else if (D == 2)
+        hipLaunchKernelGGL(sqdist_kernel<2>, grid, block, 0, st, xyz1, a_sb, a_sn, a_sd, xyz2, b_sb, b_sn, b_sd, N1, N2, out);
+    else
+        hipLaunchKernelGGL(sqdist_kernel<1>, grid, block, 0, st, xyz1, a_sb, a_sn, a_sd, xyz2, b_sb, b_sn, b_sd, N1, N2, out);
+    return rpe_launch_status();
+}

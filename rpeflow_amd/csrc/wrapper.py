@@ -1,0 +1,148 @@
+"""Host side of the four operators -- mirrors models/csrc/wrapper.py:40-127.
+
+Same names, positional/keyword arguments, layout conventions and assertion
+behaviour as the reference wrapper.  Differences, all deliberate:
+
+* GPU tensors go to librpeflow_hip.so (C ABI, include/rpeflow_hip.h) on
+  PyTorch's current stream; CPU tensors and ``cpp_impl=False`` raise, because
+  this package ships no PyTorch/CPU path (the reference falls back to one,
+  wrapper.py:67,100,124).
+* Results equal the reference's *CPU fallback* (the parity oracle), not its
+  CUDA kernels, where those differ: matmul-form distances, "first maximum"
+  in FPS, index order inside KNN ties.
+* No layout copies: KNN reads either point layout through strides (the
+  reference transposes + copies, :119-122); correlation reads NCHW directly
+  (the reference permutes both inputs to NHWC, :68-69).
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+_NULL = ctypes.c_void_p(0)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _no_torch_path(op):
+    raise NotImplementedError(
+        f"{op}(cpp_impl=False): the pure-PyTorch path is not part of rpeflow_amd; "
+        "use the reference implementation for it")
+
+
+def _as_points(t, op, name):
+    """[B,N,D] view + element strides of a [B,N,D] or [B,D,N] tensor (wrapper.py:119)."""
+    if t.dim() != 3:
+        raise RuntimeError(f"{op}: {name} must be 3-dimensional")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{op}: {name} must be a float tensor")  # k_nearest_neighbor.cpp:9
+    return t
+
+
+def squared_distance(xyz1: torch.Tensor, xyz2: torch.Tensor):
+    """models/csrc/wrapper.py:40-52.  xyz1 [B,N1,D], xyz2 [B,N2,D], D<=3 -> [B,N1,N2]."""
+    assert xyz1.shape[-1] == xyz2.shape[-1] and xyz1.shape[-1] <= 3  # assert channel_last
+    _lib.require_gpu(xyz1, xyz2, op="squared_distance")
+    xyz1, xyz2 = xyz1.float(), xyz2.float()
+    B, N1, D = xyz1.shape
+    N2 = xyz2.shape[1]
+    out = torch.empty((B, N1, N2), dtype=torch.float32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        rc = _lib.lib().rpe_squared_distance(_ptr(xyz1), *xyz1.stride(), _ptr(xyz2), *xyz2.stride(),
+                                             B, N1, N2, D, _ptr(out), _lib.stream_of(xyz1))
+    _lib.check(rc, "squared_distance")
+    return out
+
+
+def correlation2d(input1: torch.Tensor, input2: torch.Tensor, max_displacement: int, cpp_impl=True):
+    """models/csrc/wrapper.py:55-72.  NCHW in, [B,(2md+1)^2,H,W] out; forward only."""
+    if not cpp_impl:
+        _no_torch_path("correlation2d")
+    _lib.require_gpu(input1, input2, op="correlation2d")
+    assert input1.shape == input2.shape and input1.dim() == 4
+    input1 = input1.contiguous().float()
+    input2 = input2.contiguous().float()
+    B, C, H, W = input1.shape
+    n = 2 * int(max_displacement) + 1
+    out = torch.empty((B, n * n, H, W), dtype=torch.float32, device=input1.device)
+    with torch.cuda.device(input1.device):
+        rc = _lib.lib().rpe_correlation2d_forward(_ptr(input1), _ptr(input2), B, C, H, W, int(max_displacement),
+                                                  0.0, 0, _ptr(out), _lib.stream_of(input1))
+    _lib.check(rc, "correlation2d")
+    return out
+
+
+def furthest_point_sampling(xyz: torch.Tensor, n_samples: int, cpp_impl=True):
+    """models/csrc/wrapper.py:75-103.  xyz [B,N,3] -> int64 [B,n_samples]."""
+    assert xyz.shape[2] == 3 and xyz.shape[1] > n_samples
+    if not cpp_impl:
+        _no_torch_path("furthest_point_sampling")
+    _lib.require_gpu(xyz, op="furthest_point_sampling")
+    if xyz.dtype != torch.float32:
+        raise RuntimeError("points_xyz must be a float tensor")  # furthest_point_sampling.cpp:8
+    B, N, _ = xyz.shape
+    idx = torch.empty((B, n_samples), dtype=torch.int64, device=xyz.device)
+    with torch.cuda.device(xyz.device):
+        rc = _lib.lib().rpe_fps(_ptr(xyz), *xyz.stride(), B, N, int(n_samples), _ptr(idx), _lib.stream_of(xyz))
+    _lib.check(rc, "furthest_point_sampling")
+    return idx
+
+
+def k_nearest_neighbor(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cpp_impl=True):
+    """models/csrc/wrapper.py:106-127.  Points as [B,N,D] or [B,D,N] (D<=3) -> int64 [B,Q,k]."""
+    _as_points(input_xyz, "k_nearest_neighbor", "input_xyz")
+    _as_points(query_xyz, "k_nearest_neighbor", "query_xyz")
+    if input_xyz.shape[1] <= 3:  # channel_first to channel_last (a view; the kernel takes strides)
+        assert query_xyz.shape[1] == input_xyz.shape[1]
+        input_xyz = input_xyz.transpose(1, 2)
+        query_xyz = query_xyz.transpose(1, 2)
+    if not cpp_impl:
+        _no_torch_path("k_nearest_neighbor")
+    _lib.require_gpu(input_xyz, query_xyz, op="k_nearest_neighbor")
+    B, M, D = input_xyz.shape
+    Q = query_xyz.shape[1]
+    if query_xyz.shape[0] != B or query_xyz.shape[2] != D:
+        raise RuntimeError("k_nearest_neighbor: input_xyz and query_xyz disagree in batch or dimension")
+    if k > M:
+        raise RuntimeError("selected index k out of range")  # what the fallback's topk raises
+    idx = torch.empty((B, Q, k), dtype=torch.int64, device=input_xyz.device)
+    with torch.cuda.device(input_xyz.device):
+        rc = _lib.lib().rpe_knn(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(),
+                                B, M, Q, D, int(k), _ptr(idx), _NULL, _lib.stream_of(input_xyz))
+    _lib.check(rc, "k_nearest_neighbor")
+    return idx
+
+
+def k_nearest_neighbor_with_distances(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int):
+    """k_nearest_neighbor plus the sorted squared distances the kernel selected on
+    (what ``squared_distance(query, input).topk(k, largest=False).values`` holds)."""
+    if input_xyz.shape[1] <= 3:
+        input_xyz, query_xyz = input_xyz.transpose(1, 2), query_xyz.transpose(1, 2)
+    _lib.require_gpu(input_xyz, query_xyz, op="k_nearest_neighbor")
+    B, M, D = input_xyz.shape
+    Q = query_xyz.shape[1]
+    idx = torch.empty((B, Q, k), dtype=torch.int64, device=input_xyz.device)
+    dist = torch.empty((B, Q, k), dtype=torch.float32, device=input_xyz.device)
+    with torch.cuda.device(input_xyz.device):
+        rc = _lib.lib().rpe_knn(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(),
+                                B, M, Q, D, int(k), _ptr(idx), _ptr(dist), _lib.stream_of(input_xyz))
+    _lib.check(rc, "k_nearest_neighbor")
+    return idx, dist
+
+
+def _correlation2d_algo(input1, input2, max_displacement, algo, leaky_slope=0.0):
+    """correlation2d with an explicit kernel choice (1 direct, 2 MFMA) and the optional
+    fused leaky_relu of RPEFlow_core.py:362; used by tests and bench."""
+    _lib.require_gpu(input1, input2, op="correlation2d")
+    input1, input2 = input1.contiguous().float(), input2.contiguous().float()
+    B, C, H, W = input1.shape
+    n = 2 * int(max_displacement) + 1
+    out = torch.empty((B, n * n, H, W), dtype=torch.float32, device=input1.device)
+    with torch.cuda.device(input1.device):
+        rc = _lib.lib().rpe_correlation2d_forward(_ptr(input1), _ptr(input2), B, C, H, W, int(max_displacement),
+                                                  float(leaky_slope), int(algo), _ptr(out), _lib.stream_of(input1))
+    _lib.check(rc, "correlation2d")
+    return out

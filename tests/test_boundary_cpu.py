@@ -1,0 +1,76 @@
+"""CPU: the C-ABI library loads, exports every symbol include/rpeflow_hip.h declares,
+and the operator wrappers keep the reference's interface and refuse to run off-GPU."""
+import ctypes
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+from rpeflow_amd import _lib, build
+import rpeflow_amd.csrc as ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rpeflow_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rpe_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    build.build()
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert "rpe_knn" in names and "rpe_fps" in names and "rpe_correlation2d_forward" in names
+    for name in names:
+        assert hasattr(handle, name), f"{name} declared in rpeflow_hip.h but not exported"
+
+
+def test_ctypes_prototypes_cover_the_header():
+    assert set(_lib._PROTOTYPES) | {"rpe_error_string"} == set(declared_symbols())
+    assert _lib.lib().rpe_abi_version() == 1
+    assert _lib.lib().rpe_error_string(-1).decode().startswith("rpeflow_hip")
+
+
+def test_same_public_names_and_signatures_as_reference():
+    # models/csrc/__init__.py:1 and wrapper.py:40,55,75,106
+    assert ops.__all__ == ["correlation2d", "furthest_point_sampling", "squared_distance", "k_nearest_neighbor"]
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(ops.squared_distance) == ["xyz1", "xyz2"]
+    assert sig(ops.correlation2d) == ["input1", "input2", "max_displacement", "cpp_impl"]
+    assert sig(ops.furthest_point_sampling) == ["xyz", "n_samples", "cpp_impl"]
+    assert sig(ops.k_nearest_neighbor) == ["input_xyz", "query_xyz", "k", "cpp_impl"]
+
+
+def test_no_cpu_fallback():
+    x = torch.rand(1, 10, 3)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.k_nearest_neighbor(input_xyz=x, query_xyz=x, k=2)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.furthest_point_sampling(x, 4)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.squared_distance(x, x)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ops.correlation2d(torch.rand(1, 2, 4, 4), torch.rand(1, 2, 4, 4), 1)
+    with pytest.raises(NotImplementedError):
+        ops.k_nearest_neighbor(x, x, 2, cpp_impl=False)
+
+
+def test_reference_assertions_kept():
+    x = torch.rand(1, 10, 3)
+    with pytest.raises(AssertionError):  # wrapper.py:98
+        ops.furthest_point_sampling(x, 10)
+    with pytest.raises(AssertionError):  # wrapper.py:47
+        ops.squared_distance(torch.rand(1, 4, 4), torch.rand(1, 4, 4))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "rpeflow_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("parity oracle", ""), f"{f} mentions the oracle"

@@ -1,0 +1,216 @@
+"""GPU parity tests for the four operators of models/csrc/__init__.py:1.
+Every test calls the HIP kernels through the C ABI (rpeflow_amd.csrc -> ctypes ->
+librpeflow_hip.so) and checks against the CPU oracle and the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import cases as K
+from tests import inputs as I
+from tests.check import assert_bits_equal, assert_knn_tie_aware
+
+pytestmark = pytest.mark.gpu
+
+import rpeflow_amd.csrc as ops  # noqa: E402
+from rpeflow_amd import _lib  # noqa: E402
+from rpeflow_amd.csrc import wrapper as W  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def G(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_library_is_loaded_from_tree():
+    assert os.path.exists(_lib.LIB_PATH)
+    assert _lib.lib().rpe_abi_version() == 1
+
+
+def test_mfma_4x4x1_layout_probe():
+    """The correlation kernel assumes: A lane 4g+i, B lane 4g+j -> D register i, lane 4g+j."""
+    out = torch.zeros(256, device=DEV)
+    _lib.check(_lib.lib().rpe_probe_mfma4x4(out.data_ptr(), None), "probe")
+    d = out.cpu().numpy().reshape(64, 4)
+    lane = np.arange(64)
+    g, j = lane // 4, lane % 4
+    expect = (4 * g[:, None] + np.arange(4)[None, :]) * (100.0 * (4 * g + j))[:, None]
+    assert np.array_equal(d, expect.astype(np.float32)), d[:8]
+
+
+# ---------------------------------------------------------------- squared_distance
+@pytest.mark.parametrize("name", list(K.SQDIST_CASES))
+def test_squared_distance(golden_dir, name):
+    a, b = K.sqdist_inputs(name)
+    out = ops.squared_distance(dev(a), dev(b)).cpu().numpy()
+    assert_bits_equal(out, O.squared_distance(a, b), name + " vs oracle")
+    assert_bits_equal(out, G(golden_dir, name)["dist"], name + " vs reference golden")
+
+
+# ---------------------------------------------------------------- k_nearest_neighbor
+@pytest.mark.parametrize("name", list(K.KNN_CASES))
+def test_knn_golden_cases(golden_dir, name):
+    inp, qry, k = K.knn_inputs(name)
+    idx, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True)
+    assert np.array_equal(idx, oi), f"{name}: {(idx != oi).sum()} indices differ from the oracle"
+    assert_bits_equal(dist, od, name + " distances vs oracle")
+    g = G(golden_dir, name)
+    assert_knn_tie_aware(idx, dist, g["idx"], g["dist"], g["next_dist"], name + " vs reference golden")
+    # public entry point, both layouts (wrapper.py:119-122)
+    assert np.array_equal(ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy(), oi)
+    if inp.shape[1] > 3:
+        cf = ops.k_nearest_neighbor(input_xyz=dev(inp.transpose(0, 2, 1)), query_xyz=dev(qry.transpose(0, 2, 1)), k=k)
+        assert np.array_equal(cf.cpu().numpy(), oi)
+
+
+@pytest.mark.parametrize("B,M,Q,D,k", [
+    (1, 5, 1, 3, 5), (3, 64, 65, 3, 16), (2, 63, 129, 2, 1), (1, 65, 7, 3, 64), (2, 129, 33, 1, 3),
+    (1, 1000, 3, 3, 33), (5, 200, 1, 2, 2), (1, 4096, 256, 3, 16), (4, 256, 256, 3, 16), (2, 512, 2160, 2, 1),
+])
+def test_knn_ragged_shapes(B, M, Q, D, k):
+    r = I.rng(7000 + M + Q + k)
+    inp, qry = I.ids_cloud(r, B, M, D), I.ids_cloud(r, B, Q, D)
+    idx, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k)
+    oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert_bits_equal(dist.cpu().numpy(), od)
+
+
+def test_knn_duplicates_and_strided_views():
+    r = I.rng(7100)
+    base = I.unit_cloud(r, 2, 150, 3)
+    inp = np.concatenate([base, base, base[:, :40]], axis=1)  # every point 2-3 times: ties everywhere
+    qry = base[:, ::3]
+    idx, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), 8)
+    oi, od = O.k_nearest_neighbor(inp, qry, 8, return_dists=True)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    # non-contiguous prefix view of a channel-first tensor, as build_pc_pyramid makes (pwc3d_core.py:25)
+    cf = dev(inp.transpose(0, 2, 1))
+    sub = cf[:, :, :200]
+    assert not sub.is_contiguous()
+    got = ops.k_nearest_neighbor(sub, dev(qry.transpose(0, 2, 1)), 8).cpu().numpy()
+    assert np.array_equal(got, O.k_nearest_neighbor(inp[:, :200], qry, 8))
+
+
+def test_knn_self_query_full_size_property():
+    """BASELINE size (8192 x 8192, k=16): checked through size-independent properties --
+    row 0 is the query itself wherever its self-distance is the unique minimum, distances
+    ascend, and a random sample of rows equals the oracle."""
+    r = I.rng(7200)
+    pts = I.ids_cloud(r, 2, 8192, 3)
+    idx, dist = W.k_nearest_neighbor_with_distances(dev(pts), dev(pts), 16)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert (np.diff(dist, axis=-1) >= 0).all()
+    assert idx.min() >= 0 and idx.max() < 8192
+    assert all(len(set(row)) == 16 for row in idx[0, :512])
+    rows = r.choice(8192, 300, replace=False)
+    oi, od = O.k_nearest_neighbor(pts, pts[:, rows], 16, return_dists=True)
+    assert np.array_equal(idx[:, rows], oi)
+    assert_bits_equal(dist[:, rows], od)
+
+
+def test_knn_errors():
+    x = torch.rand(1, 10, 3, device=DEV)
+    with pytest.raises(RuntimeError):  # fallback's topk: k > M
+        ops.k_nearest_neighbor(x, x, 11)
+    with pytest.raises(RuntimeError):  # k_nearest_neighbor.cpp:9
+        ops.k_nearest_neighbor(x.double(), x.double(), 2)
+
+
+# ---------------------------------------------------------------- furthest_point_sampling
+@pytest.mark.parametrize("name", list(K.FPS_CASES))
+def test_fps_golden_cases(golden_dir, name):
+    xyz, S = K.fps_inputs(name)
+    got = ops.furthest_point_sampling(dev(xyz), S).cpu().numpy()
+    assert got.dtype == np.int64
+    assert np.array_equal(got, O.furthest_point_sampling(xyz, S)), name + " vs oracle"
+    assert np.array_equal(got, G(golden_dir, name)["idx"]), name + " vs reference golden"
+
+
+@pytest.mark.parametrize("B,N,S", [(1, 2, 1), (2, 65, 64), (3, 1023, 100), (1, 1025, 1024), (2, 3000, 700), (1, 9000, 50), (1, 20000, 40)])
+def test_fps_ragged_shapes(B, N, S):
+    xyz = I.ids_cloud(I.rng(8000 + N), B, N)
+    got = ops.furthest_point_sampling(dev(xyz), S).cpu().numpy()
+    assert np.array_equal(got, O.furthest_point_sampling(xyz, S))
+
+
+def test_fps_transposed_view_as_the_model_passes_it():
+    """build_pc_pyramid hands over pc.transpose(1, 2) of a channel-first cloud (pwc3d_core.py:13)."""
+    xyz = I.ids_cloud(I.rng(8100), 4, 8192)
+    cf = dev(xyz.transpose(0, 2, 1))
+    got = ops.furthest_point_sampling(cf.transpose(1, 2), 4096).cpu().numpy()
+    assert np.array_equal(got, O.furthest_point_sampling(xyz, 4096))
+    # property at full size: samples are distinct, and every prefix is the FPS of that length
+    assert all(len(set(row)) == 4096 for row in got)
+
+
+# ---------------------------------------------------------------- correlation2d
+@pytest.mark.parametrize("name", list(K.CORR_CASES))
+def test_correlation_golden_cases(golden_dir, name):
+    a, b, md = K.corr_inputs(name)
+    ref = G(golden_dir, name)["out"]
+    algos = [1, 2] if md == 4 else [1]
+    for algo in algos:
+        out = W._correlation2d_algo(dev(a), dev(b), md, algo).cpu().numpy()
+        assert out.shape == ref.shape
+        # correlation_test.cpp:82-83: mean |diff| < 1e-6; plus a worst-element bound
+        assert np.abs(out - ref).mean() < 1e-6, (name, algo)
+        assert np.abs(out - ref).max() < 5e-6, (name, algo)
+        assert np.abs(out - O.correlation2d(a, b, md)).max() < 5e-6, (name, algo)
+    out = ops.correlation2d(dev(a), dev(b), md).cpu().numpy()
+    assert np.abs(out - ref).max() < 5e-6
+
+
+@pytest.mark.parametrize("B,C,H,W", [(1, 3, 5, 7), (2, 33, 17, 65), (1, 16, 9, 15), (4, 192, 9, 15), (1, 64, 70, 130), (2, 5, 8, 64)])
+def test_correlation_ragged_shapes(B, C, H, W):
+    r = I.rng(9000 + C + H + W)
+    a, b = I.feature_map(r, B, C, H, W), I.feature_map(r, B, C, H, W)
+    ref = O.correlation2d(a, b, 4)
+    out = torch.full((B, 81, H, W), float("nan"), device=DEV)  # every element must be written
+    for algo in (1, 2):
+        out.fill_(float("nan"))
+        got = W._correlation2d_algo(dev(a), dev(b), 4, algo).cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() < 5e-6, algo
+
+
+def test_correlation_fused_leaky_relu():
+    r = I.rng(9100)
+    a, b = I.feature_map(r, 2, 32, 18, 30), I.feature_map(r, 2, 32, 18, 30)
+    ref = torch.nn.functional.leaky_relu(torch.from_numpy(O.correlation2d(a, b, 4)), 0.1).numpy()  # RPEFlow_core.py:362
+    for algo in (1, 2):
+        got = W._correlation2d_algo(dev(a), dev(b), 4, algo, leaky_slope=0.1).cpu().numpy()
+        assert np.abs(got - ref).max() < 5e-6
+
+
+def test_correlation_full_size_properties():
+    """BASELINE microbench size 1x256x544x960: linearity in in1, zero borders, and the centre
+    plane equals the per-pixel channel mean of in1*in2 computed by torch on the GPU."""
+    torch.manual_seed(0)
+    a = torch.randn(1, 256, 544, 960, device=DEV)
+    b = torch.randn(1, 256, 544, 960, device=DEV)
+    out = ops.correlation2d(a, b, 4)
+    assert out.shape == (1, 81, 544, 960)
+    centre = (a * b).mean(1)
+    assert (out[:, 40] - centre).abs().max().item() < 2e-5
+    # plane (dy=-4,dx=-4): rows 0..3 and cols 0..3 read outside the image -> exactly 0
+    assert out[:, 0, :4].abs().max().item() == 0.0 and out[:, 0, :, :4].abs().max().item() == 0.0
+    assert out[:, 80, -4:].abs().max().item() == 0.0 and out[:, 80, :, -4:].abs().max().item() == 0.0
+    # shifted plane against torch: dy=+2, dx=-3 -> plane (2+4)*9 + (-3+4)
+    sh = (a[:, :, :-2, 3:] * b[:, :, 2:, :-3]).mean(1)
+    assert (out[:, 55, :-2, 3:] - sh).abs().max().item() < 2e-5
+    out2 = ops.correlation2d(2.0 * a, b, 4)
+    assert torch.equal(out2, 2.0 * out)
+    # both kernels agree on a crop
+    d = W._correlation2d_algo(a[:, :, :64, :128].contiguous(), b[:, :, :64, :128].contiguous(), 4, 1)
+    m = W._correlation2d_algo(a[:, :, :64, :128].contiguous(), b[:, :, :64, :128].contiguous(), 4, 2)
+    assert (d - m).abs().max().item() < 5e-6

@@ -1,0 +1,56 @@
+"""Per-operator timings on one MI355X (torch.cuda events on the launch stream).
+Usage: python tools/microbench.py [corr] [knn] [fps]   -> prints one line per case."""
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import rpeflow_amd.csrc as ops
+from rpeflow_amd.csrc import wrapper as W
+
+
+def timeit(fn, warmup=3, iters=10):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def main():
+    which = sys.argv[1:] or ["corr", "knn", "fps"]
+    dev = "cuda:0"
+    torch.manual_seed(0)
+    if "corr" in which:
+        a = torch.randn(1, 256, 544, 960, device=dev)
+        b = torch.randn(1, 256, 544, 960, device=dev)
+        alg_bytes = 2 * a.numel() * 4 + 81 * 544 * 960 * 4
+        for algo in (2,):
+            us = timeit(lambda: W._correlation2d_algo(a, b, 4, algo))
+            print(f"corr algo={algo} 1x256x544x960: {us:9.1f} us  {alg_bytes / us / 1e6:7.3f} TB/s algorithmic  ({alg_bytes / us / 1e6 / 8.0:.3f} of 8 TB/s)")
+        for (B, C, H, Wd) in [(4, 32, 144, 240), (4, 64, 72, 120), (4, 96, 36, 60), (4, 128, 18, 30), (4, 192, 9, 15)]:
+            x, y = torch.randn(B, C, H, Wd, device=dev), torch.randn(B, C, H, Wd, device=dev)
+            us = timeit(lambda: ops.correlation2d(x, y, 4))
+            print(f"corr model {B}x{C}x{H}x{Wd}: {us:9.1f} us")
+    if "knn" in which:
+        for (B, M, Q, D, k) in [(4, 8192, 4096, 3, 16), (4, 4096, 4096, 3, 16), (4, 4096, 34560, 2, 1), (4, 2048, 8640, 2, 1),
+                                (4, 4096, 4096, 3, 3), (4, 2048, 4096, 3, 3), (4, 256, 256, 3, 16), (4, 8192, 8192, 3, 16)]:
+            p = torch.rand(B, D, M, device=dev) * 30
+            q = torch.rand(B, D, Q, device=dev) * 30
+            us = timeit(lambda: ops.k_nearest_neighbor(p, q, k))
+            print(f"knn B={B} M={M} Q={Q} D={D} k={k}: {us:9.1f} us  {B * M * Q / us / 1e3:8.2f} Gpair/s")
+    if "fps" in which:
+        for (B, N, S) in [(8, 8192, 4096), (2, 8192, 4096), (8, 4096, 1024)]:
+            p = (torch.rand(B, 3, N, device=dev) * 30).transpose(1, 2)
+            us = timeit(lambda: ops.furthest_point_sampling(p, S), warmup=1, iters=3)
+            print(f"fps B={B} N={N} S={S}: {us:9.1f} us  {us / S:6.3f} us/sample")
+
+
+if __name__ == "__main__":
+    main()
