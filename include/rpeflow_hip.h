@@ -84,6 +84,59 @@ int rpe_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
 int rpe_correlation2d_forward(const float *in1, const float *in2, int B, int C, int H, int W, int md,
                               float leaky_slope, int algo, float *out, rpe_stream_t stream);
 
+/* ---- batch_indexing_channel_first / _last (models/utils.py:119-137, 101-116) ---
+ * out[b][c][i] = data[b][c][idx[b][i]]   (data[b][c][n] = data[b*sb + c*sc + n*sn], out [B,C,I] contiguous)
+ * out[b][i][c] = data[b][idx[b][i]][c]   (data[b][n][c] = data[b*sb + n*sn + c*sc], out [B,I,C] contiguous)
+ * idx [B,I] int64 contiguous (callers flatten [B,I1,..,Im]).                     */
+int rpe_gather_channel_first(const float *data, int64_t sb, int64_t sc, int64_t sn, const int64_t *idx,
+                             int B, int C, int N, int I, float *out, rpe_stream_t stream);
+int rpe_gather_channel_last(const float *data, int64_t sb, int64_t sn, int64_t sc, const int64_t *idx,
+                            int B, int C, int N, int I, float *out, rpe_stream_t stream);
+
+/* ---- knn_interpolation after its KNN (models/utils.py:148-154) ------------------
+ * w_j = 1/max(||in_xyz[:,knn_j] - q_xyz||_2, 1e-8), normalised over the k neighbours;
+ * out[b][c][q] = sum_j (scale*feat[b][c][knn_j]) * w_j.  scale = -1 gives backwarp_3d's
+ * "-flow12" features (utils.py:166-167) without a negation pass.
+ * Point/feature tensors channel-first through strides (sb, channel stride, point stride);
+ * knn [B,Q,*] int64 with row stride knn_row_stride >= k; out [B,C,Q] contiguous. k <= 8. */
+int rpe_knn_interpolate(const float *in_xyz, int64_t x_sb, int64_t x_sd, int64_t x_sn,
+                        const float *feat, int64_t f_sb, int64_t f_sc, int64_t f_sn,
+                        const float *q_xyz, int64_t q_sb, int64_t q_sd, int64_t q_sn,
+                        const int64_t *knn, int64_t knn_row_stride,
+                        int B, int M, int Q, int C, int k, float scale, float *out, rpe_stream_t stream);
+
+/* ---- bilinear sampling: backwarp_2d and grid_sample_wrapper ---------------------
+ * (models/utils.py:186-198 and 288-294, i.e. F.grid_sample(bilinear, align_corners=True)
+ * after the callers' 2*g/(S-1)-1 normalisation, restated as in ATen's CPU kernel.)
+ * feat [B,C,H,W] contiguous; coordinates xy[b][d][p] = xy[b*xy_sb + d*xy_sd + p*xy_sp], d=0:x, 1:y.
+ * add_pixel_grid=1, border=1, P=H*W: backwarp_2d(feat, flow=xy, 'border').
+ * add_pixel_grid=0, border=0:         grid_sample_wrapper(feat, xy) (padding 'zeros').
+ * out [B,C,P] contiguous.                                                           */
+int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W,
+                        const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sp, int P,
+                        int add_pixel_grid, int border, float *out, rpe_stream_t stream);
+
+/* ---- project_feat_with_nn_corr (models/utils.py:297-317) -------------------------
+ * For pixel p with nearest projected point i = nn_idx[b][p]:
+ *   out[b][0:2][p] = xy[b][:,i] - (p%W, p/W);  out[b][2][p] = mean_c(sample(feat_2d, xy_i)[c]*feat_2d[b][c][p]);
+ *   out[b][3+c][p] = feat_3d[b][c][i].   feat_2d [B,C2,H,W] contiguous, out [B,C3+3,H,W]. */
+int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
+                             const float *feat_2d, int C2, int H, int W,
+                             const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
+                             const int64_t *nn_idx, int B, int N, float *out, rpe_stream_t stream);
+
+/* ---- PointConv grouping (models/pointconv.py:48-57 and 107-118) ------------------
+ * out[b][q][w*CF+c] = sum_{j<16} wn_j[w] * feats_cl[b][knn[b][q][j]][c],
+ * wn_j = leaky(W2 leaky(W1 (xyz[:,knn_j]-q_xyz[:,q]) + b1) + b2), W1 [8,3], W2 [16,8]
+ * (weight_net = MLP2d(3,[8,16]), pointconv.py:12).  feats_cl [B,M,CF] contiguous is
+ * cat([xyz, features]) channel-last (pointconv.py:43-44), CF = C+3 <= 256.
+ * The nn.Linear / norm / activation that follow stay with the caller.               */
+int rpe_pointconv_group(const float *xyz, int64_t x_sb, int64_t x_sd, int64_t x_sn,
+                        const float *q_xyz, int64_t q_sb, int64_t q_sd, int64_t q_sn,
+                        const float *feats_cl, const int64_t *knn, int64_t knn_row_stride,
+                        const float *w1, const float *b1, const float *w2, const float *b2, float leaky_slope,
+                        int B, int M, int Q, int CF, float *out, rpe_stream_t stream);
+
 /* ---- diagnostics -------------------------------------------------------------
  * Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation
  * kernel relies on: out[64*4] = D for A[lane]=lane, B[lane]=100*lane (one K).   */

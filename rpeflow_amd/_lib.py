@@ -28,6 +28,16 @@ _PROTOTYPES = {
     "rpe_correlation2d_forward": [_c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_float, _c_int, _c_ptr, _c_ptr],
     "rpe_probe_mfma4x4": [_c_ptr, _c_ptr],
+    "rpe_gather_channel_first": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
+    "rpe_gather_channel_last": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
+    "rpe_knn_interpolate": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
+                            _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
+    "rpe_bilinear_sample": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
+                            _c_int, _c_int, _c_ptr, _c_ptr],
+    "rpe_project_feat_nn_corr": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int,
+                                 _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr],
+    "rpe_pointconv_group": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64,
+                            _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
 }
 
 _lib = None

@@ -1,0 +1,242 @@
+// Gather / interpolation / sampling glue of models/utils.py as single kernels.
+//
+// The reference composes each of these from 3-10 PyTorch kernels with expanded
+// int64 index tensors (utils.py:133-135) and a normalise/denormalise round trip
+// through F.grid_sample (utils.py:186-198, 288-294).  Here every op is one launch,
+// indices are read once per output row, and lanes always walk the contiguous
+// output dimension so stores are coalesced; gathered reads hit L2 (the sources
+// are a few MB at most).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+// out[b][c][i] = data[b][c][idx[b][i]]           (batch_indexing_channel_first, utils.py:119-137)
+__global__ __launch_bounds__(256) void gather_cf_kernel(const float *__restrict__ data, int64_t sb, int64_t sc, int64_t sn,
+                                                        const int64_t *__restrict__ idx, int C, int N, int I, int c_per_block,
+                                                        float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.z;
+    if (i >= I) return;
+    const int64_t src = idx[(int64_t)b * I + i];
+    const int c0 = blockIdx.y * c_per_block, c1 = min(C, c0 + c_per_block);
+    const float *d = data + (int64_t)b * sb + src * sn;
+    float *o = out + ((int64_t)b * C) * I + i;
+    for (int c = c0; c < c1; ++c) o[(int64_t)c * I] = d[(int64_t)c * sc];
+}
+
+// out[b][i][c] = data[b][idx[b][i]][c]           (batch_indexing_channel_last, utils.py:101-116)
+__global__ __launch_bounds__(256) void gather_cl_kernel(const float *__restrict__ data, int64_t sb, int64_t sn, int64_t sc,
+                                                        const int64_t *__restrict__ idx, int C, int I,
+                                                        float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (e >= (int64_t)I * C) return;
+    const int i = (int)(e / C), c = (int)(e % C);
+    const int64_t src = idx[(int64_t)b * I + i];
+    out[(int64_t)b * I * C + e] = data[(int64_t)b * sb + src * sn + (int64_t)c * sc];
+}
+
+// knn_interpolation (utils.py:140-156) after the KNN: inverse-distance weights of the
+// k neighbours, w_j = 1/max(||p_j - q||_2, 1e-8), normalised, weighted feature sum.
+template <int KMAX>
+__global__ __launch_bounds__(256) void knn_interp_kernel(const float *__restrict__ in_xyz, int64_t x_sb, int64_t x_sd, int64_t x_sn,
+                                                         const float *__restrict__ feat, int64_t f_sb, int64_t f_sc, int64_t f_sn,
+                                                         const float *__restrict__ q_xyz, int64_t q_sb, int64_t q_sd, int64_t q_sn,
+                                                         const int64_t *__restrict__ knn, int64_t k_sq, int k, int C, int Q,
+                                                         float negate, float *__restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (q >= Q) return;
+    const float *xb = in_xyz + (int64_t)b * x_sb, *qb = q_xyz + (int64_t)b * q_sb;
+    const float qx = qb[q * q_sn], qy = qb[q_sd + q * q_sn], qz = qb[2 * q_sd + q * q_sn];
+    int64_t id[KMAX];
+    float w[KMAX];
+    float wsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        if (j < k) {
+            id[j] = knn[((int64_t)b * Q + q) * k_sq + j];
+            const float dx = xb[id[j] * x_sn] - qx, dy = xb[x_sd + id[j] * x_sn] - qy, dz = xb[2 * x_sd + id[j] * x_sn] - qz;
+            float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            d = fmaxf(d, 1e-8f);
+            w[j] = 1.0f / d;
+            wsum += w[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+        if (j < k) w[j] = w[j] / wsum;
+    const float *fb = feat + (int64_t)b * f_sb;
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j)
+            if (j < k) s += (negate * fb[(int64_t)c * f_sc + id[j] * f_sn]) * w[j];
+        out[((int64_t)b * C + c) * Q + q] = s;
+    }
+}
+
+// ATen CPU grid_sample un-normalisation after the callers' own normalisation:
+//   gn = 2*g/(S-1) - 1 (utils.py:189-190, 290-291);  u = (gn+1) * ((S-1)/2);  border: clamp to [0,S-1]
+__device__ __forceinline__ float unnormalise(float g, int S, bool border) {
+    const float gn = 2.0f * g / (float)(S - 1) - 1.0f;
+    float u = (gn + 1.0f) * ((float)(S - 1) / 2.0f);
+    if (border) {
+        u = (u > 0.0f) ? u : 0.0f;  // NaN -> 0 like clamp_min's operand order
+        u = fminf(u, (float)(S - 1));
+    }
+    return u;
+}
+
+struct Bilinear {
+    int o_nw, o_ne, o_sw, o_se;  // offsets inside one H*W plane, -1 = outside the image
+    float w_nw, w_ne, w_sw, w_se;
+    __device__ __forceinline__ void setup(float gx, float gy, int H, int W, bool border) {
+        const float u = unnormalise(gx, W, border), v = unnormalise(gy, H, border);
+        const float fx = floorf(u), fy = floorf(v);
+        const float w = u - fx, e = 1.0f - w, n = v - fy, s = 1.0f - n;
+        w_nw = s * e; w_ne = s * w; w_sw = n * e; w_se = n * w;
+        const bool ok_x = fx >= -2.0f && fx <= (float)W + 1.0f, ok_y = fy >= -2.0f && fy <= (float)H + 1.0f;
+        const int ix = ok_x ? (int)fx : -2, iy = ok_y ? (int)fy : -2;
+        const bool in_w = ix >= 0 && ix < W, in_e = ix + 1 >= 0 && ix + 1 < W;
+        const bool in_n = iy >= 0 && iy < H, in_s = iy + 1 >= 0 && iy + 1 < H;
+        o_nw = (in_n && in_w) ? iy * W + ix : -1;
+        o_ne = (in_n && in_e) ? iy * W + ix + 1 : -1;
+        o_sw = (in_s && in_w) ? (iy + 1) * W + ix : -1;
+        o_se = (in_s && in_e) ? (iy + 1) * W + ix + 1 : -1;
+    }
+    __device__ __forceinline__ float sample(const float *plane) const {
+        const float v_nw = o_nw >= 0 ? plane[o_nw] : 0.f, v_ne = o_ne >= 0 ? plane[o_ne] : 0.f;
+        const float v_sw = o_sw >= 0 ? plane[o_sw] : 0.f, v_se = o_se >= 0 ? plane[o_se] : 0.f;
+        float acc = v_nw * w_nw + v_ne * w_ne;
+        acc = acc + v_sw * w_sw;
+        acc = acc + v_se * w_se;
+        return acc;
+    }
+};
+
+// out[b][c][p] = bilinear(feat[b][c], (gx,gy)[b][p]);  add_grid: coordinates are
+// pixel (p % W, p / W) + flow  (backwarp_2d, utils.py:186-198); otherwise xy as given
+// (grid_sample_wrapper, utils.py:288-294).
+__global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__ feat, int C, int H, int W,
+                                                       const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sp,
+                                                       int P, int add_grid, int border, int c_per_block,
+                                                       float *__restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.z;
+    if (p >= P) return;
+    float gx = xy[(int64_t)b * xy_sb + (int64_t)p * xy_sp];
+    float gy = xy[(int64_t)b * xy_sb + xy_sd + (int64_t)p * xy_sp];
+    if (add_grid) {
+        gx = (float)(p % W) + gx;
+        gy = (float)(p / W) + gy;
+    }
+    Bilinear bl;
+    bl.setup(gx, gy, H, W, border != 0);
+    const int64_t HW = (int64_t)H * W;
+    const int c0 = blockIdx.y * c_per_block, c1 = min(C, c0 + c_per_block);
+    for (int c = c0; c < c1; ++c) out[((int64_t)b * C + c) * P + p] = bl.sample(feat + ((int64_t)b * C + c) * HW);
+}
+
+// project_feat_with_nn_corr (utils.py:297-317), one thread per pixel p with nearest point i:
+//   out[0:2] = xy_i - pixel, out[2] = mean_c(sample(feat_2d, xy_i)[c] * feat_2d[c][p]), out[3:] = feat_3d[:, i]
+__global__ __launch_bounds__(256) void project_feat_kernel(const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
+                                                           const float *__restrict__ feat2d, int C2, int H, int W,
+                                                           const float *__restrict__ feat3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn,
+                                                           int C3, const int64_t *__restrict__ nn, float *__restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    if (p >= HW) return;
+    const int64_t i = nn[(int64_t)b * HW + p];
+    const float px = xy[(int64_t)b * xy_sb + i * xy_sn], py = xy[(int64_t)b * xy_sb + xy_sd + i * xy_sn];
+    float *o = out + (int64_t)b * (C3 + 3) * HW + p;
+    o[0] = px - (float)(p % W);
+    o[HW] = py - (float)(p / W);
+    Bilinear bl;
+    bl.setup(px, py, H, W, false);
+    const float *f2 = feat2d + (int64_t)b * C2 * HW;
+    float s = 0.f;
+    for (int c = 0; c < C2; ++c) s += bl.sample(f2 + (int64_t)c * HW) * f2[(int64_t)c * HW + p];
+    o[2 * (int64_t)HW] = s / (float)C2;
+    const float *f3 = feat3d + (int64_t)b * f3_sb + i * f3_sn;
+    for (int c = 0; c < C3; ++c) o[(int64_t)(3 + c) * HW] = f3[(int64_t)c * f3_sc];
+}
+
+int channel_split(int C, long items, int B) {
+    // enough blocks to fill 256 CUs without making each thread's channel loop trivial
+    long blocks = ((items + 255) / 256) * B;
+    int split = 1;
+    while (split < C && blocks * split < 2048 && C / (split * 2) >= 4) split *= 2;
+    return (C + split - 1) / split;
+}
+
+}  // namespace
+
+RPE_API int rpe_gather_channel_first(const float *data, int64_t sb, int64_t sc, int64_t sn, const int64_t *idx, int B, int C,
+                                     int N, int I, float *out, rpe_stream_t stream) {
+    if (!data || !idx || !out || B < 0 || C < 0 || N <= 0 || I < 0) return RPE_EINVAL;
+    if (B == 0 || C == 0 || I == 0) return 0;
+    if (B > 65535) return RPE_EUNSUPPORTED;
+    const int cpb = channel_split(C, I, B);
+    dim3 grid((I + 255) / 256, (C + cpb - 1) / cpb, B);
+    hipLaunchKernelGGL(gather_cf_kernel, grid, dim3(256), 0, (hipStream_t)stream, data, sb, sc, sn, idx, C, N, I, cpb, out);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_gather_channel_last(const float *data, int64_t sb, int64_t sn, int64_t sc, const int64_t *idx, int B, int C,
+                                    int N, int I, float *out, rpe_stream_t stream) {
+    if (!data || !idx || !out || B < 0 || C < 0 || N <= 0 || I < 0) return RPE_EINVAL;
+    if (B == 0 || C == 0 || I == 0) return 0;
+    if (B > 65535) return RPE_EUNSUPPORTED;
+    const int64_t total = (int64_t)I * C;
+    dim3 grid((unsigned)((total + 255) / 256), B);
+    hipLaunchKernelGGL(gather_cl_kernel, grid, dim3(256), 0, (hipStream_t)stream, data, sb, sn, sc, idx, C, I, out);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_knn_interpolate(const float *in_xyz, int64_t x_sb, int64_t x_sd, int64_t x_sn, const float *feat, int64_t f_sb,
+                                int64_t f_sc, int64_t f_sn, const float *q_xyz, int64_t q_sb, int64_t q_sd, int64_t q_sn,
+                                const int64_t *knn, int64_t knn_row_stride, int B, int M, int Q, int C, int k, float scale,
+                                float *out, rpe_stream_t stream) {
+    if (!in_xyz || !feat || !q_xyz || !knn || !out || B < 0 || M <= 0 || Q < 0 || C < 0 || k < 1) return RPE_EINVAL;
+    if (k > 8) return RPE_EUNSUPPORTED;
+    if (B == 0 || Q == 0 || C == 0) return 0;
+    if (B > 65535) return RPE_EUNSUPPORTED;
+    dim3 grid((Q + 255) / 256, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (k <= 3)
+        hipLaunchKernelGGL(knn_interp_kernel<3>, grid, dim3(256), 0, st, in_xyz, x_sb, x_sd, x_sn, feat, f_sb, f_sc, f_sn, q_xyz,
+                           q_sb, q_sd, q_sn, knn, knn_row_stride, k, C, Q, scale, out);
+    else
+        hipLaunchKernelGGL(knn_interp_kernel<8>, grid, dim3(256), 0, st, in_xyz, x_sb, x_sd, x_sn, feat, f_sb, f_sc, f_sn, q_xyz,
+                           q_sb, q_sd, q_sn, knn, knn_row_stride, k, C, Q, scale, out);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W, const float *xy, int64_t xy_sb, int64_t xy_sd,
+                                int64_t xy_sp, int P, int add_pixel_grid, int border, float *out, rpe_stream_t stream) {
+    if (!feat || !xy || !out || B < 0 || C < 0 || H < 1 || W < 1 || P < 0) return RPE_EINVAL;
+    if (add_pixel_grid && P != H * W) return RPE_EINVAL;
+    if (B == 0 || C == 0 || P == 0) return 0;
+    if (B > 65535) return RPE_EUNSUPPORTED;
+    const int cpb = channel_split(C, P, B);
+    dim3 grid((P + 255) / 256, (C + cpb - 1) / cpb, B);
+    hipLaunchKernelGGL(bilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, C, H, W, xy, xy_sb, xy_sd, xy_sp, P,
+                       add_pixel_grid, border, cpb, out);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
+                                     int H, int W, const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
+                                     const int64_t *nn_idx, int B, int N, float *out, rpe_stream_t stream) {
+    if (!xy || !feat_2d || !feat_3d || !nn_idx || !out || B < 0 || C2 < 1 || C3 < 0 || H < 1 || W < 1 || N < 1) return RPE_EINVAL;
+    if (B == 0) return 0;
+    if (B > 65535) return RPE_EUNSUPPORTED;
+    dim3 grid((H * W + 255) / 256, B);
+    hipLaunchKernelGGL(project_feat_kernel, grid, dim3(256), 0, (hipStream_t)stream, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2, H, W,
+                       feat_3d, f3_sb, f3_sc, f3_sn, C3, nn_idx, out);
+    return rpe_launch_status();
+}

@@ -1,0 +1,229 @@
+"""Host-side mirror of the hot-path functions of the reference's models/utils.py.
+
+Same names and argument meaning as the reference (file:line cited per function);
+each call is ONE HIP kernel from librpeflow_hip.so (plus the KNN where the
+reference also runs one).  GPU tensors only; see rpeflow_amd/_lib.py.
+
+The 1x1-conv helpers (Conv1dNormRelu, Conv2dNormRelu, MLP1d, MLP2d; utils.py:7-98)
+are dense convolutions and stay on PyTorch (MIOpen/hipBLASLt); they are restated
+here only so that module trees and state-dict keys match the reference.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .csrc import k_nearest_neighbor
+
+_NULL = ctypes.c_void_p(0)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def _launch(dev_tensor, name, fn, *args):
+    with torch.cuda.device(dev_tensor.device):
+        rc = fn(*args, _lib.stream_of(dev_tensor))
+    _lib.check(rc, name)
+
+
+# ------------------------------------------------------------------ 1x1 conv stacks (PyTorch)
+def _norm(kind, channels, dims):
+    if kind == "batch_norm":
+        return (nn.BatchNorm1d if dims == 1 else nn.BatchNorm2d)(channels)
+    if kind == "instance_norm":
+        return (nn.InstanceNorm1d if dims == 1 else nn.InstanceNorm2d)(channels)
+    if kind is None:
+        return nn.Identity()
+    raise NotImplementedError("Unknown normalization function: %s" % kind)
+
+
+def _act(kind):
+    if kind == "relu":
+        return nn.ReLU(inplace=True)
+    if kind == "leaky_relu":
+        return nn.LeakyReLU(negative_slope=0.1, inplace=True)
+    if kind is None:
+        return nn.Identity()
+    raise NotImplementedError("Unknown activation function: %s" % kind)
+
+
+class _ConvNormRelu(nn.Module):
+    """utils.py:7-62: conv_fn / norm_fn / relu_fn, in that order and under those names."""
+    dims = 1
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=0, dilation=1, groups=1,
+                 norm=None, activation="leaky_relu"):
+        super().__init__()
+        conv = nn.Conv1d if self.dims == 1 else nn.Conv2d
+        self.conv_fn = conv(in_channels, out_channels, kernel_size, stride, padding, dilation, groups)
+        self.norm_fn = _norm(norm, out_channels, self.dims)
+        self.relu_fn = _act(activation)
+
+    def forward(self, x):
+        return self.relu_fn(self.norm_fn(self.conv_fn(x)))
+
+
+class Conv1dNormRelu(_ConvNormRelu):
+    dims = 1
+
+
+class Conv2dNormRelu(_ConvNormRelu):
+    dims = 2
+
+
+class _MLP(nn.Module):
+    """utils.py:65-98: ModuleList ``convs`` of 1x1 ConvNormRelu blocks."""
+    block = Conv1dNormRelu
+
+    def __init__(self, in_channels, mlps, norm=None, activation="leaky_relu"):
+        super().__init__()
+        assert isinstance(in_channels, int) and isinstance(mlps, list)
+        widths = [in_channels] + mlps
+        self.convs = nn.ModuleList(self.block(a, b, norm=norm, activation=activation) for a, b in zip(widths[:-1], widths[1:]))
+
+    def forward(self, x):
+        for conv in self.convs:
+            x = conv(x)
+        return x
+
+
+class MLP1d(_MLP):
+    block = Conv1dNormRelu
+
+
+class MLP2d(_MLP):
+    block = Conv2dNormRelu
+
+
+# ------------------------------------------------------------------ gathers
+def batch_indexing_channel_first(batched_data: torch.Tensor, batched_indices: torch.Tensor):
+    """utils.py:119-137.  data [B,C,N], indices [B,I1..Im] -> [B,C,I1..Im]."""
+    assert batched_data.shape[0] == batched_indices.shape[0]
+    _lib.require_gpu(batched_data, batched_indices, op="batch_indexing_channel_first")
+    data = _f32(batched_data)
+    B, C, N = data.shape
+    idx = batched_indices.reshape(B, -1).to(torch.int64).contiguous()
+    I = idx.shape[1]
+    out = torch.empty((B, C, I), dtype=torch.float32, device=data.device)
+    _launch(data, "batch_indexing_channel_first", _lib.lib().rpe_gather_channel_first,
+            _ptr(data), *data.stride(), _ptr(idx), B, C, N, I, _ptr(out))
+    return out.view([B, C] + list(batched_indices.shape[1:]))
+
+
+def batch_indexing_channel_last(batched_data: torch.Tensor, batched_indices: torch.Tensor):
+    """utils.py:101-116.  data [B,N,C] or [B,N], indices [B,I1..Im] -> [B,I1..Im,C]."""
+    assert batched_data.shape[0] == batched_indices.shape[0]
+    _lib.require_gpu(batched_data, batched_indices, op="batch_indexing_channel_last")
+    squeeze = batched_data.dim() == 2
+    data = _f32(batched_data.unsqueeze(-1) if squeeze else batched_data)
+    B, N, C = data.shape
+    idx = batched_indices.reshape(B, -1).to(torch.int64).contiguous()
+    I = idx.shape[1]
+    out = torch.empty((B, I, C), dtype=torch.float32, device=data.device)
+    _launch(data, "batch_indexing_channel_last", _lib.lib().rpe_gather_channel_last,
+            _ptr(data), *data.stride(), _ptr(idx), B, C, N, I, _ptr(out))
+    shape = [B] + list(batched_indices.shape[1:])
+    return out.view(shape) if squeeze else out.view(shape + [C])
+
+
+# ------------------------------------------------------------------ 3-D interpolation / warp
+def _interpolate(input_xyz, input_features, query_xyz, knn_indices, k, scale=1.0):
+    input_xyz, input_features, query_xyz = _f32(input_xyz), _f32(input_features), _f32(query_xyz)
+    B, _, M = input_xyz.shape
+    C, Q = input_features.shape[1], query_xyz.shape[2]
+    out = torch.empty((B, C, Q), dtype=torch.float32, device=input_xyz.device)
+    knn_indices = knn_indices if knn_indices.stride(2) == 1 and knn_indices.stride(0) == Q * knn_indices.stride(1) \
+        else knn_indices.contiguous()
+    _launch(input_xyz, "knn_interpolation", _lib.lib().rpe_knn_interpolate,
+            _ptr(input_xyz), *input_xyz.stride(), _ptr(input_features), *input_features.stride(),
+            _ptr(query_xyz), *query_xyz.stride(), _ptr(knn_indices), knn_indices.stride(1),
+            B, M, Q, C, int(k), float(scale), _ptr(out))
+    return out
+
+
+def knn_interpolation(input_xyz, input_features, query_xyz, k=3):
+    """utils.py:140-156.  [B,3,M], [B,C,M], [B,3,Q] -> [B,C,Q]: KNN kernel + one fused kernel
+    (the reference: KNN + 2 gathers + norm + clamp + reciprocal + 2 reductions + multiply)."""
+    _lib.require_gpu(input_xyz, input_features, query_xyz, op="knn_interpolation")
+    knn_indices = k_nearest_neighbor(input_xyz, query_xyz, k)
+    return _interpolate(input_xyz, input_features, query_xyz, knn_indices, k)
+
+
+def backwarp_3d(xyz1, xyz2, flow12, k=3):
+    """utils.py:159-169.  The "-flow12" features are negated inside the kernel."""
+    _lib.require_gpu(xyz1, xyz2, flow12, op="backwarp_3d")
+    xyz1_warp = xyz1 + flow12
+    knn_indices = k_nearest_neighbor(xyz1_warp, xyz2, k)
+    flow21 = _interpolate(xyz1_warp, flow12, xyz2, knn_indices, k, scale=-1.0)
+    return xyz2 + flow21
+
+
+# ------------------------------------------------------------------ 2-D sampling
+mesh_grid_cache = {}
+
+
+def mesh_grid(n, h, w, device, channel_first=True):
+    """utils.py:172-183 (kept for callers that want the grid itself; the kernels below
+    generate pixel coordinates on the fly and never read it)."""
+    key = "%d,%d,%d,%s,%s" % (n, h, w, device, channel_first)
+    if key not in mesh_grid_cache:
+        xs = torch.arange(0, w, dtype=torch.float32, device=device)[None, None, :].expand(n, h, w)
+        ys = torch.arange(0, h, dtype=torch.float32, device=device)[None, :, None].expand(n, h, w)
+        grid = torch.stack([xs, ys], 1)
+        mesh_grid_cache[key] = grid if channel_first else grid.permute(0, 2, 3, 1)
+    return mesh_grid_cache[key]
+
+
+def backwarp_2d(x, flow12, padding_mode):
+    """utils.py:186-198.  x [B,C,H,W], flow12 [B,2,H,W]; padding 'border' or 'zeros'."""
+    assert x.size()[-2:] == flow12.size()[-2:]
+    if padding_mode not in ("border", "zeros"):
+        raise NotImplementedError("backwarp_2d: padding_mode %r" % (padding_mode,))
+    _lib.require_gpu(x, flow12, op="backwarp_2d")
+    x, flow12 = _f32(x).contiguous(), _f32(flow12).contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    _launch(x, "backwarp_2d", _lib.lib().rpe_bilinear_sample, _ptr(x), B, C, H, W,
+            _ptr(flow12), 2 * H * W, H * W, 1, H * W, 1, int(padding_mode == "border"), _ptr(out))
+    return out
+
+
+def grid_sample_wrapper(feat_2d, xy):
+    """utils.py:288-294.  feat_2d [B,C,H,W], xy [B,2,N] -> [B,C,N]; zeros outside the image."""
+    _lib.require_gpu(feat_2d, xy, op="grid_sample_wrapper")
+    feat_2d, xy = _f32(feat_2d).contiguous(), _f32(xy)
+    B, C, H, W = feat_2d.shape
+    N = xy.shape[2]
+    out = torch.empty((B, C, N), dtype=torch.float32, device=feat_2d.device)
+    _launch(feat_2d, "grid_sample_wrapper", _lib.lib().rpe_bilinear_sample, _ptr(feat_2d), B, C, H, W,
+            _ptr(xy), *xy.stride(), N, 0, 0, _ptr(out))
+    return out
+
+
+@torch.no_grad()
+def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None):
+    """utils.py:297-317.  xy [B,2,N], feat_2d [B,C2,H,W], feat_3d [B,C3,N], nn_indices [B,H*W]
+    -> [B,C3+3,H,W].  One kernel; the reference runs grid_sample over all N points, three
+    gathers, a product, a mean and a concat."""
+    _lib.require_gpu(xy, feat_2d, feat_3d, op="project_feat_with_nn_corr")
+    xy, feat_2d, feat_3d = _f32(xy), _f32(feat_2d).contiguous(), _f32(feat_3d)
+    B, C2, H, W = feat_2d.shape
+    if nn_indices is None:
+        grid = mesh_grid(B, H, W, xy.device).reshape(B, 2, -1)
+        nn_indices = k_nearest_neighbor(xy, grid, k=1)[..., 0]
+    else:
+        assert nn_indices.shape == (B, H * W)
+    nn_indices = nn_indices.to(torch.int64).contiguous()
+    C3, N = feat_3d.shape[1], feat_3d.shape[2]
+    out = torch.empty((B, C3 + 3, H, W), dtype=torch.float32, device=feat_2d.device)
+    _launch(feat_2d, "project_feat_with_nn_corr", _lib.lib().rpe_project_feat_nn_corr,
+            _ptr(xy), *xy.stride(), _ptr(feat_2d), C2, H, W, _ptr(feat_3d), *feat_3d.stride(), C3,
+            _ptr(nn_indices), B, N, _ptr(out))
+    return out

@@ -1,0 +1,149 @@
+"""GPU parity tests for the glue ops of models/utils.py and the 3-D blocks of
+models/pointconv.py / models/pwc3d_core.py, through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import cases as K
+from tests import inputs as I
+from tests.test_oracle_golden import _shapes_corr3d, _shapes_pointconv
+
+pytestmark = pytest.mark.gpu
+
+from rpeflow_amd import utils as U  # noqa: E402
+from rpeflow_amd import pointconv as PC  # noqa: E402
+from rpeflow_amd import pwc3d_core as P3  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def G(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def close(got, ref, atol, rtol=0.0, what=""):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=what)
+
+
+def test_glue_ops_against_reference_golden(golden_dir):
+    d, g = K.glue_inputs(), G(golden_dir, "glue_ops")
+    t = {k: dev(v) for k, v in d.items()}
+    assert np.array_equal(U.batch_indexing_channel_first(t["feat_3d"], t["idx"]).cpu().numpy(), g["gather_cf"])
+    cl = t["feat_3d"].transpose(1, 2).contiguous()
+    assert np.array_equal(U.batch_indexing_channel_last(cl, t["idx"]).cpu().numpy(), g["gather_cl"])
+    # strided (non-contiguous) source, as the model's transposed views are
+    assert np.array_equal(U.batch_indexing_channel_last(t["feat_3d"].transpose(1, 2), t["idx"]).cpu().numpy(), g["gather_cl"])
+    close(U.backwarp_2d(t["feat_2d"], t["flow"], padding_mode="border"), g["backwarp_2d"], 3e-6, what="backwarp_2d")
+    close(U.grid_sample_wrapper(t["feat_2d"], t["xy"]), g["grid_sample_wrapper"], 3e-6, what="grid_sample_wrapper")
+    close(U.knn_interpolation(t["xyz"], t["feat_3d"], t["xyz_q"], k=3), g["knn_interp"], 5e-6, what="knn_interpolation")
+    close(U.backwarp_3d(t["xyz"], t["xyz"] + 0.1, t["flow3"], k=3), g["backwarp_3d"], 1e-5, what="backwarp_3d")
+    close(U.project_feat_with_nn_corr(t["xy"], t["feat_2d"], t["feat_3d"]), g["project_feat"], 3e-6, what="project_feat")
+
+
+def test_glue_ops_against_oracle_other_shapes():
+    r = I.rng(5100)
+    B, C2, C3, H, W, N = 3, 33, 67, 9, 15, 256
+    feat2 = I.feature_map(r, B, C2, H, W)
+    flow = I.flow_field(r, B, H, W, std=6.0)
+    xy = np.ascontiguousarray(I.pixel_cloud(r, B, N, H, W).transpose(0, 2, 1))
+    feat3 = r.standard_normal((B, C3, N), dtype=np.float32)
+    close(U.backwarp_2d(dev(feat2), dev(flow), "border"), O.backwarp_2d(feat2, flow, "border"), 3e-6)
+    close(U.backwarp_2d(dev(feat2), dev(flow), "zeros"), O.backwarp_2d(feat2, flow, "zeros"), 3e-6)
+    close(U.grid_sample_wrapper(dev(feat2), dev(xy)), O.grid_sample_wrapper(feat2, xy), 3e-6)
+    nn = O.k_nearest_neighbor(xy, np.ascontiguousarray(I.pixel_grid(B, H, W).transpose(0, 2, 1)), 1)[..., 0]
+    got = U.project_feat_with_nn_corr(dev(xy), dev(feat2), dev(feat3), dev(nn))
+    close(got, O.project_feat_with_nn_corr(xy, feat2, feat3, nn), 3e-6)
+    # the implicit KNN (nn_indices=None) picks the same pixels
+    got2 = U.project_feat_with_nn_corr(dev(xy), dev(feat2), dev(feat3))
+    assert torch.equal(got, got2)
+    # interpolation with C=67 features and 8192 queries (RPEFlow_core.py:355 at level 0)
+    xyz = np.ascontiguousarray(I.ids_cloud(r, 2, 4096).transpose(0, 2, 1))
+    q = np.ascontiguousarray(I.ids_cloud(r, 2, 8192).transpose(0, 2, 1))
+    f = r.standard_normal((2, 67, 4096), dtype=np.float32)
+    close(U.knn_interpolation(dev(xyz), dev(f), dev(q), k=3), O.knn_interpolation(xyz, f, q, 3), 1e-5)
+
+
+def test_gather_edge_cases():
+    r = I.rng(5200)
+    data = r.standard_normal((2, 5, 11), dtype=np.float32)
+    idx = r.integers(0, 11, (2, 4096, 16)).astype(np.int64)
+    assert np.array_equal(U.batch_indexing_channel_first(dev(data), dev(idx)).cpu().numpy(), O.batch_indexing_channel_first(data, idx))
+    one = r.integers(0, 11, (2, 1)).astype(np.int64)
+    assert np.array_equal(U.batch_indexing_channel_first(dev(data), dev(one)).cpu().numpy(), O.batch_indexing_channel_first(data, one))
+    flat = r.standard_normal((2, 11), dtype=np.float32)  # 2-D data branch, utils.py:113-114
+    assert np.array_equal(U.batch_indexing_channel_last(dev(flat), dev(one)).cpu().numpy(), O.batch_indexing_channel_last(flat, one))
+    # prefix slice of indices (sample_index[:, :n], pwc3d_core.py:25)
+    wide = r.integers(0, 11, (2, 40)).astype(np.int64)
+    got = U.batch_indexing_channel_first(dev(data), dev(wide)[:, :17]).cpu().numpy()
+    assert np.array_equal(got, O.batch_indexing_channel_first(data, wide[:, :17]))
+
+
+def _load(module, shapes, seed):
+    params = I.fill_params(shapes, seed)
+    module.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    return module.to(DEV).eval(), params
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("name", ["pointconv_down", "pointconv_nosample"])
+def test_pointconv_modules(golden_dir, name):
+    c, x = K.BLOCK_CASES[name], K.block_inputs(name)
+    cls = PC.PointConvDownSampling if name == "pointconv_down" else PC.PointConvNoSampling
+    m, p = _load(cls(c["C"], c["Cout"], norm=c["norm"], k=c["k"]), _shapes_pointconv(c["C"], c["Cout"], c["norm"]), c["seed"] + 1000)
+    if name == "pointconv_down":
+        out = m(dev(x["xyz"]), dev(x["feat"]), dev(x["sampled"]))
+    else:
+        out = m(dev(x["xyz"]), dev(x["feat"]))
+        knn = O.k_nearest_neighbor(x["xyz"], x["xyz"], 20)  # wider precomputed table, pointconv.py:102-105
+        out2 = m(dev(x["xyz"]), dev(x["feat"]), dev(knn))
+        assert torch.equal(out, out2)
+    close(out, G(golden_dir, name)["out"], atol=1e-4, rtol=1e-4, what=name + " vs reference golden")
+    ref = O.pointconv(p, x["xyz"], x["feat"], sampled_xyz=x["sampled"], k=c["k"], norm=c["norm"])
+    close(out, ref, atol=1e-4, rtol=1e-4, what=name + " vs oracle")
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("C,M,Q", [(2, 64, 64), (61, 500, 77), (125, 300, 300), (195, 256, 256), (253, 100, 40)])
+def test_pointconv_group_channel_rounds(C, M, Q):
+    """Every channel-round instantiation (C+3 <= 64, 128, 192, 256) against the oracle."""
+    r = I.rng(6100 + C)
+    xyz = np.ascontiguousarray(I.ids_cloud(r, 2, M).transpose(0, 2, 1))
+    feat = r.standard_normal((2, C, M), dtype=np.float32)
+    m, p = _load(PC.PointConvDownSampling(C, 8, norm=None), _shapes_pointconv(C, 8, None), 77)
+    sampled = xyz[:, :, :Q].copy()
+    out = m(dev(xyz), dev(feat), dev(sampled))
+    close(out, O.pointconv(p, xyz, feat, sampled_xyz=sampled, k=16), atol=1e-4, rtol=1e-4)
+
+
+@torch.no_grad()
+def test_correlation3d_module(golden_dir):
+    c, x = K.BLOCK_CASES["correlation3d"], K.block_inputs("correlation3d")
+    m, p = _load(P3.Correlation3D(c["C"], c["C"], k=c["k"]), _shapes_corr3d(c["C"]), c["seed"] + 1000)
+    out = m(dev(x["xyz1"]), dev(x["feat1"]), dev(x["xyz2"]), dev(x["feat2"]))
+    close(out, G(golden_dir, "correlation3d")["out"], atol=1e-4, rtol=1e-4, what="vs reference golden")
+    knn11 = O.k_nearest_neighbor(x["xyz1"], x["xyz1"], c["k"])
+    out2 = m(dev(x["xyz1"]), dev(x["feat1"]), dev(x["xyz2"]), dev(x["feat2"]), dev(knn11))
+    close(out2, O.correlation3d(p, x["xyz1"], x["feat1"], x["xyz2"], x["feat2"], knn11, c["k"]), atol=1e-4, rtol=1e-4)
+
+
+@torch.no_grad()
+def test_build_pc_pyramid_prefix_property():
+    r = I.rng(6200)
+    pc1 = np.ascontiguousarray(I.ids_cloud(r, 2, 8192).transpose(0, 2, 1))
+    pc2 = (pc1 + r.standard_normal(pc1.shape, dtype=np.float32) * np.float32(0.05)).astype(np.float32)
+    xyzs1, xyzs2, idx1, idx2 = P3.build_pc_pyramid(dev(pc1), dev(pc2), [4096, 2048, 1024, 512, 256])
+    both = np.concatenate([pc1, pc2]).transpose(0, 2, 1)
+    ref = O.furthest_point_sampling(both, 4096)
+    assert np.array_equal(idx1[1].cpu().numpy(), ref[:2]) and np.array_equal(idx2[1].cpu().numpy(), ref[2:])
+    for lvl, n in enumerate([4096, 2048, 1024, 512, 256], start=1):
+        assert xyzs1[lvl].shape == (2, 3, n)
+        assert np.array_equal(xyzs1[lvl].cpu().numpy(), np.take_along_axis(pc1, ref[:2, None, :n], axis=2))
+        assert np.array_equal(xyzs2[lvl].cpu().numpy(), np.take_along_axis(pc2, ref[2:, None, :n], axis=2))
