@@ -141,6 +141,9 @@ int rpe_pointconv_group(const float *xyz, int64_t x_sb, int64_t x_sd, int64_t x_
  * Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation
  * kernel relies on: out[64*4] = D for A[lane]=lane, B[lane]=100*lane (one K).   */
 int rpe_probe_mfma4x4(float *out256, rpe_stream_t stream);
+/* Selects the FPS kernel: 1 (default) = DPP reductions + packed fp32, 0 = shuffle-based
+ * first version.  Both give identical indices; kept for A/B timing and cross-checks. */
+int rpe_debug_set_fps_variant(int variant);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,134 @@ __global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__
     }
 }
 
+
+// ---- DPP reductions (gfx9 row_shr / row_bcast controls): ~8 cycles a step instead of a
+// ds_bpermute round trip per __shfl_xor.  After the six steps lane 63 holds the result;
+// after the first four, lane 15 of every row holds its row's result.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max(float v) {
+    const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return fmaxf(v, __int_as_float(o));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_min(int v) {
+    const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+    return min(v, o);
+}
+__device__ __forceinline__ float row_max16(float v) {
+    v = dpp_max<0x111, 0xf>(v);  // row_shr:1
+    v = dpp_max<0x112, 0xf>(v);  // row_shr:2
+    v = dpp_max<0x114, 0xf>(v);  // row_shr:4
+    v = dpp_max<0x118, 0xf>(v);  // row_shr:8
+    return v;
+}
+__device__ __forceinline__ int row_min16(int v) {
+    v = dpp_min<0x111, 0xf>(v);
+    v = dpp_min<0x112, 0xf>(v);
+    v = dpp_min<0x114, 0xf>(v);
+    v = dpp_min<0x118, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row_max16(v);
+    v = dpp_max<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+    v = dpp_max<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3
+    return rpe_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min(int v) {
+    v = row_min16(v);
+    v = dpp_min<0x142, 0xa>(v);
+    v = dpp_min<0x143, 0xc>(v);
+    return rpe_readlane(v, 63);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Same algorithm as fps_kernel; differences: packed fp32 arithmetic for the distance
+// (v_pk_add/v_pk_mul, each component rounded exactly as the scalar form), a two-phase
+// argmax (max of the values, then min of the indices holding it) on DPP, first-max rule
+// unchanged.
+template <int PPT, bool LDS_XYZ>
+__global__ __launch_bounds__(kThreads) void fps_kernel_dpp(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
+                                                           int N, int S, int64_t *__restrict__ idx) {
+    static_assert(PPT % 2 == 0, "packed path needs an even number of points per thread");
+    constexpr int H = PPT / 2;
+    extern __shared__ float lds[];
+    float *part_v = lds;
+    int *part_i = reinterpret_cast<int *>(lds + 2 * kWaves);
+    float *lx = lds + 4 * kWaves, *ly = lx + N, *lz = ly + N;
+
+    const int tid = threadIdx.x, lane = rpe_lane();
+    const int wave = rpe_uniform(tid >> 6);
+    const int b = blockIdx.x;
+    xyz += (int64_t)b * sb;
+    idx += (int64_t)b * S;
+
+    f32x2 px[H], py[H], pz[H], md[H];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int i = tid + j * kThreads;
+        const bool valid = i < N;
+        const float *a = xyz + (int64_t)(valid ? i : 0) * sn;
+        const float x = a[0], y = a[sd], z = a[2 * sd];
+        px[j >> 1][j & 1] = x;
+        py[j >> 1][j & 1] = y;
+        pz[j >> 1][j & 1] = z;
+        md[j >> 1][j & 1] = valid ? 1e10f : -INFINITY;
+        if (LDS_XYZ && valid) {
+            lx[i] = x;
+            ly[i] = y;
+            lz[i] = z;
+        }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int s = 0; s < S; ++s) {
+        if (tid == 0) idx[s] = (int64_t)cur;
+        if (s == S - 1) break;
+        float cx, cy, cz;
+        if (LDS_XYZ) {
+            cx = lx[cur]; cy = ly[cur]; cz = lz[cur];
+        } else {
+            const float *a = xyz + (int64_t)cur * sn;
+            cx = a[0]; cy = a[sd]; cz = a[2 * sd];
+        }
+        const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
+            const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            f32x2 nd = xx + yy;
+            nd = nd + zz;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float m = fminf(md[h][e], nd[e]);
+                md[h][e] = m;
+                const bool take = m > bv;  // strict: first index wins inside a thread
+                bv = take ? m : bv;
+                bi = take ? tid + (2 * h + e) * kThreads : bi;
+            }
+        }
+        const float wmax = wave_max(bv);
+        const int widx = wave_min(bv == wmax ? bi : 0x7fffffff);
+        const int par = (s & 1) * kWaves;
+        if (lane == 0) {
+            part_v[par + wave] = wmax;
+            part_i[par + wave] = widx;
+        }
+        __syncthreads();
+        const float pv = part_v[par + (lane & (kWaves - 1))];
+        const int pi = part_i[par + (lane & (kWaves - 1))];
+        const float bmax = rpe_readlane(row_max16(pv), 15);
+        cur = rpe_readlane(row_min16(pv == bmax ? pi : 0x7fffffff), 15);
+    }
+}
+
+int g_fps_variant = 1;  // 0: shuffle-based fps_kernel, 1: DPP + packed math
+
 template <int PPT>
 int launch_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, hipStream_t st) {
     const size_t small = sizeof(float) * 4 * kWaves;
@@ -104,6 +232,9 @@ int launch_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int 
     const bool use_lds = full <= 150 * 1024;
     const size_t shmem = use_lds ? full : small;
     auto kern = use_lds ? fps_kernel<PPT, true> : fps_kernel<PPT, false>;
+    if constexpr (PPT % 2 == 0) {
+        if (g_fps_variant == 1) kern = use_lds ? fps_kernel_dpp<PPT, true> : fps_kernel_dpp<PPT, false>;
+    }
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return (int)e;
@@ -113,6 +244,12 @@ int launch_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int 
 }
 
 }  // namespace
+
+RPE_API int rpe_debug_set_fps_variant(int variant) {
+    if (variant < 0 || variant > 1) return RPE_EINVAL;
+    g_fps_variant = variant;
+    return 0;
+}
 
 RPE_API int rpe_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx,
                     rpe_stream_t stream) {

@@ -1,0 +1,183 @@
+"""The hot-path operator sequence of ONE RPEFlow forward, at the shapes the model
+produces for a batch of FlyingThings3D-sized frame pairs.
+
+This is the bench workload: every call the reference's forward makes into the
+hot path -- FPS, the 43 KNNs, correlation2d, backwarp_2d/3d, knn_interpolation,
+project_feat_with_nn_corr, grid_sample_wrapper, the PointConv layers of
+FeaturePyramid3D / FlowEstimator3D and Correlation3D -- in the reference's order
+and with its tensor shapes (RPEFlow.py:36-99, RPEFlow_core.py:302-432).  The dense
+2-D convolutions, Restormer attention and MI heads between those calls are NOT part
+of the hot path and are replaced by resident synthetic
+feature maps of the right shape, so a step times the hot path and nothing else.
+"""
+import contextlib
+
+import torch
+
+from types import SimpleNamespace
+
+OP_NAMES = ["correlation2d", "k_nearest_neighbor", "build_pc_pyramid", "FeaturePyramid3D", "Correlation3D",
+            "FlowEstimator3D", "backwarp_2d", "backwarp_3d", "grid_sample_wrapper", "knn_interpolation",
+            "project_feat_with_nn_corr"]
+
+
+def native_ops():
+    """The HIP-backed implementations of this package (the only ones it ships)."""
+    from . import csrc, pwc3d_core, utils
+    table = {}
+    for name in OP_NAMES:
+        for mod in (csrc, pwc3d_core, utils):
+            if hasattr(mod, name):
+                table[name] = getattr(mod, name)
+                break
+    return SimpleNamespace(**table)
+
+PYRAMID_2D = [16, 32, 64, 96, 128, 192]   # RPEFlow_core.py:174-177
+PYRAMID_3D = [16, 32, 64, 96, 128, 192]   # RPEFlow_core.py:215-219
+N_SAMPLES = [4096, 2048, 1024, 512, 256]  # RPEFlow.py:74
+
+
+class Timer:
+    """Per-category GPU time, measured with events on the stream the kernels run on."""
+
+    def __init__(self, enabled):
+        self.enabled = enabled
+        self.spans = {}
+
+    @contextlib.contextmanager
+    def span(self, name):
+        if not self.enabled:
+            yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        yield
+        b.record()
+        self.spans.setdefault(name, []).append((a, b))
+
+    def totals_ms(self):
+        torch.cuda.synchronize()
+        return {k: (sum(a.elapsed_time(b) for a, b in v), len(v)) for k, v in self.spans.items()}
+
+
+class HotPathWorkload(torch.nn.Module):
+    def __init__(self, batch=4, height=544, width=960, n_points=8192, device="cuda:0", seed=0, ops=None):
+        """``ops``: a namespace with the OP_NAMES callables/classes; default = this package's
+        HIP-backed ones.  (bench.py passes a CPU port here for its cpu_baseline leg.)"""
+        super().__init__()
+        self.ops = ops = ops or native_ops()
+        self.B, self.N = batch, n_points
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        H64, W64 = (height + 63) // 64 * 64, (width + 63) // 64 * 64  # resize_to_64x, utils.py:227-241
+        self.sensor = (H64 // 32, W64 // 32)  # ids.sensor_size_divisor = 32 (conf/test/things.yaml)
+        self.sizes = [(H64 >> (l + 1), W64 >> (l + 1)) for l in range(6)]
+
+        def rnd(*shape, scale=1.0):
+            return (torch.randn(*shape, generator=g) * scale).to(device)
+
+        # clouds as the IDS transform leaves them (utils.py:320-346): x,y in sensor pixels, z = f*log(depth)-ish
+        sh, sw = self.sensor
+        xy = torch.rand(batch, 2, n_points, generator=g) * torch.tensor([sw - 1.0, sh - 1.0])[None, :, None]
+        xy = xy - torch.tensor([(sw - 1) / 2, (sh - 1) / 2])[None, :, None]
+        z = 22.0 + 91.0 * torch.rand(batch, 1, n_points, generator=g)
+        self.pc1 = torch.cat([xy, z], 1).to(device).contiguous()
+        self.pc2 = (self.pc1 + rnd(batch, 3, n_points, scale=0.05)).contiguous()
+
+        self.feats1_2d = [rnd(batch, c, h, w) for c, (h, w) in zip(PYRAMID_2D, self.sizes)]
+        self.feats2_2d = [rnd(batch, c, h, w) for c, (h, w) in zip(PYRAMID_2D, self.sizes)]
+        self.efeats_2d = [rnd(batch, c, h, w) for c, (h, w) in zip([32, 32, 64, 96, 128, 192], self.sizes)]
+        self.flow_feat_2d = [rnd(batch, 64, h, w) for (h, w) in self.sizes]  # flow_estimator_2d.flow_feat_dim = 32+32
+        self.flow_2d = [rnd(batch, 2, h, w, scale=2.0) for (h, w) in self.sizes]
+
+        torch.manual_seed(seed)
+        self.feature_pyramid_3d = ops.FeaturePyramid3D(PYRAMID_3D, norm="batch_norm", k=16)
+        self.correlations_3d = torch.nn.ModuleList(
+            [torch.nn.Identity()] + [ops.Correlation3D(c, c, k=16) for c in PYRAMID_3D[1:]])
+        self.flow_estimator_3d = ops.FlowEstimator3D([64 + 64 + 3 + 64, 128, 128, 64], None, conv_last=False, k=16)
+        self.flow_head_3d = torch.nn.Conv1d(64, 3, kernel_size=1)
+        self.aligners = torch.nn.ModuleList([torch.nn.Conv1d(c, 64, 1) for c in PYRAMID_3D])
+        self.to(device).eval()
+
+    @torch.no_grad()
+    def forward(self, timer=None):
+        t = timer or Timer(False)
+        B, o = self.B, self.ops
+        correlation2d, k_nearest_neighbor, build_pc_pyramid = o.correlation2d, o.k_nearest_neighbor, o.build_pc_pyramid
+        backwarp_2d, backwarp_3d, grid_sample_wrapper = o.backwarp_2d, o.backwarp_3d, o.grid_sample_wrapper
+        knn_interpolation, project_feat_with_nn_corr = o.knn_interpolation, o.project_feat_with_nn_corr
+        sh, sw = self.sensor
+        with t.span("fps+pyramid"):
+            xyzs1, xyzs2, _, _ = build_pc_pyramid(self.pc1, self.pc2, N_SAMPLES)
+        with t.span("feature_pyramid_3d"):
+            feats1_3d = self.feature_pyramid_3d(xyzs1)
+            feats2_3d = self.feature_pyramid_3d(xyzs2)
+
+        flows_3d, flow_feats_3d = [], []
+        for level in range(5, 0, -1):
+            xyz1, xyz2 = xyzs1[level], xyzs2[level]
+            f1_2d, f2_2d, ef_2d = self.feats1_2d[level], self.feats2_2d[level], self.efeats_2d[level]
+            f1_3d, f2_3d = feats1_3d[level], feats2_3d[level]
+            h, w = self.sizes[level]
+            n = xyz1.shape[-1]
+            scale = torch.tensor([(w - 1) / (sw - 1), (h - 1) / (sh - 1)], device=xyz1.device)[None, :, None]
+            centre = torch.tensor([(sw - 1) / 2, (sh - 1) / 2], device=xyz1.device)[None, :, None]
+            xy1 = (xyz1[:, :2] + centre) * scale  # project_pc2image 'parallel' + rescale (RPEFlow_core.py:316-324)
+            xy2 = (xyz2[:, :2] + centre) * scale
+
+            with t.span("knn2d_k1"):
+                gx = torch.arange(w, device=xy1.device, dtype=torch.float32)
+                gy = torch.arange(h, device=xy1.device, dtype=torch.float32)
+                grid = torch.stack([gx[None, :].expand(h, w), gy[:, None].expand(h, w)]).reshape(1, 2, -1).expand(B, 2, h * w)
+                nn_proj1 = k_nearest_neighbor(xy1, grid, k=1)
+                nn_proj2 = k_nearest_neighbor(xy2, grid, k=1)
+            with t.span("knn3d_k16"):
+                knn_1in1 = k_nearest_neighbor(xyz1, xyz1, k=16)
+
+            with t.span("project_feat"):  # pyramid fusers 2D (RPEFlow_core.py:334-335)
+                project_feat_with_nn_corr(xy1, f1_2d, f1_3d, nn_proj1[..., 0])
+                project_feat_with_nn_corr(xy2, f2_2d, f2_3d, nn_proj2[..., 0])
+            with t.span("grid_sample"):  # pyramid fusers 3D (:336-337)
+                grid_sample_wrapper(f1_2d, xy1)
+                grid_sample_wrapper(f2_2d, xy2)
+
+            if level == 5:
+                last_flow_3d = torch.zeros(B, 3, n, device=xyz1.device)
+                last_flow_feat_3d = torch.zeros(B, 64, n, device=xyz1.device)
+                xyz2_warp, f2_2d_warp = xyz2, f2_2d
+            else:
+                with t.span("backwarp_2d"):
+                    f2_2d_warp = backwarp_2d(f2_2d, self.flow_2d[level], padding_mode="border")
+                with t.span("knn_interpolation"):
+                    up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], 1), xyz1)
+                    last_flow_3d, last_flow_feat_3d = up[:, :3], up[:, 3:]
+                with t.span("backwarp_3d"):
+                    xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
+
+            with t.span("correlation3d"):
+                corr_3d = self.correlations_3d[level](xyz1, f1_3d, xyz2_warp, f2_3d, knn_1in1)
+            with t.span("correlation2d"):
+                corr_2d = torch.nn.functional.leaky_relu(correlation2d(f1_2d, f2_2d_warp, 4), 0.1)
+
+            with t.span("project_feat"):  # corr fuser 2D (:373)
+                flow_3d_to_2d = last_flow_3d[:, :2] * scale
+                project_feat_with_nn_corr(xy1, corr_2d, torch.cat([corr_3d, flow_3d_to_2d], 1), nn_proj1[..., 0])
+            with t.span("grid_sample"):  # corr fuser 3D (:376; utils via RPEFlow_core.py:107-108)
+                grid_sample_wrapper(torch.cat([corr_2d, self.flow_2d[level]], 1), xy1)
+                grid_sample_wrapper(ef_2d, xy1)
+
+            with t.span("flow_estimator_3d"):
+                x_3d = torch.cat([self.aligners[level](corr_3d), self.aligners[level](f1_3d), last_flow_3d, last_flow_feat_3d], 1)
+                flow_feat_3d = self.flow_estimator_3d(xyz1, x_3d, knn_1in1)
+            with t.span("project_feat"):  # decoder fusers (:394-395)
+                project_feat_with_nn_corr(xy1, self.flow_feat_2d[level], flow_feat_3d, nn_proj1[..., 0])
+            with t.span("grid_sample"):
+                grid_sample_wrapper(self.flow_feat_2d[level], xy1)
+
+            flows_3d.append(last_flow_3d + self.flow_head_3d(flow_feat_3d))
+            flow_feats_3d.append(flow_feat_3d)
+
+        flows_3d = flows_3d[::-1]
+        with t.span("knn_interpolation"):  # final upsampling (:429-430)
+            for i in range(len(flows_3d)):
+                flows_3d[i] = knn_interpolation(xyzs1[i + 1], flows_3d[i], xyzs1[i])
+        return flows_3d[0], corr_2d

@@ -136,6 +136,22 @@ def test_fps_golden_cases(golden_dir, name):
     assert np.array_equal(got, G(golden_dir, name)["idx"]), name + " vs reference golden"
 
 
+@pytest.mark.parametrize("variant", [0, 1])
+def test_fps_both_kernel_variants_agree(golden_dir, variant):
+    """The first (shuffle) kernel and the DPP/packed-math kernel give identical samples."""
+    try:
+        _lib.check(_lib.lib().rpe_debug_set_fps_variant(variant), "set variant")
+        for name in K.FPS_CASES:
+            xyz, S = K.fps_inputs(name)
+            got = ops.furthest_point_sampling(dev(xyz), S).cpu().numpy()
+            assert np.array_equal(got, G(golden_dir, name)["idx"]), (name, variant)
+        xyz = I.ids_cloud(I.rng(8300), 2, 5000)  # N not a multiple of 1024: padded lanes must never win
+        got = ops.furthest_point_sampling(dev(xyz), 4999).cpu().numpy()
+        assert np.array_equal(got, O.furthest_point_sampling(xyz, 4999))
+    finally:
+        _lib.lib().rpe_debug_set_fps_variant(1)
+
+
 @pytest.mark.parametrize("B,N,S", [(1, 2, 1), (2, 65, 64), (3, 1023, 100), (1, 1025, 1024), (2, 3000, 700), (1, 9000, 50), (1, 20000, 40)])
 def test_fps_ragged_shapes(B, N, S):
     xyz = I.ids_cloud(I.rng(8000 + N), B, N)

@@ -37,7 +37,8 @@ def main():
         for (B, C, H, Wd) in [(4, 32, 144, 240), (4, 64, 72, 120), (4, 96, 36, 60), (4, 128, 18, 30), (4, 192, 9, 15)]:
             x, y = torch.randn(B, C, H, Wd, device=dev), torch.randn(B, C, H, Wd, device=dev)
             us = timeit(lambda: ops.correlation2d(x, y, 4))
-            print(f"corr model {B}x{C}x{H}x{Wd}: {us:9.1f} us")
+            us1 = timeit(lambda: W._correlation2d_algo(x, y, 4, 1))
+            print(f"corr model {B}x{C}x{H}x{Wd}: mfma {us:9.1f} us   direct {us1:9.1f} us")
     if "knn" in which:
         for (B, M, Q, D, k) in [(4, 8192, 4096, 3, 16), (4, 4096, 4096, 3, 16), (4, 4096, 34560, 2, 1), (4, 2048, 8640, 2, 1),
                                 (4, 4096, 4096, 3, 3), (4, 2048, 4096, 3, 3), (4, 256, 256, 3, 16), (4, 8192, 8192, 3, 16)]:
@@ -48,8 +49,12 @@ def main():
     if "fps" in which:
         for (B, N, S) in [(8, 8192, 4096), (2, 8192, 4096), (8, 4096, 1024)]:
             p = (torch.rand(B, 3, N, device=dev) * 30).transpose(1, 2)
-            us = timeit(lambda: ops.furthest_point_sampling(p, S), warmup=1, iters=3)
-            print(f"fps B={B} N={N} S={S}: {us:9.1f} us  {us / S:6.3f} us/sample")
+            from rpeflow_amd import _lib
+            for variant in (0, 1):
+                _lib.lib().rpe_debug_set_fps_variant(variant)
+                us = timeit(lambda: ops.furthest_point_sampling(p, S), warmup=1, iters=3)
+                print(f"fps variant={variant} B={B} N={N} S={S}: {us:9.1f} us  {us / S:6.3f} us/sample")
+            _lib.lib().rpe_debug_set_fps_variant(1)
 
 
 if __name__ == "__main__":
