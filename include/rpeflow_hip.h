@@ -80,7 +80,8 @@ int rpe_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
  *   out[b][(dy+md)*(2md+1)+(dx+md)][y][x] = (1/C) sum_c in1[b][c][y][x]*in2[b][c][y+dy][x+dx]
  * zero outside the image.  in1,in2 [B,C,H,W] contiguous; out [B,(2md+1)^2,H,W].
  * leaky_slope != 0 fuses the caller's leaky_relu (RPEFlow_core.py:362); pass 0
- * for the plain operator.  algo: 0 = pick, 1 = direct (any md), 2 = MFMA (md==4). */
+ * for the plain operator.  algo: 0 = pick, 1 = direct (any md), 2 = MFMA tiles (md==4),
+ * 3 = row kernel (md 1..4, W <= 256). */
 int rpe_correlation2d_forward(const float *in1, const float *in2, int B, int C, int H, int W, int md,
                               float leaky_slope, int algo, float *out, rpe_stream_t stream);
 
@@ -119,11 +120,13 @@ int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W,
 /* ---- project_feat_with_nn_corr (models/utils.py:297-317) -------------------------
  * For pixel p with nearest projected point i = nn_idx[b][p]:
  *   out[b][0:2][p] = xy[b][:,i] - (p%W, p/W);  out[b][2][p] = mean_c(sample(feat_2d, xy_i)[c]*feat_2d[b][c][p]);
- *   out[b][3+c][p] = feat_3d[b][c][i].   feat_2d [B,C2,H,W] contiguous, out [B,C3+3,H,W]. */
+ *   out[b][3+c][p] = feat_3d[b][c][i].   feat_2d [B,C2,H,W] contiguous, out [B,C3+3,H,W].
+ * workspace: B*N*(C2+C3) floats of scratch (per-point rows: the samples are taken once per
+ * point, as the reference does, then gathered per pixel).                                  */
 int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
                              const float *feat_2d, int C2, int H, int W,
                              const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
-                             const int64_t *nn_idx, int B, int N, float *out, rpe_stream_t stream);
+                             const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream);
 
 /* ---- PointConv grouping (models/pointconv.py:48-57 and 107-118) ------------------
  * out[b][q][w*CF+c] = sum_{j<16} wn_j[w] * feats_cl[b][knn[b][q][j]][c],
@@ -136,6 +139,30 @@ int rpe_pointconv_group(const float *xyz, int64_t x_sb, int64_t x_sd, int64_t x_
                         const float *feats_cl, const int64_t *knn, int64_t knn_row_stride,
                         const float *w1, const float *b1, const float *w2, const float *b2, float leaky_slope,
                         int B, int M, int Q, int CF, float *out, rpe_stream_t stream);
+
+/* ---- Correlation3D (models/pwc3d_core.py:69-117) ---------------------------------
+ * rpe_corr3d_hidden: hidden[b][c][n][j] = leaky(p1[b][c][n] + p2[b][c][knn_j] + wc[c][0..2].rel_j),
+ *   rel_j = xyz_s[:,knn_j] - xyz_q[:,n]; p1 [B,C,N] = Wa.feat1 + bias, p2 [B,C,M] = Wb.feat2 are the
+ *   per-point halves of cost_mlp's first 1x1 conv (its input is the concatenation
+ *   [feat1 | feat2_nbr | rel], pwc3d_core.py:92-94), wc [C,3] its last three input columns.
+ *   hidden [B,C,N,16] contiguous feeds cost_mlp's second layer (a GEMM, left to the caller).
+ * rpe_corr3d_weighted_sum: out[b][c][n] = sum_{j<16} net(rel_j)[c] * value, with
+ *   net = MLP2d(3,[8,8,C],relu) (w1 [8,3], w2 [8,8], w3 [C,8]; weight_net1/2, :66-67) and
+ *   value = vals[b][c][n][j] (gather=0, vals [B,C,N,16]: p2n cost, :96-98) or
+ *   value = vals[b][c][knn_j] (gather=1, vals [B,C,M]: n2n cost, :106-115).
+ * xyz_* channel-first through strides (batch, dim, point); knn [B,N,*] int64, row stride >= 16. */
+int rpe_corr3d_hidden(const float *p1, const float *p2, const float *wc,
+                      const float *xyz_q, int64_t q_sb, int64_t q_sd, int64_t q_sn,
+                      const float *xyz_s, int64_t s_sb, int64_t s_sd, int64_t s_sn,
+                      const int64_t *knn, int64_t knn_row_stride, int B, int C, int N, int M,
+                      float leaky_slope, float *hidden, rpe_stream_t stream);
+int rpe_corr3d_weighted_sum(const float *vals, int gather,
+                            const float *w1, const float *b1, const float *w2, const float *b2,
+                            const float *w3, const float *b3,
+                            const float *xyz_q, int64_t q_sb, int64_t q_sd, int64_t q_sn,
+                            const float *xyz_s, int64_t s_sb, int64_t s_sd, int64_t s_sn,
+                            const int64_t *knn, int64_t knn_row_stride, int B, int C, int N, int M,
+                            float *out, rpe_stream_t stream);
 
 /* ---- diagnostics -------------------------------------------------------------
  * Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation

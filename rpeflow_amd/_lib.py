@@ -28,6 +28,11 @@ _PROTOTYPES = {
     "rpe_correlation2d_forward": [_c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_float, _c_int, _c_ptr, _c_ptr],
     "rpe_probe_mfma4x4": [_c_ptr, _c_ptr],
+    "rpe_corr3d_hidden": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
+                          _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
+    "rpe_corr3d_weighted_sum": [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
+                                _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
+                                _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_debug_set_fps_variant": [_c_int],
     "rpe_gather_channel_first": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_gather_channel_last": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
@@ -36,7 +41,7 @@ _PROTOTYPES = {
     "rpe_bilinear_sample": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
                             _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_project_feat_nn_corr": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int,
-                                 _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr],
+                                 _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_pointconv_group": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64,
                             _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
 }

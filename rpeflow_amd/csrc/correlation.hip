@@ -6,6 +6,8 @@
 //
 //   corr_direct_kernel  any max_displacement; one thread per output element.
 //                       Slow, simple; the cross-check for the kernel below.
+//   corr_row_kernel     max_displacement 1..4, W <= 256: one workgroup per image row, VALU, LDS-staged;
+//                       what every in-model call uses.
 //   corr_mfma_kernel    max_displacement == 4.  The contraction over channels runs
 //                       on the matrix cores with v_mfma_f32_4x4x1_16b_f32: one
 //                       instruction = 16 independent 4x4 outer products.  Lane l of
@@ -48,6 +50,102 @@ __global__ __launch_bounds__(256) void corr_direct_kernel(const float *__restric
     s = s / (float)C;
     if (slope != 0.f) s = s >= 0.f ? s : s * slope;
     out[((int64_t)b * n * n + d) * HW + (int64_t)y * W + x] = s;
+}
+
+
+// ---- row kernel: small and medium maps (every in-model call) ------------------------
+// One workgroup per (batch, image row): the row of in1 and the 2md+1 rows of in2 it needs
+// are staged in LDS per chunk of CK channels; thread t owns pixel x = t % XW and the
+// displacement rows dy = g, g+G, ... of group g = t / XW, all 2md+1 dx of them in
+// registers (accumulators, LDS offsets are immediates).  Every output of the row is
+// produced by exactly one thread in channel order: deterministic, no atomics.
+// Launch-/LDS-bound by design: the in-model maps are at most 144x240x32 (0.3 GFLOP a
+// sample in total), far below anything the MFMA tile kernel can fill the chip with.
+template <int MDT, int G>
+__global__ __launch_bounds__(256) void corr_row_kernel(const float *__restrict__ in1, const float *__restrict__ in2,
+                                                       int C, int H, int W, float slope, float *__restrict__ out) {
+    constexpr int N = 2 * MDT + 1;
+    constexpr int XW = 256 / G;            // threads (pixels) per displacement group
+    constexpr int NDY = (N + G - 1) / G;   // displacement rows per thread
+    constexpr int CK = 4;
+    extern __shared__ float lds[];
+    const int Wp = W + 2 * MDT;
+    float *l1 = lds;                 // [CK][W]
+    float *l2 = lds + CK * W;        // [CK][N][Wp]
+    const int tid = threadIdx.x, y = blockIdx.x, b = blockIdx.y;
+    const int x = tid % XW, g = tid / XW;
+    const int64_t HW = (int64_t)H * W;
+    const float *g1 = in1 + (int64_t)b * C * HW + (int64_t)y * W;
+    const float *g2 = in2 + (int64_t)b * C * HW;
+
+    float acc[NDY][N];
+#pragma unroll
+    for (int i = 0; i < NDY; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc[i][j] = 0.f;
+
+    const bool active = x < W;
+    const int xr = active ? x : 0;
+    for (int c0 = 0; c0 < C; c0 += CK) {
+        __syncthreads();
+        for (int e = tid; e < CK * W; e += 256) {
+            const int c = e / W, px = e - c * W;
+            l1[e] = (c0 + c < C) ? g1[(int64_t)(c0 + c) * HW + px] : 0.f;
+        }
+        for (int e = tid; e < CK * N * Wp; e += 256) {
+            const int c = e / (N * Wp), r = e - c * (N * Wp);
+            const int dy = r / Wp, px = r - dy * Wp;
+            const int y2 = y + dy - MDT, x2 = px - MDT;
+            const bool ok = (c0 + c < C) && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
+            l2[e] = ok ? g2[(int64_t)(c0 + c) * HW + (int64_t)y2 * W + x2] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CK; ++c) {
+            const float a = l1[c * W + xr];
+#pragma unroll
+            for (int i = 0; i < NDY; ++i) {
+                const int dy = g + i * G;
+                if (dy < N) {
+                    const float *row = l2 + (c * N + dy) * Wp + xr;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) acc[i][j] = __fmaf_rn(a, row[j], acc[i][j]);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    const float fc = (float)C;
+#pragma unroll
+    for (int i = 0; i < NDY; ++i) {
+        const int dy = g + i * G;
+        if (dy < N) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float v = acc[i][j] / fc;
+                if (slope != 0.f) v = v >= 0.f ? v : v * slope;
+                out[((int64_t)b * N * N + dy * N + j) * HW + (int64_t)y * W + x] = v;
+            }
+        }
+    }
+}
+
+template <int MDT>
+int launch_row(const float *in1, const float *in2, int B, int C, int H, int W, float slope, float *out, hipStream_t st) {
+    constexpr int N = 2 * MDT + 1;
+    const size_t shmem = sizeof(float) * 4 * ((size_t)W + (size_t)N * (W + 2 * MDT));
+    dim3 grid(H, B), block(256);
+    auto launch = [&](auto kern) -> int {
+        if (shmem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(kern, grid, block, shmem, st, in1, in2, C, H, W, slope, out);
+        return 0;
+    };
+    if (W <= 64) return launch(corr_row_kernel<MDT, 4>);
+    if (W <= 128) return launch(corr_row_kernel<MDT, 2>);
+    return launch(corr_row_kernel<MDT, 1>);
 }
 
 // ---- MFMA kernel ---------------------------------------------------------------
@@ -202,8 +300,24 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int n = 2 * md + 1;
-    if (algo == 0) algo = (md == MD) ? 2 : 1;
-    if (algo == 2) {
+    // pick: row kernel for every in-model size, MFMA tiles for large maps, direct for anything else
+    if (algo == 0) {
+        const bool row_ok = md >= 1 && md <= 4 && W <= 256 && H <= 65535;
+        if (md == MD && (int64_t)H * W > 256 * 256) algo = 2;
+        else algo = row_ok ? 3 : ((md == MD) ? 2 : 1);
+    }
+    if (algo == 3) {
+        if (W > 256 || H > 65535 || B > 65535) return RPE_EUNSUPPORTED;
+        int rc;
+        switch (md) {
+            case 1: rc = launch_row<1>(in1, in2, B, C, H, W, leaky_slope, out, st); break;
+            case 2: rc = launch_row<2>(in1, in2, B, C, H, W, leaky_slope, out, st); break;
+            case 3: rc = launch_row<3>(in1, in2, B, C, H, W, leaky_slope, out, st); break;
+            case 4: rc = launch_row<4>(in1, in2, B, C, H, W, leaky_slope, out, st); break;
+            default: return RPE_EUNSUPPORTED;
+        }
+        if (rc) return rc;
+    } else if (algo == 2) {
         if (md != MD) return RPE_EUNSUPPORTED;
         if (B > 65535) return RPE_EUNSUPPORTED;
         launch_mfma<2, 4, 4>(in1, in2, B, C, H, W, leaky_slope, out, st);

@@ -140,12 +140,35 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__
     for (int c = c0; c < c1; ++c) out[((int64_t)b * C + c) * P + p] = bl.sample(feat + ((int64_t)b * C + c) * HW);
 }
 
-// project_feat_with_nn_corr (utils.py:297-317), one thread per pixel p with nearest point i:
-//   out[0:2] = xy_i - pixel, out[2] = mean_c(sample(feat_2d, xy_i)[c] * feat_2d[c][p]), out[3:] = feat_3d[:, i]
-__global__ __launch_bounds__(256) void project_feat_kernel(const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
-                                                           const float *__restrict__ feat2d, int C2, int H, int W,
-                                                           const float *__restrict__ feat3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn,
-                                                           int C3, const int64_t *__restrict__ nn, float *__restrict__ out) {
+// project_feat_with_nn_corr (utils.py:297-317) in two launches.
+//   point_rows_kernel:   rows[b][i][:] = [ sample(feat_2d[b], xy_i)[0..C2) | feat_3d[b][:, i] ]   (channel-last, per POINT)
+//   project_rows_kernel: for pixel p with nearest point i = nn[b][p]:
+//       out[0:2] = xy_i - pixel, out[2] = mean_c(rows[i][c] * feat_2d[c][p]), out[3:] = rows[i][C2:]
+// The reference samples per point too (grid_sample_wrapper over all N points, utils.py:308) and then
+// gathers per pixel; sampling per pixel instead would repeat the 4-corner fetch ~HW/N = 8 times.
+// A pixel's gather is one contiguous row here instead of C2+C3 strided reads.
+__global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
+                                                         const float *__restrict__ feat2d, int C2, int H, int W,
+                                                         const float *__restrict__ feat3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn,
+                                                         int C3, int N, float *__restrict__ rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= N) return;
+    const float px = xy[(int64_t)b * xy_sb + (int64_t)i * xy_sn], py = xy[(int64_t)b * xy_sb + xy_sd + (int64_t)i * xy_sn];
+    Bilinear bl;
+    bl.setup(px, py, H, W, false);
+    const int64_t HW = (int64_t)H * W;
+    const float *f2 = feat2d + (int64_t)b * C2 * HW;
+    float *row = rows + ((int64_t)b * N + i) * (C2 + C3);
+    for (int c = 0; c < C2; ++c) row[c] = bl.sample(f2 + (int64_t)c * HW);
+    const float *f3 = feat3d + (int64_t)b * f3_sb + (int64_t)i * f3_sn;
+    for (int c = 0; c < C3; ++c) row[C2 + c] = f3[(int64_t)c * f3_sc];
+}
+
+__global__ __launch_bounds__(256) void project_rows_kernel(const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
+                                                           const float *__restrict__ feat2d, int C2, int H, int W, int C3, int N,
+                                                           const float *__restrict__ rows, const int64_t *__restrict__ nn,
+                                                           float *__restrict__ out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     const int HW = H * W;
@@ -155,14 +178,12 @@ __global__ __launch_bounds__(256) void project_feat_kernel(const float *__restri
     float *o = out + (int64_t)b * (C3 + 3) * HW + p;
     o[0] = px - (float)(p % W);
     o[HW] = py - (float)(p / W);
-    Bilinear bl;
-    bl.setup(px, py, H, W, false);
-    const float *f2 = feat2d + (int64_t)b * C2 * HW;
+    const float *row = rows + ((int64_t)b * N + i) * (C2 + C3);
+    const float *f2 = feat2d + (int64_t)b * C2 * HW + p;
     float s = 0.f;
-    for (int c = 0; c < C2; ++c) s += bl.sample(f2 + (int64_t)c * HW) * f2[(int64_t)c * HW + p];
+    for (int c = 0; c < C2; ++c) s += row[c] * f2[(int64_t)c * HW];
     o[2 * (int64_t)HW] = s / (float)C2;
-    const float *f3 = feat3d + (int64_t)b * f3_sb + i * f3_sn;
-    for (int c = 0; c < C3; ++c) o[(int64_t)(3 + c) * HW] = f3[(int64_t)c * f3_sc];
+    for (int c = 0; c < C3; ++c) o[(int64_t)(3 + c) * HW] = row[C2 + c];
 }
 
 int channel_split(int C, long items, int B) {
@@ -231,12 +252,15 @@ RPE_API int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W, c
 
 RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
                                      int H, int W, const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
-                                     const int64_t *nn_idx, int B, int N, float *out, rpe_stream_t stream) {
-    if (!xy || !feat_2d || !feat_3d || !nn_idx || !out || B < 0 || C2 < 1 || C3 < 0 || H < 1 || W < 1 || N < 1) return RPE_EINVAL;
+                                     const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream) {
+    if (!xy || !feat_2d || !feat_3d || !nn_idx || !out || !workspace || B < 0 || C2 < 1 || C3 < 0 || H < 1 || W < 1 || N < 1)
+        return RPE_EINVAL;
     if (B == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
-    dim3 grid((H * W + 255) / 256, B);
-    hipLaunchKernelGGL(project_feat_kernel, grid, dim3(256), 0, (hipStream_t)stream, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2, H, W,
-                       feat_3d, f3_sb, f3_sc, f3_sn, C3, nn_idx, out);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(point_rows_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2, H, W,
+                       feat_3d, f3_sb, f3_sc, f3_sn, C3, N, workspace);
+    hipLaunchKernelGGL(project_rows_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2,
+                       H, W, C3, N, workspace, nn_idx, out);
     return rpe_launch_status();
 }

@@ -89,6 +89,15 @@ class HotPathWorkload(torch.nn.Module):
         self.flow_feat_2d = [rnd(batch, 64, h, w) for (h, w) in self.sizes]  # flow_estimator_2d.flow_feat_dim = 32+32
         self.flow_2d = [rnd(batch, 2, h, w, scale=2.0) for (h, w) in self.sizes]
 
+        # per-level constants of the projection (RPEFlow_core.py:316-330), resident like the inputs
+        self.scale, self.centre, self.grid = [], [], []
+        for (h, w) in self.sizes:
+            self.scale.append(torch.tensor([(w - 1) / (sw - 1), (h - 1) / (sh - 1)])[None, :, None].to(device))
+            self.centre.append(torch.tensor([(sw - 1) / 2, (sh - 1) / 2])[None, :, None].to(device))
+            gx, gy = torch.arange(w, dtype=torch.float32), torch.arange(h, dtype=torch.float32)
+            grid = torch.stack([gx[None, :].expand(h, w), gy[:, None].expand(h, w)]).reshape(1, 2, -1)
+            self.grid.append(grid.to(device).expand(batch, 2, h * w))
+
         torch.manual_seed(seed)
         self.feature_pyramid_3d = ops.FeaturePyramid3D(PYRAMID_3D, norm="batch_norm", k=16)
         self.correlations_3d = torch.nn.ModuleList(
@@ -119,15 +128,11 @@ class HotPathWorkload(torch.nn.Module):
             f1_3d, f2_3d = feats1_3d[level], feats2_3d[level]
             h, w = self.sizes[level]
             n = xyz1.shape[-1]
-            scale = torch.tensor([(w - 1) / (sw - 1), (h - 1) / (sh - 1)], device=xyz1.device)[None, :, None]
-            centre = torch.tensor([(sw - 1) / 2, (sh - 1) / 2], device=xyz1.device)[None, :, None]
+            scale, centre, grid = self.scale[level], self.centre[level], self.grid[level]
             xy1 = (xyz1[:, :2] + centre) * scale  # project_pc2image 'parallel' + rescale (RPEFlow_core.py:316-324)
             xy2 = (xyz2[:, :2] + centre) * scale
 
             with t.span("knn2d_k1"):
-                gx = torch.arange(w, device=xy1.device, dtype=torch.float32)
-                gy = torch.arange(h, device=xy1.device, dtype=torch.float32)
-                grid = torch.stack([gx[None, :].expand(h, w), gy[:, None].expand(h, w)]).reshape(1, 2, -1).expand(B, 2, h * w)
                 nn_proj1 = k_nearest_neighbor(xy1, grid, k=1)
                 nn_proj2 = k_nearest_neighbor(xy2, grid, k=1)
             with t.span("knn3d_k16"):

@@ -60,40 +60,84 @@ class Correlation3D(nn.Module):
     (pwc3d_core.py:92-94), so it is applied per POINT before the gather --
     W_a feat1 + gather(W_b feat2) + W_c rel -- instead of per (point, neighbour) pair:
     k = 16 times fewer multiply-adds in that layer, and the [B, 2C+3, N, k] tensor is
-    never built.  Results differ from the reference only by fp32 re-association."""
+    never built.  The gather + sum + leaky_relu, both weight nets and both k-sums run
+    in three launches of two HIP kernels (csrc/corr3d.hip); the only dense work left is
+    three GEMMs on hipBLASLt.  Results differ from the reference by fp32 re-association
+    only."""
 
     def __init__(self, in_channels, out_channels, k=16):
         super().__init__()
+        if k != 16:
+            raise NotImplementedError("rpeflow_amd Correlation3D is built for k=16 (conf/*/*.yaml pwc3d.k)")
         self.k = k
         self.cost_mlp = MLP2d(3 + 2 * in_channels, [out_channels, out_channels], activation="leaky_relu")
         self.weight_net1 = MLP2d(3, [8, 8, out_channels], activation="relu")
         self.weight_net2 = MLP2d(3, [8, 8, out_channels], activation="relu")
+        self._cache = None
+
+    def _weights(self, in_channels):
+        """Contiguous fp32 views of the parameters in the layout the kernels read; rebuilt when a
+        parameter changes (load_state_dict, .to(), an optimiser step)."""
+        params = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._cache is None or self._cache[0] != key:
+            first, second = self.cost_mlp.convs[0].conv_fn, self.cost_mlp.convs[1].conv_fn
+            w = first.weight.detach()[:, :, 0, 0].float()
+            c = in_channels
+            net = lambda m: [t.detach().float().reshape(t.shape[0], -1).contiguous() if t.dim() > 1 else t.detach().float().contiguous()
+                             for conv in m.convs for t in (conv.conv_fn.weight, conv.conv_fn.bias)]
+            self._cache = (key, dict(
+                w_a=w[:, :c].contiguous(), w_b=w[:, c:2 * c].contiguous(), w_c=w[:, 2 * c:].contiguous(),
+                b_first=first.bias.detach().float().contiguous(),
+                w_second=second.weight.detach()[:, :, 0, 0].float().contiguous(),
+                b_second=second.bias.detach().float().contiguous(),
+                net1=net(self.weight_net1), net2=net(self.weight_net2)))
+        return self._cache[1]
 
     def forward(self, xyz1, feat1, xyz2, feat2, knn_indices_1in1=None):
+        from . import _lib
+        from .utils import _ptr
+        _lib.require_gpu(xyz1, feat1, xyz2, feat2, op="Correlation3D")
         batch_size, in_channels, n_points = feat1.shape
+        m_points = xyz2.shape[2]
+        w = self._weights(in_channels)
+        c_out = w["w_a"].shape[0]
+        xyz1, xyz2 = xyz1.float(), xyz2.float()
+        lib, stream = _lib.lib(), _lib.stream_of(xyz1)
+
         knn_indices_1in2 = k_nearest_neighbor(input_xyz=xyz2, query_xyz=xyz1, k=self.k)
-        knn_xyz2_norm = batch_indexing_channel_first(xyz2, knn_indices_1in2) - xyz1.view(batch_size, 3, n_points, 1)
+        part1 = torch.baddbmm(w["b_first"][None, :, None], w["w_a"][None].expand(batch_size, -1, -1), feat1.float())
+        part2 = torch.matmul(w["w_b"], feat2.float())
+        hidden = torch.empty((batch_size, c_out, n_points, self.k), dtype=torch.float32, device=xyz1.device)
+        with torch.cuda.device(xyz1.device):
+            rc = lib.rpe_corr3d_hidden(_ptr(part1), _ptr(part2), _ptr(w["w_c"]), _ptr(xyz1), *xyz1.stride(),
+                                       _ptr(xyz2), *xyz2.stride(), _ptr(knn_indices_1in2), knn_indices_1in2.stride(1),
+                                       batch_size, c_out, n_points, m_points, 0.1, _ptr(hidden), stream)
+        _lib.check(rc, "Correlation3D (hidden)")
+        # second cost_mlp layer: one GEMM over all (point, neighbour) pairs, then leaky_relu(0.1)
+        p2p_cost = torch.baddbmm(w["b_second"][None, :, None], w["w_second"][None].expand(batch_size, -1, -1),
+                                 hidden.view(batch_size, c_out, -1))
+        p2p_cost = torch.nn.functional.leaky_relu(p2p_cost, 0.1, inplace=True)
 
-        first = self.cost_mlp.convs[0]
-        w = first.conv_fn.weight[:, :, 0, 0]  # [Cout, 2C+3], input order feat1 | feat2 | rel (:92)
-        w_a, w_b, w_c = w[:, :in_channels], w[:, in_channels:2 * in_channels], w[:, 2 * in_channels:]
-        part1 = torch.matmul(w_a, feat1) + first.conv_fn.bias[None, :, None]  # [B,Cout,N]
-        part2 = batch_indexing_channel_first(torch.matmul(w_b, feat2), knn_indices_1in2)  # [B,Cout,N,k]
-        part3 = torch.einsum("oc,bcnk->bonk", w_c, knn_xyz2_norm)
-        hidden = first.relu_fn(first.norm_fn(part1[:, :, :, None] + part2 + part3))
-        p2p_cost = self.cost_mlp.convs[1](hidden)
-
-        weights2 = self.weight_net2(knn_xyz2_norm)
-        p2n_cost = torch.sum(weights2 * p2p_cost, dim=3)
+        p2n_cost = torch.empty((batch_size, c_out, n_points), dtype=torch.float32, device=xyz1.device)
+        with torch.cuda.device(xyz1.device):
+            rc = lib.rpe_corr3d_weighted_sum(_ptr(p2p_cost), 0, *[_ptr(t) for t in w["net2"]], _ptr(xyz1), *xyz1.stride(),
+                                             _ptr(xyz2), *xyz2.stride(), _ptr(knn_indices_1in2), knn_indices_1in2.stride(1),
+                                             batch_size, c_out, n_points, m_points, _ptr(p2n_cost), stream)
+        _lib.check(rc, "Correlation3D (p2n)")
 
         if knn_indices_1in1 is not None:
             assert knn_indices_1in1.shape == torch.Size([batch_size, n_points, self.k])
+            knn_indices_1in1 = knn_indices_1in1.to(torch.int64).contiguous()
         else:
             knn_indices_1in1 = k_nearest_neighbor(input_xyz=xyz1, query_xyz=xyz1, k=self.k)
-        knn_xyz1_norm = batch_indexing_channel_first(xyz1, knn_indices_1in1) - xyz1.view(batch_size, 3, n_points, 1)
-        weights1 = self.weight_net1(knn_xyz1_norm)
-        n2n_cost = batch_indexing_channel_first(p2n_cost, knn_indices_1in1)
-        return torch.sum(weights1 * n2n_cost, dim=3)
+        n2n_cost = torch.empty_like(p2n_cost)
+        with torch.cuda.device(xyz1.device):
+            rc = lib.rpe_corr3d_weighted_sum(_ptr(p2n_cost), 1, *[_ptr(t) for t in w["net1"]], _ptr(xyz1), *xyz1.stride(),
+                                             _ptr(xyz1), *xyz1.stride(), _ptr(knn_indices_1in1), knn_indices_1in1.stride(1),
+                                             batch_size, c_out, n_points, n_points, _ptr(n2n_cost), stream)
+        _lib.check(rc, "Correlation3D (n2n)")
+        return n2n_cost
 
 
 class FlowEstimator3D(nn.Module):

@@ -174,7 +174,7 @@ def test_fps_transposed_view_as_the_model_passes_it():
 def test_correlation_golden_cases(golden_dir, name):
     a, b, md = K.corr_inputs(name)
     ref = G(golden_dir, name)["out"]
-    algos = [1, 2] if md == 4 else [1]
+    algos = [1, 2, 3] if md == 4 else [1, 3]
     for algo in algos:
         out = W._correlation2d_algo(dev(a), dev(b), md, algo).cpu().numpy()
         assert out.shape == ref.shape
@@ -186,12 +186,13 @@ def test_correlation_golden_cases(golden_dir, name):
     assert np.abs(out - ref).max() < 5e-6
 
 
-@pytest.mark.parametrize("B,C,H,Wd", [(1, 3, 5, 7), (2, 33, 17, 65), (1, 16, 9, 15), (4, 192, 9, 15), (1, 64, 70, 130), (2, 5, 8, 64)])
+@pytest.mark.parametrize("B,C,H,Wd", [(1, 3, 5, 7), (2, 33, 17, 65), (1, 16, 9, 15), (4, 192, 9, 15), (1, 64, 70, 130), (2, 5, 8, 64),
+                                      (1, 32, 10, 240), (2, 6, 3, 129), (1, 2, 2, 256)])
 def test_correlation_ragged_shapes(B, C, H, Wd):
     r = I.rng(9000 + C + H + Wd)
     a, b = I.feature_map(r, B, C, H, Wd), I.feature_map(r, B, C, H, Wd)
     ref = O.correlation2d(a, b, 4)
-    for algo in (1, 2):
+    for algo in (1, 2, 3):
         got = W._correlation2d_algo(dev(a), dev(b), 4, algo).cpu().numpy()
         assert np.isfinite(got).all()
         assert np.abs(got - ref).max() < 5e-6, algo
@@ -201,7 +202,7 @@ def test_correlation_fused_leaky_relu():
     r = I.rng(9100)
     a, b = I.feature_map(r, 2, 32, 18, 30), I.feature_map(r, 2, 32, 18, 30)
     ref = torch.nn.functional.leaky_relu(torch.from_numpy(O.correlation2d(a, b, 4)), 0.1).numpy()  # RPEFlow_core.py:362
-    for algo in (1, 2):
+    for algo in (1, 2, 3):
         got = W._correlation2d_algo(dev(a), dev(b), 4, algo, leaky_slope=0.1).cpu().numpy()
         assert np.abs(got - ref).max() < 5e-6
 

@@ -38,7 +38,9 @@ def main():
             x, y = torch.randn(B, C, H, Wd, device=dev), torch.randn(B, C, H, Wd, device=dev)
             us = timeit(lambda: ops.correlation2d(x, y, 4))
             us1 = timeit(lambda: W._correlation2d_algo(x, y, 4, 1))
-            print(f"corr model {B}x{C}x{H}x{Wd}: mfma {us:9.1f} us   direct {us1:9.1f} us")
+            us3 = timeit(lambda: W._correlation2d_algo(x, y, 4, 3))
+            us2 = timeit(lambda: W._correlation2d_algo(x, y, 4, 2))
+            print(f"corr model {B}x{C}x{H}x{Wd}: picked {us:9.1f} us   direct {us1:9.1f} us  mfma {us2:9.1f} us  row {us3:9.1f} us")
     if "knn" in which:
         for (B, M, Q, D, k) in [(4, 8192, 4096, 3, 16), (4, 4096, 4096, 3, 16), (4, 4096, 34560, 2, 1), (4, 2048, 8640, 2, 1),
                                 (4, 4096, 4096, 3, 3), (4, 2048, 4096, 3, 3), (4, 256, 256, 3, 16), (4, 8192, 8192, 3, 16)]:
