@@ -80,8 +80,7 @@ int rpe_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
  *   out[b][(dy+md)*(2md+1)+(dx+md)][y][x] = (1/C) sum_c in1[b][c][y][x]*in2[b][c][y+dy][x+dx]
  * zero outside the image.  in1,in2 [B,C,H,W] contiguous; out [B,(2md+1)^2,H,W].
  * leaky_slope != 0 fuses the caller's leaky_relu (RPEFlow_core.py:362); pass 0
- * for the plain operator.  algo: 0 = pick, 1 = direct (any md), 2 = MFMA tiles (md==4),
- * 3 = row kernel (md 1..4, W <= 256). */
+ * for the plain operator.  algo: 0 = pick, 1 = direct (any md), 2 = MFMA tiles (md==4). */
 int rpe_correlation2d_forward(const float *in1, const float *in2, int B, int C, int H, int W, int md,
                               float leaky_slope, int algo, float *out, rpe_stream_t stream);
 

@@ -6,8 +6,6 @@
 //
 //   corr_direct_kernel  any max_displacement; one thread per output element.
 //                       Slow, simple; the cross-check for the kernel below.
-//   corr_row_kernel     max_displacement 1..4, W <= 256: one workgroup per image row, VALU, LDS-staged;
-//                       what every in-model call uses.
 //   corr_mfma_kernel    max_displacement == 4.  The contraction over channels runs
 //                       on the matrix cores with v_mfma_f32_4x4x1_16b_f32: one
 //                       instruction = 16 independent 4x4 outer products.  Lane l of
@@ -52,101 +50,6 @@ __global__ __launch_bounds__(256) void corr_direct_kernel(const float *__restric
     out[((int64_t)b * n * n + d) * HW + (int64_t)y * W + x] = s;
 }
 
-
-// ---- row kernel: small and medium maps (every in-model call) ------------------------
-// One workgroup per (batch, image row): the row of in1 and the 2md+1 rows of in2 it needs
-// are staged in LDS per chunk of CK channels; thread t owns pixel x = t % XW and the
-// displacement rows dy = g, g+G, ... of group g = t / XW, all 2md+1 dx of them in
-// registers (accumulators, LDS offsets are immediates).  Every output of the row is
-// produced by exactly one thread in channel order: deterministic, no atomics.
-// Launch-/LDS-bound by design: the in-model maps are at most 144x240x32 (0.3 GFLOP a
-// sample in total), far below anything the MFMA tile kernel can fill the chip with.
-template <int MDT, int G>
-__global__ __launch_bounds__(256) void corr_row_kernel(const float *__restrict__ in1, const float *__restrict__ in2,
-                                                       int C, int H, int W, float slope, float *__restrict__ out) {
-    constexpr int N = 2 * MDT + 1;
-    constexpr int XW = 256 / G;            // threads (pixels) per displacement group
-    constexpr int NDY = (N + G - 1) / G;   // displacement rows per thread
-    constexpr int CK = 4;
-    extern __shared__ float lds[];
-    const int Wp = W + 2 * MDT;
-    float *l1 = lds;                 // [CK][W]
-    float *l2 = lds + CK * W;        // [CK][N][Wp]
-    const int tid = threadIdx.x, y = blockIdx.x, b = blockIdx.y;
-    const int x = tid % XW, g = tid / XW;
-    const int64_t HW = (int64_t)H * W;
-    const float *g1 = in1 + (int64_t)b * C * HW + (int64_t)y * W;
-    const float *g2 = in2 + (int64_t)b * C * HW;
-
-    float acc[NDY][N];
-#pragma unroll
-    for (int i = 0; i < NDY; ++i)
-#pragma unroll
-        for (int j = 0; j < N; ++j) acc[i][j] = 0.f;
-
-    const bool active = x < W;
-    const int xr = active ? x : 0;
-    for (int c0 = 0; c0 < C; c0 += CK) {
-        __syncthreads();
-        for (int e = tid; e < CK * W; e += 256) {
-            const int c = e / W, px = e - c * W;
-            l1[e] = (c0 + c < C) ? g1[(int64_t)(c0 + c) * HW + px] : 0.f;
-        }
-        for (int e = tid; e < CK * N * Wp; e += 256) {
-            const int c = e / (N * Wp), r = e - c * (N * Wp);
-            const int dy = r / Wp, px = r - dy * Wp;
-            const int y2 = y + dy - MDT, x2 = px - MDT;
-            const bool ok = (c0 + c < C) && y2 >= 0 && y2 < H && x2 >= 0 && x2 < W;
-            l2[e] = ok ? g2[(int64_t)(c0 + c) * HW + (int64_t)y2 * W + x2] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < CK; ++c) {
-            const float a = l1[c * W + xr];
-#pragma unroll
-            for (int i = 0; i < NDY; ++i) {
-                const int dy = g + i * G;
-                if (dy < N) {
-                    const float *row = l2 + (c * N + dy) * Wp + xr;
-#pragma unroll
-                    for (int j = 0; j < N; ++j) acc[i][j] = __fmaf_rn(a, row[j], acc[i][j]);
-                }
-            }
-        }
-    }
-    if (!active) return;
-    const float fc = (float)C;
-#pragma unroll
-    for (int i = 0; i < NDY; ++i) {
-        const int dy = g + i * G;
-        if (dy < N) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                float v = acc[i][j] / fc;
-                if (slope != 0.f) v = v >= 0.f ? v : v * slope;
-                out[((int64_t)b * N * N + dy * N + j) * HW + (int64_t)y * W + x] = v;
-            }
-        }
-    }
-}
-
-template <int MDT>
-int launch_row(const float *in1, const float *in2, int B, int C, int H, int W, float slope, float *out, hipStream_t st) {
-    constexpr int N = 2 * MDT + 1;
-    const size_t shmem = sizeof(float) * 4 * ((size_t)W + (size_t)N * (W + 2 * MDT));
-    dim3 grid(H, B), block(256);
-    auto launch = [&](auto kern) -> int {
-        if (shmem > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-            if (e != hipSuccess) return (int)e;
-        }
-        hipLaunchKernelGGL(kern, grid, block, shmem, st, in1, in2, C, H, W, slope, out);
-        return 0;
-    };
-    if (W <= 64) return launch(corr_row_kernel<MDT, 4>);
-    if (W <= 128) return launch(corr_row_kernel<MDT, 2>);
-    return launch(corr_row_kernel<MDT, 1>);
-}
 
 // ---- MFMA kernel ---------------------------------------------------------------
 constexpr int MD = 4;       // max displacement this kernel is built for
@@ -276,6 +179,183 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_kernel(const float *_
     }
 }
 
+
+// ---- MFMA kernel, v2: LDS-DMA ring ------------------------------------------------------
+// Same MFMA formulation as corr_mfma_kernel; what changes is how operands reach LDS and how
+// much work one wave owns:
+//   * 4 waves, one per SIMD, 4 image rows per wave: 4 rows x 9 dy x 3 shifts x 4 = 432
+//     accumulator registers per lane (the 512-register file of a lone wave); 108 MFMAs per
+//     channel against 40 LDS operand reads (2.7 MFMA per read, 1.7 in v1);
+//   * tiles of in1 (16 rows x 64 px) and in2 (24 x 72, 4-px halo) for a chunk of 4 channels
+//     travel global -> LDS by global_load_lds_dwordx4 (1 KiB per wave-instruction, no staging
+//     registers).  Out-of-image pieces are not masked: their lanes read a 16-byte zero word,
+//     so every wave issues exactly PIECES_PER_WAVE DMAs per chunk and the counted
+//     s_waitcnt vmcnt(N) below is exact;
+//   * a ring of 3 LDS slots (44 KiB each): chunk k+2 is in flight while chunk k feeds the
+//     MFMAs; one raw s_barrier per chunk (after it, everybody has finished chunk k-1, whose
+//     slot the new DMA overwrites);
+//   * epilogue through LDS: each wave transposes its accumulators to [dx][64 px] rows and
+//     stores 256-byte coalesced segments (v1 stores 4-byte pieces at a 16-byte stride).
+// Requires W % 4 == 0, C % 4 == 0 and 16-byte aligned inputs (whole float4 pieces in or out of
+// the image); anything else takes corr_mfma_kernel.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+__device__ float4 g_corr_zero16;  // zero-initialised; the source of every out-of-image DMA lane
+
+template <int RY, int NW, int CK, int NSLOT>
+struct V2 {
+    static constexpr int TY = RY * NW;              // in1 rows per workgroup
+    static constexpr int TY2 = TY + 2 * MD;         // in2 rows (halo)
+    static constexpr int F1 = CK * TY * (TX / 4);   // float4 pieces-elements of the in1 tile
+    static constexpr int F2 = CK * TY2 * (PX2 / 4); // ... of the in2 tile
+    static constexpr int PIECES1 = (F1 + 63) / 64;  // a DMA piece = 64 lanes x 16 B
+    static constexpr int PIECES2 = (F2 + 63) / 64;
+    static constexpr int PPW = (PIECES1 + PIECES2 + NW - 1) / NW;  // pieces per wave per chunk (exact, incl. padding)
+    static constexpr int OFF2 = PIECES1 * 256;      // float offset of the in2 tile inside a slot
+    static constexpr int SLOT = PPW * NW * 256;     // floats per ring slot
+    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)NSLOT * SLOT;
+    static_assert(F1 % 64 == 0, "in1 tile must be whole pieces so that the in2 tile starts piece-aligned");
+    static_assert(NSLOT * SLOT >= NW * 2 * ND * TX, "epilogue staging must fit in the ring");
+};
+
+template <int RY, int NW, int CK, int NSLOT>
+__global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const float *__restrict__ in1,
+                                                                      const float *__restrict__ in2, int C, int H, int W,
+                                                                      float slope, float *__restrict__ out) {
+    using G = V2<RY, NW, CK, NSLOT>;
+    extern __shared__ float lds[];  // the ONLY LDS object of this kernel: [NSLOT][SLOT]
+    const int tid = threadIdx.x, lane = rpe_lane();
+    const int wave = rpe_uniform(tid >> 6);
+    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * G::TY, b = blockIdx.z;
+    const int64_t HW = (int64_t)H * W;
+    const float *g1 = in1 + (int64_t)b * C * HW;
+    const float *g2 = in2 + (int64_t)b * C * HW;
+    const float *zero = reinterpret_cast<const float *>(&g_corr_zero16);
+
+    // this lane's source offset (floats, inside a CK-channel chunk) for each of its wave's pieces
+    int off[G::PPW];  // < 0: outside the image or padding -> zero word  (CK*H*W < 2^31 checked by the launcher)
+#pragma unroll
+    for (int t = 0; t < G::PPW; ++t) {
+        const int q = wave + NW * t;  // piece index inside the slot, wave-uniform
+        int o = -1;
+        if (q < G::PIECES1) {
+            const int f = q * 64 + lane;  // float4 index in [CK][TY][16]
+            const int c = f / (G::TY * 16), r = (f / 16) % G::TY, c4 = f % 16;
+            const int y = y0 + r, x = x0 + 4 * c4;
+            if (y < H && x < W) o = c * (H * W) + y * W + x;
+        } else {
+            const int f = (q - G::PIECES1) * 64 + lane;  // float4 index in [CK][TY2][18]
+            const int c = f / (G::TY2 * 18), r = (f / 18) % G::TY2, c4 = f % 18;
+            const int y = y0 - MD + r, x = x0 - MD + 4 * c4;
+            if (f < G::F2 && y >= 0 && y < H && x >= 0 && x < W) o = c * (H * W) + y * W + x;
+        }
+        off[t] = o;
+    }
+
+    auto issue = [&](int chunk) {
+        float *slot = lds + (chunk % NSLOT) * G::SLOT;
+        const int64_t cbase = (int64_t)chunk * CK * HW;
+#pragma unroll
+        for (int t = 0; t < G::PPW; ++t) {
+            const int q = wave + NW * t;
+            const float *src = off[t] >= 0 ? (q >= G::PIECES1 ? g2 : g1) + cbase + off[t] : zero;
+            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(slot + q * 256), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[RY][ND][3];
+#pragma unroll
+    for (int ry = 0; ry < RY; ++ry)
+#pragma unroll
+        for (int dy = 0; dy < ND; ++dy)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) acc[ry][dy][s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = C / CK;
+    constexpr int AHEAD = NSLOT - 1;  // chunks in flight beyond the one being consumed
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p)
+        if (p < nchunks) issue(p);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        // chunk ch has landed once at most the DMAs of the AHEAD-1 younger chunks of THIS wave are pending
+        const int younger = min(nchunks - 1 - ch, AHEAD - 1);
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PPW) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... for every wave; and everyone is done reading chunk ch-1
+        if (ch + AHEAD < nchunks) issue(ch + AHEAD);
+
+        const float *l1 = lds + (ch % NSLOT) * G::SLOT;
+        const float *l2 = l1 + G::OFF2;
+#pragma unroll 1
+        for (int c = 0; c < CK; ++c) {
+            float a[RY];
+#pragma unroll
+            for (int ry = 0; ry < RY; ++ry) a[ry] = l1[(c * G::TY + wave * RY + ry) * TX + lane];
+#pragma unroll
+            for (int r = 0; r < RY + 2 * MD; ++r) {
+                const float *row = l2 + (c * G::TY2 + wave * RY + r) * PX2 + lane;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const float bv = row[4 * s];
+#pragma unroll
+                    for (int ry = 0; ry < RY; ++ry) {
+                        const int dy = r - ry;
+                        if (dy >= 0 && dy < ND)
+                            acc[ry][dy][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[ry], bv, acc[ry][dy][s], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: per wave and (row, dy), a [9 dx][64 px] staging tile in LDS, then coalesced stores
+    __builtin_amdgcn_s_barrier();  // all waves left the ring (no DMA pending: vmcnt(0) above)
+    float *stage = lds + wave * (2 * ND * TX);  // two tiles per wave, used alternately
+    const int g = lane >> 2, j = lane & 3;
+    const float fc = (float)C;
+#pragma unroll
+    for (int ry = 0; ry < RY; ++ry) {
+        const int y = y0 + wave * RY + ry;
+#pragma unroll
+        for (int dy = 0; dy < ND; ++dy) {
+            float *tile = stage + ((ry * ND + dy) & 1) * (ND * TX);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int dx = 4 * (s - 1) + j - i;
+                    if (dx >= -MD && dx <= MD) {
+                        float v = acc[ry][dy][s][i] / fc;
+                        if (slope != 0.f) v = v >= 0.f ? v : v * slope;
+                        tile[(dx + MD) * TX + 4 * g + i] = v;
+                    }
+                }
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's tile is written
+            __builtin_amdgcn_wave_barrier();
+            if (y < H && x0 + lane < W) {
+                float *o = out + ((int64_t)b * ND * ND + dy * ND) * HW + (int64_t)y * W + x0 + lane;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) o[(int64_t)d * HW] = tile[d * TX + lane];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+template <int RY, int NW, int CK, int NSLOT>
+int launch_mfma_dma(const float *in1, const float *in2, int B, int C, int H, int W, float slope, float *out, hipStream_t st) {
+    using G = V2<RY, NW, CK, NSLOT>;
+    if (C % CK != 0 || (int64_t)H * W * CK >= (1ll << 31)) return RPE_EUNSUPPORTED;
+    auto kern = corr_mfma_dma_kernel<RY, NW, CK, NSLOT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((W + TX - 1) / TX, (H + G::TY - 1) / G::TY, B), block(NW * RPE_WAVE);
+    hipLaunchKernelGGL(kern, grid, block, G::LDS_BYTES, st, in1, in2, C, H, W, slope, out);
+    return 0;
+}
+
 __global__ void probe_mfma4x4_kernel(float *out) {
     const int lane = threadIdx.x;
     f32x4 d = {0.f, 0.f, 0.f, 0.f};
@@ -300,27 +380,19 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int n = 2 * md + 1;
-    // pick: row kernel for every in-model size, MFMA tiles for large maps, direct for anything else
-    if (algo == 0) {
-        const bool row_ok = md >= 1 && md <= 4 && W <= 256 && H <= 65535;
-        if (md == MD && (int64_t)H * W > 256 * 256) algo = 2;
-        else algo = row_ok ? 3 : ((md == MD) ? 2 : 1);
-    }
-    if (algo == 3) {
-        if (W > 256 || H > 65535 || B > 65535) return RPE_EUNSUPPORTED;
-        int rc;
-        switch (md) {
-            case 1: rc = launch_row<1>(in1, in2, B, C, H, W, leaky_slope, out, st); break;
-            case 2: rc = launch_row<2>(in1, in2, B, C, H, W, leaky_slope, out, st); break;
-            case 3: rc = launch_row<3>(in1, in2, B, C, H, W, leaky_slope, out, st); break;
-            case 4: rc = launch_row<4>(in1, in2, B, C, H, W, leaky_slope, out, st); break;
-            default: return RPE_EUNSUPPORTED;
-        }
-        if (rc) return rc;
-    } else if (algo == 2) {
+    // pick (measured on MI355X, B=4): MFMA tiles from 72x120 maps up, one-thread-per-output below
+    if (algo == 0) algo = (md == MD && (int64_t)H * W >= 72 * 120) ? 2 : 1;
+    if (algo == 2) {
         if (md != MD) return RPE_EUNSUPPORTED;
         if (B > 65535) return RPE_EUNSUPPORTED;
         launch_mfma<2, 4, 4>(in1, in2, B, C, H, W, leaky_slope, out, st);
+    } else if (algo >= 4 && algo <= 6) {
+        const bool aligned = ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
+        if (md != MD || B > 65535 || W % 4 != 0 || !aligned) return RPE_EUNSUPPORTED;
+        int rc = algo == 4 ? launch_mfma_dma<2, 4, 4, 3>(in1, in2, B, C, H, W, leaky_slope, out, st)
+               : algo == 5 ? launch_mfma_dma<2, 4, 2, 4>(in1, in2, B, C, H, W, leaky_slope, out, st)
+                           : launch_mfma_dma<2, 8, 2, 3>(in1, in2, B, C, H, W, leaky_slope, out, st);
+        if (rc) return rc;
     } else if (algo == 1) {
         if ((int64_t)B * n * n > 65535 || H > 65535) return RPE_EUNSUPPORTED;
         dim3 grid((W + 255) / 256, H, B * n * n), block(256);

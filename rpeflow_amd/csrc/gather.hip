@@ -150,19 +150,23 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__
 __global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
                                                          const float *__restrict__ feat2d, int C2, int H, int W,
                                                          const float *__restrict__ feat3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn,
-                                                         int C3, int N, float *__restrict__ rows) {
+                                                         int C3, int N, int c_per_block, float *__restrict__ rows) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
+    const int b = blockIdx.z;
     if (i >= N) return;
-    const float px = xy[(int64_t)b * xy_sb + (int64_t)i * xy_sn], py = xy[(int64_t)b * xy_sb + xy_sd + (int64_t)i * xy_sn];
-    Bilinear bl;
-    bl.setup(px, py, H, W, false);
-    const int64_t HW = (int64_t)H * W;
-    const float *f2 = feat2d + (int64_t)b * C2 * HW;
-    float *row = rows + ((int64_t)b * N + i) * (C2 + C3);
-    for (int c = 0; c < C2; ++c) row[c] = bl.sample(f2 + (int64_t)c * HW);
+    const int CT = C2 + C3;
+    const int c0 = blockIdx.y * c_per_block, c1 = min(CT, c0 + c_per_block);
+    float *row = rows + ((int64_t)b * N + i) * CT;
+    if (c0 < C2) {
+        const float px = xy[(int64_t)b * xy_sb + (int64_t)i * xy_sn], py = xy[(int64_t)b * xy_sb + xy_sd + (int64_t)i * xy_sn];
+        Bilinear bl;
+        bl.setup(px, py, H, W, false);
+        const int64_t HW = (int64_t)H * W;
+        const float *f2 = feat2d + (int64_t)b * C2 * HW;
+        for (int c = c0; c < min(c1, C2); ++c) row[c] = bl.sample(f2 + (int64_t)c * HW);
+    }
     const float *f3 = feat3d + (int64_t)b * f3_sb + (int64_t)i * f3_sn;
-    for (int c = 0; c < C3; ++c) row[C2 + c] = f3[(int64_t)c * f3_sc];
+    for (int c = max(c0, C2); c < c1; ++c) row[c] = f3[(int64_t)(c - C2) * f3_sc];
 }
 
 __global__ __launch_bounds__(256) void project_rows_kernel(const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(256) void project_rows_kernel(const float *__restri
     for (int c = 0; c < C3; ++c) o[(int64_t)(3 + c) * HW] = row[C2 + c];
 }
 
+int channel_split(int C, long items, int B);
 int channel_split(int C, long items, int B) {
     // enough blocks to fill 256 CUs without making each thread's channel loop trivial
     long blocks = ((items + 255) / 256) * B;
@@ -258,8 +263,9 @@ RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_
     if (B == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(point_rows_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2, H, W,
-                       feat_3d, f3_sb, f3_sc, f3_sn, C3, N, workspace);
+    const int cpb = 8;  // channels per thread: 32-byte row segments, (C2+C3)/8 times the threads
+    hipLaunchKernelGGL(point_rows_kernel, dim3((N + 255) / 256, (C2 + C3 + cpb - 1) / cpb, B), dim3(256), 0, st, xy, xy_sb, xy_sd,
+                       xy_sn, feat_2d, C2, H, W, feat_3d, f3_sb, f3_sc, f3_sn, C3, N, cpb, workspace);
     hipLaunchKernelGGL(project_rows_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2,
                        H, W, C3, N, workspace, nn_idx, out);
     return rpe_launch_status();

@@ -170,12 +170,23 @@ def test_fps_transposed_view_as_the_model_passes_it():
 
 
 # ---------------------------------------------------------------- correlation2d
+DMA_ALGOS = (4, 5, 6)  # LDS-DMA ring variants of the MFMA kernel: need W % 4 == 0 and C % 4 (or 2) == 0
+
+
+def corr_algos(C, Wd, md):
+    algos = [1]
+    if md == 4:
+        algos.append(2)
+        if Wd % 4 == 0:
+            algos += [a for a in DMA_ALGOS if C % (4 if a == 4 else 2) == 0]
+    return algos
+
+
 @pytest.mark.parametrize("name", list(K.CORR_CASES))
 def test_correlation_golden_cases(golden_dir, name):
     a, b, md = K.corr_inputs(name)
     ref = G(golden_dir, name)["out"]
-    algos = [1, 2, 3] if md == 4 else [1, 3]
-    for algo in algos:
+    for algo in corr_algos(a.shape[1], a.shape[3], md):
         out = W._correlation2d_algo(dev(a), dev(b), md, algo).cpu().numpy()
         assert out.shape == ref.shape
         # correlation_test.cpp:82-83: mean |diff| < 1e-6; plus a worst-element bound
@@ -187,12 +198,13 @@ def test_correlation_golden_cases(golden_dir, name):
 
 
 @pytest.mark.parametrize("B,C,H,Wd", [(1, 3, 5, 7), (2, 33, 17, 65), (1, 16, 9, 15), (4, 192, 9, 15), (1, 64, 70, 130), (2, 5, 8, 64),
-                                      (1, 32, 10, 240), (2, 6, 3, 129), (1, 2, 2, 256)])
+                                      (1, 32, 10, 240), (2, 6, 3, 129), (1, 2, 2, 256), (2, 12, 40, 68), (1, 8, 33, 132),
+                                      (3, 4, 16, 64), (1, 20, 7, 4)])
 def test_correlation_ragged_shapes(B, C, H, Wd):
     r = I.rng(9000 + C + H + Wd)
     a, b = I.feature_map(r, B, C, H, Wd), I.feature_map(r, B, C, H, Wd)
     ref = O.correlation2d(a, b, 4)
-    for algo in (1, 2, 3):
+    for algo in corr_algos(C, Wd, 4):
         got = W._correlation2d_algo(dev(a), dev(b), 4, algo).cpu().numpy()
         assert np.isfinite(got).all()
         assert np.abs(got - ref).max() < 5e-6, algo
@@ -200,9 +212,9 @@ def test_correlation_ragged_shapes(B, C, H, Wd):
 
 def test_correlation_fused_leaky_relu():
     r = I.rng(9100)
-    a, b = I.feature_map(r, 2, 32, 18, 30), I.feature_map(r, 2, 32, 18, 30)
+    a, b = I.feature_map(r, 2, 32, 18, 32), I.feature_map(r, 2, 32, 18, 32)
     ref = torch.nn.functional.leaky_relu(torch.from_numpy(O.correlation2d(a, b, 4)), 0.1).numpy()  # RPEFlow_core.py:362
-    for algo in (1, 2, 3):
+    for algo in corr_algos(32, 32, 4):
         got = W._correlation2d_algo(dev(a), dev(b), 4, algo, leaky_slope=0.1).cpu().numpy()
         assert np.abs(got - ref).max() < 5e-6
 
@@ -225,7 +237,11 @@ def test_correlation_full_size_properties():
     assert (out[:, 55, :-2, 3:] - sh).abs().max().item() < 2e-5
     out2 = ops.correlation2d(2.0 * a, b, 4)
     assert torch.equal(out2, 2.0 * out)
-    # both kernels agree on a crop
-    d = W._correlation2d_algo(a[:, :, :64, :128].contiguous(), b[:, :, :64, :128].contiguous(), 4, 1)
-    m = W._correlation2d_algo(a[:, :, :64, :128].contiguous(), b[:, :, :64, :128].contiguous(), 4, 2)
-    assert (d - m).abs().max().item() < 5e-6
+    # every kernel agrees on a crop, and the DMA-ring variants agree with the first MFMA kernel at full size
+    ca, cb = a[:, :, :64, :128].contiguous(), b[:, :, :64, :128].contiguous()
+    d = W._correlation2d_algo(ca, cb, 4, 1)
+    for algo in (2,) + DMA_ALGOS:
+        assert (d - W._correlation2d_algo(ca, cb, 4, algo)).abs().max().item() < 5e-6, algo
+    full = W._correlation2d_algo(a, b, 4, 2)
+    for algo in DMA_ALGOS:
+        assert (full - W._correlation2d_algo(a, b, 4, algo)).abs().max().item() < 5e-6, algo
