@@ -23,6 +23,9 @@
 //
 // out[b][(dy+md)*(2md+1)+(dx+md)][y][x] = (1/C) sum_c in1[b][c][y][x] * in2[b][c][y+dy][x+dx],
 // zero outside the image (wrapper.py:56-65).
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -181,33 +184,48 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_kernel(const float *_
 
 
 // ---- MFMA kernel, v2: LDS-DMA ring ------------------------------------------------------
-// Same MFMA formulation as corr_mfma_kernel; what changes is how operands reach LDS and how
-// much work one wave owns:
-//   * 4 waves, one per SIMD, 4 image rows per wave: 4 rows x 9 dy x 3 shifts x 4 = 432
-//     accumulator registers per lane (the 512-register file of a lone wave); 108 MFMAs per
-//     channel against 40 LDS operand reads (2.7 MFMA per read, 1.7 in v1);
-//   * tiles of in1 (16 rows x 64 px) and in2 (24 x 72, 4-px halo) for a chunk of 4 channels
-//     travel global -> LDS by global_load_lds_dwordx4 (1 KiB per wave-instruction, no staging
-//     registers).  Out-of-image pieces are not masked: their lanes read a 16-byte zero word,
-//     so every wave issues exactly PIECES_PER_WAVE DMAs per chunk and the counted
-//     s_waitcnt vmcnt(N) below is exact;
-//   * a ring of 3 LDS slots (44 KiB each): chunk k+2 is in flight while chunk k feeds the
-//     MFMAs; one raw s_barrier per chunk (after it, everybody has finished chunk k-1, whose
-//     slot the new DMA overwrites);
-//   * epilogue through LDS: each wave transposes its accumulators to [dx][64 px] rows and
-//     stores 256-byte coalesced segments (v1 stores 4-byte pieces at a 16-byte stride).
-// Requires W % 4 == 0, C % 4 == 0 and 16-byte aligned inputs (whole float4 pieces in or out of
+// Same MFMA formulation as corr_mfma_kernel; what changes is how operands reach LDS:
+//   * tiles of in1 (TY rows x 64 px) and in2 (TY+8 rows x 72 px, 4-px halo) for a chunk of CK
+//     channels travel global -> LDS by global_load_lds_dwordx4 (1 KiB per wave-instruction, no
+//     staging registers).  Out-of-image pieces are not masked: their lanes read a 16-byte zero
+//     word, so every wave issues exactly PPW DMAs per chunk and the counted s_waitcnt vmcnt(N)
+//     below is exact;
+//   * a ring of NSLOT LDS slots: chunks k+1..k+NSLOT-1 are in flight while chunk k feeds the
+//     MFMAs; one raw s_barrier per chunk (after it everybody has finished chunk k-1, whose slot
+//     the next DMAs overwrite);
+//   * PD > 0: the operand reads of one (channel, in2 row) step are issued PD steps ahead of the
+//     MFMAs that consume them (a register ring of PD+1 x 3 B operands, A operands double-buffered),
+//     across channel boundaries inside a chunk; sched_group_barrier pins "3 LDS reads, then the
+//     step's MFMAs"; the next chunk's DMAs are issued one piece every few steps instead of as a
+//     burst after the barrier (a DMA issue costs the wave tens of cycles, which its SIMD partner
+//     fills with MFMAs as long as the two do not burst together);
+//   * epilogue through LDS: each wave transposes its accumulators to [dx][64 px] rows and stores
+//     256-byte coalesced segments (v1 stores 4-byte pieces at a 16-byte stride).
+// With RY = 2 the 216 accumulators leave room for two waves per SIMD (8 waves x 2 rows = 16 rows
+// per workgroup); RY = 4 (432 accumulators) does not survive hipcc's AGPR/VGPR split.
+// Requires W % 4 == 0, C % CK == 0 and 16-byte aligned inputs (whole float4 pieces in or out of
 // the image); anything else takes corr_mfma_kernel.
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
 __device__ float4 g_corr_zero16;  // zero-initialised; the source of every out-of-image DMA lane
 
+// f(integral_constant<int, 0>{}), ..., f(integral_constant<int, N-1>{}): a loop whose index is a
+// constant expression (sched_group_barrier needs immediates)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 template <int RY, int NW, int CK, int NSLOT>
 struct V2 {
     static constexpr int TY = RY * NW;              // in1 rows per workgroup
     static constexpr int TY2 = TY + 2 * MD;         // in2 rows (halo)
-    static constexpr int F1 = CK * TY * (TX / 4);   // float4 pieces-elements of the in1 tile
+    static constexpr int F1 = CK * TY * (TX / 4);   // float4 elements of the in1 tile
     static constexpr int F2 = CK * TY2 * (PX2 / 4); // ... of the in2 tile
     static constexpr int PIECES1 = (F1 + 63) / 64;  // a DMA piece = 64 lanes x 16 B
     static constexpr int PIECES2 = (F2 + 63) / 64;
@@ -219,15 +237,27 @@ struct V2 {
     static_assert(NSLOT * SLOT >= NW * 2 * ND * TX, "epilogue staging must fit in the ring");
 };
 
-template <int RY, int NW, int CK, int NSLOT>
+template <int RY, int NW, int CK, int NSLOT, int PD>
 __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const float *__restrict__ in1,
-                                                                      const float *__restrict__ in2, int C, int H, int W,
-                                                                      float slope, float *__restrict__ out) {
+                                                                      const float *__restrict__ in2, int nbatch, int C, int H,
+                                                                      int W, float slope, float *__restrict__ out) {
     using G = V2<RY, NW, CK, NSLOT>;
     extern __shared__ float lds[];  // the ONLY LDS object of this kernel: [NSLOT][SLOT]
     const int tid = threadIdx.x, lane = rpe_lane();
     const int wave = rpe_uniform(tid >> 6);
-    const int x0 = blockIdx.x * TX, y0 = blockIdx.y * G::TY, b = blockIdx.z;
+    // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (ids i and i+8 share one, each with
+    // its own L2), so XCD k is given the contiguous range [k*per, (k+1)*per) of the ROW-major tile
+    // order: the ~32 tiles an XCD runs at once are then about two full tile rows.  That matters
+    // because an in2 segment [x0-4, x0+68) spans four 128-byte lines of which two are also read by
+    // the left and two by the right neighbour (and 8 of 24 rows by the tile below): un-shared, in2 is
+    // fetched 3x (measured: fabric traffic 1.75 GB -> 1.20 GB on the 1x256x544x960 case).
+    // Speed only; any placement gives the same result.
+    const int nty = (H + G::TY - 1) / G::TY, ntx = (W + TX - 1) / TX;
+    const int per = gridDim.x / 8;
+    const int tile = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
+    if (tile >= ntx * nty * nbatch) return;  // padding workgroups of the remap (uniform exit, before any barrier)
+    const int b = tile / (ntx * nty), tr = tile % (ntx * nty);
+    const int x0 = (tr % ntx) * TX, y0 = (tr / ntx) * G::TY;
     const int64_t HW = (int64_t)H * W;
     const float *g1 = in1 + (int64_t)b * C * HW;
     const float *g2 = in2 + (int64_t)b * C * HW;
@@ -253,15 +283,16 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
         off[t] = o;
     }
 
-    auto issue = [&](int chunk) {
+    auto issue_piece = [&](int chunk, int t) {  // t is a compile-time constant at every call site
         float *slot = lds + (chunk % NSLOT) * G::SLOT;
         const int64_t cbase = (int64_t)chunk * CK * HW;
+        const int q = wave + NW * t;
+        const float *src = off[t] >= 0 ? (q >= G::PIECES1 ? g2 : g1) + cbase + off[t] : zero;
+        __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(slot + q * 256), 16, 0, 0);
+    };
+    auto issue = [&](int chunk) {
 #pragma unroll
-        for (int t = 0; t < G::PPW; ++t) {
-            const int q = wave + NW * t;
-            const float *src = off[t] >= 0 ? (q >= G::PIECES1 ? g2 : g1) + cbase + off[t] : zero;
-            __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(slot + q * 256), 16, 0, 0);
-        }
+        for (int t = 0; t < G::PPW; ++t) issue_piece(chunk, t);
     };
 
     f32x4 acc[RY][ND][3];
@@ -274,39 +305,85 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
 
     const int nchunks = C / CK;
     constexpr int AHEAD = NSLOT - 1;  // chunks in flight beyond the one being consumed
+    static_assert(AHEAD >= 1 && AHEAD <= 6, "ring depth supported by the wait table below");
+    static_assert((AHEAD - 1) * G::PPW <= 63, "vmcnt is a 6-bit counter");
 #pragma unroll
     for (int p = 0; p < AHEAD; ++p)
         if (p < nchunks) issue(p);
     for (int ch = 0; ch < nchunks; ++ch) {
-        // chunk ch has landed once at most the DMAs of the AHEAD-1 younger chunks of THIS wave are pending
+        // chunk ch has landed once at most the DMAs of the younger chunks of THIS wave are pending
         const int younger = min(nchunks - 1 - ch, AHEAD - 1);
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PPW) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        switch (younger) {  // wave-uniform
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * G::PPW) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PPW) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * G::PPW) : "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * G::PPW) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * G::PPW) : "memory"); break;
+        }
         __builtin_amdgcn_s_barrier();  // ... for every wave; and everyone is done reading chunk ch-1
-        if (ch + AHEAD < nchunks) issue(ch + AHEAD);
+        const bool more = ch + AHEAD < nchunks;  // wave-uniform
+        if (PD == 0 && more) issue(ch + AHEAD);  // PD > 0: spread over the MFMA steps below
 
-        const float *l1 = lds + (ch % NSLOT) * G::SLOT;
-        const float *l2 = l1 + G::OFF2;
+        const float *l1 = lds + (ch % NSLOT) * G::SLOT + (wave * RY) * TX + lane;
+        const float *l2 = lds + (ch % NSLOT) * G::SLOT + G::OFF2 + (wave * RY) * PX2 + lane;
+        if constexpr (PD == 0) {
 #pragma unroll 1
-        for (int c = 0; c < CK; ++c) {
-            float a[RY];
+            for (int c = 0; c < CK; ++c) {
+                float a[RY];
 #pragma unroll
-            for (int ry = 0; ry < RY; ++ry) a[ry] = l1[(c * G::TY + wave * RY + ry) * TX + lane];
+                for (int ry = 0; ry < RY; ++ry) a[ry] = l1[(c * G::TY + ry) * TX];
 #pragma unroll
-            for (int r = 0; r < RY + 2 * MD; ++r) {
-                const float *row = l2 + (c * G::TY2 + wave * RY + r) * PX2 + lane;
+                for (int r = 0; r < RY + 2 * MD; ++r) {
+                    const float *row = l2 + (c * G::TY2 + r) * PX2;
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const float bv = row[4 * s];
+                    for (int s = 0; s < 3; ++s) {
+                        const float bv = row[4 * s];
+#pragma unroll
+                        for (int ry = 0; ry < RY; ++ry) {
+                            const int dy = r - ry;  // in2 row (y + dy - MD) sits at local row ry + dy
+                            if (dy >= 0 && dy < ND)
+                                acc[ry][dy][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[ry], bv, acc[ry][dy][s], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else {
+            constexpr int ROWS = RY + 2 * MD, STEPS = CK * ROWS;
+            constexpr int DMA_EVERY = STEPS / G::PPW;
+            static_assert(DMA_EVERY >= 1, "more DMA pieces than steps");
+            float br[PD + 1][3], ar[2][RY];
+            auto load_step = [&](int t) {  // compile-time t after inlining
+                const int c = t / ROWS, r = t % ROWS;
+                if (r == 0) {
+#pragma unroll
+                    for (int ry = 0; ry < RY; ++ry) ar[c & 1][ry] = l1[(c * G::TY + ry) * TX];
+                }
+#pragma unroll
+                for (int s = 0; s < 3; ++s) br[t % (PD + 1)][s] = l2[(c * G::TY2 + r) * PX2 + 4 * s];
+            };
+#pragma unroll
+            for (int t = 0; t < PD; ++t) load_step(t);
+            static_for<STEPS>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                constexpr int c = t / ROWS, r = t % ROWS;
+                if constexpr (t % DMA_EVERY == DMA_EVERY / 2 && t / DMA_EVERY < G::PPW) {
+                    if (more) issue_piece(ch + AHEAD, t / DMA_EVERY);
+                }
+                if constexpr (t + PD < STEPS) load_step(t + PD);
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
 #pragma unroll
                     for (int ry = 0; ry < RY; ++ry) {
                         const int dy = r - ry;
                         if (dy >= 0 && dy < ND)
-                            acc[ry][dy][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[ry], bv, acc[ry][dy][s], 0, 0, 0);
+                            acc[ry][dy][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[c & 1][ry], br[t % (PD + 1)][s], acc[ry][dy][s], 0, 0, 0);
                     }
-                }
-            }
+                constexpr int n_valid = (r < RY ? r + 1 : (r >= ND ? ROWS - r : RY));  // in1 rows this in2 row pairs with
+                if constexpr (t + PD < STEPS)
+                    __builtin_amdgcn_sched_group_barrier(0x100, ((t + PD) % ROWS == 0) ? 3 + RY : 3, 0);  // DS reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * n_valid, 0);                             // MFMAs
+            });
         }
     }
 
@@ -320,7 +397,7 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
         const int y = y0 + wave * RY + ry;
 #pragma unroll
         for (int dy = 0; dy < ND; ++dy) {
-            float *tile = stage + ((ry * ND + dy) & 1) * (ND * TX);
+            float *tile_lds = stage + ((ry * ND + dy) & 1) * (ND * TX);
 #pragma unroll
             for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -329,7 +406,7 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
                     if (dx >= -MD && dx <= MD) {
                         float v = acc[ry][dy][s][i] / fc;
                         if (slope != 0.f) v = v >= 0.f ? v : v * slope;
-                        tile[(dx + MD) * TX + 4 * g + i] = v;
+                        tile_lds[(dx + MD) * TX + 4 * g + i] = v;
                     }
                 }
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's tile is written
@@ -337,24 +414,27 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
             if (y < H && x0 + lane < W) {
                 float *o = out + ((int64_t)b * ND * ND + dy * ND) * HW + (int64_t)y * W + x0 + lane;
 #pragma unroll
-                for (int d = 0; d < ND; ++d) o[(int64_t)d * HW] = tile[d * TX + lane];
+                for (int d = 0; d < ND; ++d) o[(int64_t)d * HW] = tile_lds[d * TX + lane];
             }
             __builtin_amdgcn_wave_barrier();
         }
     }
 }
 
-template <int RY, int NW, int CK, int NSLOT>
+template <int RY, int NW, int CK, int NSLOT, int PD>
 int launch_mfma_dma(const float *in1, const float *in2, int B, int C, int H, int W, float slope, float *out, hipStream_t st) {
     using G = V2<RY, NW, CK, NSLOT>;
     if (C % CK != 0 || (int64_t)H * W * CK >= (1ll << 31)) return RPE_EUNSUPPORTED;
-    auto kern = corr_mfma_dma_kernel<RY, NW, CK, NSLOT>;
+    auto kern = corr_mfma_dma_kernel<RY, NW, CK, NSLOT, PD>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    dim3 grid((W + TX - 1) / TX, (H + G::TY - 1) / G::TY, B), block(NW * RPE_WAVE);
-    hipLaunchKernelGGL(kern, grid, block, G::LDS_BYTES, st, in1, in2, C, H, W, slope, out);
+    const int64_t tiles = (int64_t)((W + TX - 1) / TX) * ((H + G::TY - 1) / G::TY) * B;
+    if (tiles > (1 << 28)) return RPE_EUNSUPPORTED;
+    dim3 grid((unsigned)((tiles + 7) / 8 * 8)), block(NW * RPE_WAVE);  // multiple of 8: see the tile-order note
+    hipLaunchKernelGGL(kern, grid, block, G::LDS_BYTES, st, in1, in2, B, C, H, W, slope, out);
     return 0;
 }
+
 
 __global__ void probe_mfma4x4_kernel(float *out) {
     const int lane = threadIdx.x;
@@ -380,18 +460,30 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int n = 2 * md + 1;
-    // pick (measured on MI355X, B=4): MFMA tiles from 72x120 maps up, one-thread-per-output below
-    if (algo == 0) algo = (md == MD && (int64_t)H * W >= 72 * 120) ? 2 : 1;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
+    // pick (measured on MI355X, B=4, see profiles/): the LDS-DMA ring kernels where their alignment
+    // conditions hold -- 8 waves x 2 rows from 144x240 maps up, 4 waves x 2 rows down to 36x60 --
+    // the register-staged MFMA kernel for other large maps, one thread per output for the rest.
+    if (algo == 0) {
+        const bool dma_ok = md == MD && W % 4 == 0 && aligned && B <= 65535 && (int64_t)H * W * 4 < (1ll << 31);
+        const int64_t px = (int64_t)H * W;
+        if (dma_ok && C % 4 == 0 && px >= 144 * 240) algo = 8;
+        else if (dma_ok && C % 2 == 0 && px >= 144 * 240) algo = 7;
+        else if (dma_ok && C % 4 == 0 && px >= 36 * 60) algo = 4;
+        else if (md == MD && px >= 72 * 120) algo = 2;
+        else algo = 1;
+    }
     if (algo == 2) {
         if (md != MD) return RPE_EUNSUPPORTED;
         if (B > 65535) return RPE_EUNSUPPORTED;
         launch_mfma<2, 4, 4>(in1, in2, B, C, H, W, leaky_slope, out, st);
-    } else if (algo >= 4 && algo <= 6) {
-        const bool aligned = ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
+    } else if (algo >= 4 && algo <= 8) {
         if (md != MD || B > 65535 || W % 4 != 0 || !aligned) return RPE_EUNSUPPORTED;
-        int rc = algo == 4 ? launch_mfma_dma<2, 4, 4, 3>(in1, in2, B, C, H, W, leaky_slope, out, st)
-               : algo == 5 ? launch_mfma_dma<2, 4, 2, 4>(in1, in2, B, C, H, W, leaky_slope, out, st)
-                           : launch_mfma_dma<2, 8, 2, 3>(in1, in2, B, C, H, W, leaky_slope, out, st);
+        int rc = algo == 4 ? launch_mfma_dma<2, 4, 4, 3, 4>(in1, in2, B, C, H, W, leaky_slope, out, st)
+               : algo == 5 ? launch_mfma_dma<2, 4, 2, 4, 0>(in1, in2, B, C, H, W, leaky_slope, out, st)
+               : algo == 6 ? launch_mfma_dma<2, 8, 2, 3, 0>(in1, in2, B, C, H, W, leaky_slope, out, st)
+               : algo == 7 ? launch_mfma_dma<2, 8, 2, 3, 3>(in1, in2, B, C, H, W, leaky_slope, out, st)
+                           : launch_mfma_dma<2, 8, 4, 3, 2>(in1, in2, B, C, H, W, leaky_slope, out, st);
         if (rc) return rc;
     } else if (algo == 1) {
         if ((int64_t)B * n * n > 65535 || H > 65535) return RPE_EUNSUPPORTED;
