@@ -237,7 +237,7 @@ struct V2 {
     static_assert(NSLOT * SLOT >= NW * 2 * ND * TX, "epilogue staging must fit in the ring");
 };
 
-template <int RY, int NW, int CK, int NSLOT, int PD>
+template <int RY, int NW, int CK, int NSLOT, int PD, bool SPREAD>
 __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const float *__restrict__ in1,
                                                                       const float *__restrict__ in2, int nbatch, int C, int H,
                                                                       int W, float slope, float *__restrict__ out) {
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
         }
         __builtin_amdgcn_s_barrier();  // ... for every wave; and everyone is done reading chunk ch-1
         const bool more = ch + AHEAD < nchunks;  // wave-uniform
-        if (PD == 0 && more) issue(ch + AHEAD);  // PD > 0: spread over the MFMA steps below
+        if (!(PD > 0 && SPREAD) && more) issue(ch + AHEAD);  // SPREAD: issued piece by piece among the MFMA steps below
 
         const float *l1 = lds + (ch % NSLOT) * G::SLOT + (wave * RY) * TX + lane;
         const float *l2 = lds + (ch % NSLOT) * G::SLOT + G::OFF2 + (wave * RY) * PX2 + lane;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
             static_for<STEPS>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
                 constexpr int c = t / ROWS, r = t % ROWS;
-                if constexpr (t % DMA_EVERY == DMA_EVERY / 2 && t / DMA_EVERY < G::PPW) {
+                if constexpr (SPREAD && t % DMA_EVERY == DMA_EVERY / 2 && t / DMA_EVERY < G::PPW) {
                     if (more) issue_piece(ch + AHEAD, t / DMA_EVERY);
                 }
                 if constexpr (t + PD < STEPS) load_step(t + PD);
@@ -421,11 +421,11 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
     }
 }
 
-template <int RY, int NW, int CK, int NSLOT, int PD>
+template <int RY, int NW, int CK, int NSLOT, int PD, bool SPREAD>
 int launch_mfma_dma(const float *in1, const float *in2, int B, int C, int H, int W, float slope, float *out, hipStream_t st) {
     using G = V2<RY, NW, CK, NSLOT>;
     if (C % CK != 0 || (int64_t)H * W * CK >= (1ll << 31)) return RPE_EUNSUPPORTED;
-    auto kern = corr_mfma_dma_kernel<RY, NW, CK, NSLOT, PD>;
+    auto kern = corr_mfma_dma_kernel<RY, NW, CK, NSLOT, PD, SPREAD>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     const int64_t tiles = (int64_t)((W + TX - 1) / TX) * ((H + G::TY - 1) / G::TY) * B;
@@ -467,8 +467,7 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
     if (algo == 0) {
         const bool dma_ok = md == MD && W % 4 == 0 && aligned && B <= 65535 && (int64_t)H * W * 4 < (1ll << 31);
         const int64_t px = (int64_t)H * W;
-        if (dma_ok && C % 4 == 0 && px >= 144 * 240) algo = 8;
-        else if (dma_ok && C % 2 == 0 && px >= 144 * 240) algo = 7;
+        if (dma_ok && C % 2 == 0 && px >= 144 * 240) algo = 7;
         else if (dma_ok && C % 4 == 0 && px >= 36 * 60) algo = 4;
         else if (md == MD && px >= 72 * 120) algo = 2;
         else algo = 1;
@@ -479,11 +478,11 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
         launch_mfma<2, 4, 4>(in1, in2, B, C, H, W, leaky_slope, out, st);
     } else if (algo >= 4 && algo <= 8) {
         if (md != MD || B > 65535 || W % 4 != 0 || !aligned) return RPE_EUNSUPPORTED;
-        int rc = algo == 4 ? launch_mfma_dma<2, 4, 4, 3, 4>(in1, in2, B, C, H, W, leaky_slope, out, st)
-               : algo == 5 ? launch_mfma_dma<2, 4, 2, 4, 0>(in1, in2, B, C, H, W, leaky_slope, out, st)
-               : algo == 6 ? launch_mfma_dma<2, 8, 2, 3, 0>(in1, in2, B, C, H, W, leaky_slope, out, st)
-               : algo == 7 ? launch_mfma_dma<2, 8, 2, 3, 3>(in1, in2, B, C, H, W, leaky_slope, out, st)
-                           : launch_mfma_dma<2, 8, 4, 3, 2>(in1, in2, B, C, H, W, leaky_slope, out, st);
+        int rc = algo == 4 ? launch_mfma_dma<2, 4, 4, 3, 4, true>(in1, in2, B, C, H, W, leaky_slope, out, st)
+               : algo == 5 ? launch_mfma_dma<2, 4, 2, 4, 0, false>(in1, in2, B, C, H, W, leaky_slope, out, st)
+               : algo == 6 ? launch_mfma_dma<2, 8, 2, 3, 0, false>(in1, in2, B, C, H, W, leaky_slope, out, st)
+               : algo == 7 ? launch_mfma_dma<2, 8, 2, 3, 3, true>(in1, in2, B, C, H, W, leaky_slope, out, st)
+                           : launch_mfma_dma<2, 8, 4, 3, 3, false>(in1, in2, B, C, H, W, leaky_slope, out, st);
         if (rc) return rc;
     } else if (algo == 1) {
         if ((int64_t)B * n * n > 65535 || H > 65535) return RPE_EUNSUPPORTED;
