@@ -167,8 +167,9 @@ int rpe_corr3d_weighted_sum(const float *vals, int gather,
  * Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation
  * kernel relies on: out[64*4] = D for A[lane]=lane, B[lane]=100*lane (one K).   */
 int rpe_probe_mfma4x4(float *out256, rpe_stream_t stream);
-/* Selects the FPS kernel: 1 (default) = DPP reductions + packed fp32, 0 = shuffle-based
- * first version.  Both give identical indices; kept for A/B timing and cross-checks. */
+/* Selects the FPS kernel: 1 (default) = DPP reductions + packed fp32, 2 = Morton-sorted
+ * points with exact box skipping (1024 < N <= 16384, else 1), 0 = shuffle-based first
+ * version.  All give identical indices; kept for A/B timing and cross-checks. */
 int rpe_debug_set_fps_variant(int variant);
 
 #ifdef __cplusplus
