@@ -1,0 +1,137 @@
+"""Sharded evaluation harness -- the counterpart of eval_withocc.py:43-135 / eval_noocc.py:46-116.
+
+The reference evaluates on one GPU and pulls ~12 scalars per sample to the host with ``.item()``.
+Here frame pairs are independent units (BatchNorm in eval mode, no cross-sample state), so:
+
+* one process per GPU; rank r evaluates samples r, r+W, r+2W, ... -- no padding or duplication
+  (``DistributedSampler``'s pad-to-even would bias the count-weighted means);
+* the accumulators live in ONE float64[12] tensor on the device, updated without host syncs:
+  {count, EPE, 1px, Fl} 2-D, {count, EPE, 5cm, 10cm} 3-D, the same for non-occluded points;
+* after the loop a single SUM all-reduce of that tensor (RCCL over xGMI through
+  torch.distributed's "nccl" backend; "gloo" on CPU in the tests) -- the template is
+  ``dist_reduce_sum`` (utils.py:26-31), which the reference calls once per scalar.
+
+Counts stay below 2^53, so float64 sums of counts are exact; the value sums differ from a
+single-process run only by float64 re-association.
+"""
+import argparse
+import json
+import os
+
+import torch
+
+FIELDS = ["count_2d", "epe_2d", "acc_1px", "fl", "count_3d", "epe_3d", "acc_5cm", "acc_10cm",
+          "count_3d_noc", "epe_3d_noc", "acc_5cm_noc", "acc_10cm_noc"]
+
+
+def new_accumulator(device):
+    return torch.zeros(len(FIELDS), dtype=torch.float64, device=device)
+
+
+@torch.no_grad()
+def accumulate(acc, outputs, inputs):
+    """Adds one batch to ``acc``.  Per-sample arithmetic of eval_withocc.py:65-108: EPE maps
+    sqrt(sum diff^2) in fp32; masks from the extra target channel (if any) and not-NaN; Fl =
+    epe > 3 and epe/|gt| > 0.05; the non-occluded group only where inputs carry occ_mask_3d."""
+    f2p, f3p = outputs["flow_2d"].float(), outputs["flow_3d"].float()
+    f2t, f3t = inputs["flow_2d"].float(), inputs["flow_3d"].float()
+    m2 = f2t[:, 2] > 0 if f2t.shape[1] > 2 else torch.ones_like(f2t[:, 0], dtype=torch.bool)
+    m3 = f3t[:, 3] > 0 if f3t.shape[1] > 3 else torch.ones_like(f3t[:, 0], dtype=torch.bool)
+    f2t, f3t = f2t[:, :2], f3t[:, :3]
+    epe2 = torch.sqrt(torch.sum((f2p - f2t) ** 2, dim=1))
+    epe3 = torch.sqrt(torch.sum((f3p - f3t) ** 2, dim=1))
+    m2 = m2 & ~torch.isnan(epe2)
+    m3 = m3 & ~torch.isnan(epe3)
+    fl = (epe2 > 3.0) & (epe2 / torch.linalg.norm(f2t, dim=1) > 0.05)
+
+    def group(epe, mask, *thresholds_or_maps):
+        d = lambda t: t.to(torch.float64).sum()
+        out = [d(mask), d(torch.where(mask, epe, torch.zeros_like(epe)))]
+        for t in thresholds_or_maps:
+            hit = t if torch.is_tensor(t) else (epe < t)
+            out.append(d(hit & mask))
+        return out
+
+    vals = group(epe2, m2, 1.0, fl) + group(epe3, m3, 0.05, 0.1)
+    if "occ_mask_3d" in inputs:
+        vals += group(epe3, m3 & (inputs["occ_mask_3d"] == 0), 0.05, 0.1)
+    else:
+        vals += [torch.zeros((), dtype=torch.float64, device=acc.device)] * 4
+    acc += torch.stack(vals).to(acc.device)
+    return acc
+
+
+def finalize(acc):
+    """eval_withocc.py:119-135: sums / counts (percentages for the accuracy entries)."""
+    a = [float(x) for x in acc.tolist()]
+    div = lambda s, c: s / c if c > 0 else float("nan")
+    m = {"EPE2D": div(a[1], a[0]), "1px": 100 * div(a[2], a[0]), "Fl": 100 * div(a[3], a[0]),
+         "EPE3D": div(a[5], a[4]), "5cm": 100 * div(a[6], a[4]), "10cm": 100 * div(a[7], a[4])}
+    if a[8] > 0:
+        m.update({"EPE3D_noc": div(a[9], a[8]), "5cm_noc": 100 * div(a[10], a[8]), "10cm_noc": 100 * div(a[11], a[8])})
+    m["counts"] = {"2d": a[0], "3d": a[4], "3d_noc": a[8]}
+    return m
+
+
+def shard_indices(n_samples, rank, world_size):
+    """Rank r takes r, r+W, ...; the union over ranks is exactly range(n_samples)."""
+    return list(range(rank, n_samples, world_size))
+
+
+def collate(samples):
+    return {k: torch.stack([s[k] for s in samples]) for k in samples[0]}
+
+
+def to_device(batch, device):
+    """copy_to_device (utils.py:34-43) for the flat dict the datasets return."""
+    return {k: v.to(device, non_blocking=True) for k, v in batch.items()}
+
+
+@torch.no_grad()
+def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=None):
+    """Evaluates this rank's shard and returns the GLOBAL metrics (identical on every rank)."""
+    acc = new_accumulator(device)
+    mine = shard_indices(len(dataset), rank, world_size)
+    for start in range(0, len(mine), batch_size):  # the last batch may be short
+        batch = to_device(collate([dataset[i] for i in mine[start:start + batch_size]]), device)
+        accumulate(acc, model(batch), batch)
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # the one collective of the evaluation
+    return finalize(acc), acc
+
+
+def main():
+    p = argparse.ArgumentParser(description="Sharded synthetic evaluation (one process per GPU; launch with torchrun for N > 1)")
+    p.add_argument("--samples", type=int, default=8)
+    p.add_argument("--batch", type=int, default=4)
+    p.add_argument("--height", type=int, default=544)
+    p.add_argument("--width", type=int, default=960)
+    p.add_argument("--points", type=int, default=8192)
+    p.add_argument("--dsec", action="store_true")
+    p.add_argument("--weights", default=None, help="reference checkpoint ({'state_dict': ...}); default: seeded random init")
+    args = p.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    from .model import RPEFlow
+    torch.manual_seed(0)
+    model = RPEFlow().to(device).eval()
+    if args.weights:
+        model.load_state_dict(torch.load(args.weights, map_location=device)["state_dict"], strict=True)
+    from .synthetic import SyntheticPairs
+    data = SyntheticPairs(args.samples, args.height, args.width, args.points, dsec=args.dsec)
+    metrics, _ = evaluate(model, data, args.batch, device, rank, world)
+    if rank == 0:
+        print(json.dumps(metrics))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

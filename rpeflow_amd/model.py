@@ -1,0 +1,540 @@
+"""RPEFlow model counterpart -- the CALLER of the hot path.
+
+Same module tree, parameter names and shapes as the reference's ``models/RPEFlow.py`` +
+``models/RPEFlow_core.py`` (so its checkpoints load with ``strict=True``), same forward
+arithmetic at inference.  Every hot-path call -- FPS, KNN, correlation2d, warps, gathers,
+PointConv, Correlation3D -- goes to the HIP kernels of this package; dense convolutions,
+the Restormer cross-attention blocks and resizes stay on PyTorch-ROCm (MIOpen / hipBLASLt),
+which SURVEY.md section 2 marks as outside the hot path.
+
+Inference only.  The mutual-information heads (models/mutual_info.py) exist as parameter
+holders so state dicts match, but are not evaluated: their output is a training loss that
+never reaches the flows (RPEFlow_core.py:33-35, RPEFlow.py:95-99).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .csrc import correlation2d, k_nearest_neighbor
+from .pwc3d_core import Correlation3D, FeaturePyramid3D, FlowEstimator3D, build_pc_pyramid
+from .utils import (Conv1dNormRelu, Conv2dNormRelu, backwarp_2d, backwarp_3d, grid_sample_wrapper,
+                    knn_interpolation, mesh_grid, project_feat_with_nn_corr)
+
+
+class Config(dict):
+    """Attribute-style nested dict (the reference uses omegaconf.DictConfig: cfgs.pwc2d.max_displacement ...)."""
+
+    def __init__(self, d=None):
+        super().__init__()
+        for k, v in (d or {}).items():
+            self[k] = Config(v) if isinstance(v, dict) else v
+
+    __getattr__ = dict.__getitem__
+
+
+def things_config():
+    """The ``model`` section of conf/test/things.yaml:13-45."""
+    return Config({
+        "name": "RPEFlow", "batch_size": 4, "freeze_bn": False,
+        "ids": {"enabled": True, "sensor_size_divisor": 32},
+        "attention": {"norm": "WithBias", "attention": "mdta", "layers": 2},
+        "pwc2d": {"event_bins": 10, "event_polarity": True, "max_displacement": 4,
+                  "norm": {"feature_pyramid": "batch_norm", "flow_estimator": None, "context_network": None}},
+        "pwc3d": {"k": 16, "norm": {"feature_pyramid": "batch_norm", "correlation": None, "flow_estimator": None}},
+    })
+
+
+# ------------------------------------------------------------------ Restormer cross blocks (restormer_arch.py)
+class _ChannelNorm(nn.Module):
+    """LayerNorm over the channel axis of [B,C,...] (restormer_arch.py:31-83); parameters under ``body``."""
+
+    class _Affine(nn.Module):
+        def __init__(self, dim, with_bias):
+            super().__init__()
+            self.weight = nn.Parameter(torch.ones(dim))
+            if with_bias:
+                self.bias = nn.Parameter(torch.zeros(dim))
+
+    def __init__(self, dim, kind):
+        super().__init__()
+        self.with_bias = kind != "BiasFree"
+        self.body = self._Affine(dim, self.with_bias)
+
+    def forward(self, x):
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        var = x.var(1, keepdim=True, unbiased=False)
+        if self.with_bias:
+            x = (x - x.mean(1, keepdim=True)) / torch.sqrt(var + 1e-5)
+            return x * self.body.weight.view(shape) + self.body.bias.view(shape)
+        return x / torch.sqrt(var + 1e-5) * self.body.weight.view(shape)
+
+
+class _MutualAttention(nn.Module):
+    """Mutual_Attention{2D,3D} (restormer_arch.py:169-204, 251-283): channel attention, q from x, k/v from y."""
+
+    def __init__(self, dim, num_heads, bias, dims):
+        super().__init__()
+        conv = nn.Conv2d if dims == 2 else nn.Conv1d
+        self.num_heads = num_heads
+        self.temperature = nn.Parameter(torch.ones(num_heads, 1, 1))
+        self.qkv_dwconv = conv(dim * 3, dim * 3, kernel_size=3, stride=1, padding=1, groups=dim * 3, bias=bias)
+        self.project_out = conv(dim, dim, kernel_size=1, bias=bias)
+
+    def forward(self, x, y):
+        shape = x.shape
+        q, k, v = self.qkv_dwconv(torch.cat((x, y, y), dim=1)).chunk(3, dim=1)
+        heads = lambda t: t.reshape(shape[0], self.num_heads, shape[1] // self.num_heads, -1)
+        q, k, v = F.normalize(heads(q), dim=-1), F.normalize(heads(k), dim=-1), heads(v)
+        attn = ((q @ k.transpose(-2, -1)) * self.temperature).softmax(dim=-1)
+        return self.project_out((attn @ v).reshape(shape))
+
+
+class _GatedFeedForward(nn.Module):
+    """FeedForward{2D,3D} (restormer_arch.py:88-110, 225-248)."""
+
+    def __init__(self, dim, expansion, bias, dims):
+        super().__init__()
+        conv = nn.Conv2d if dims == 2 else nn.Conv1d
+        hidden = int(dim * expansion)
+        self.project_in = conv(dim, hidden * 2, kernel_size=1, bias=bias)
+        self.dwconv = conv(hidden * 2, hidden * 2, kernel_size=3, stride=1, padding=1, groups=hidden * 2, bias=bias)
+        self.project_out = conv(hidden, dim, kernel_size=1, bias=bias)
+
+    def forward(self, x):
+        a, b = self.dwconv(self.project_in(x)).chunk(2, dim=1)
+        return self.project_out(F.gelu(a) * b)
+
+
+class _CrossTransformerBlock(nn.Module):
+    dims = 2
+
+    def __init__(self, dim, num_heads, ffn_expansion_factor=2.66, bias=False, LayerNorm_type="WithBias"):
+        super().__init__()
+        self.norm1x = _ChannelNorm(dim, LayerNorm_type)
+        self.norm1y = _ChannelNorm(dim, LayerNorm_type)
+        self.attn = _MutualAttention(dim, num_heads, bias, self.dims)
+        self.norm2 = _ChannelNorm(dim, LayerNorm_type)
+        self.ffn = _GatedFeedForward(dim, ffn_expansion_factor, bias, self.dims)
+
+    def forward(self, x, y):
+        assert x.shape == y.shape
+        x = x + self.attn(self.norm1x(x), self.norm1y(y))
+        return x + self.ffn(self.norm2(x))
+
+
+class CrossTransformerBlock2D(_CrossTransformerBlock):
+    """restormer_arch.py:207-222."""
+    dims = 2
+
+
+class CrossTransformerBlock3D(_CrossTransformerBlock):
+    """restormer_arch.py:287-302."""
+    dims = 1
+
+
+# ------------------------------------------------------------------ MI heads: parameters only (mutual_info.py)
+class _MIHeads(nn.Module):
+    def __init__(self, input_channels, hidden_channels, dims, event):
+        super().__init__()
+        block = Conv2dNormRelu if dims == 2 else Conv1dNormRelu
+        for name in ["rgb", "point"] + (["event"] if event else []):
+            setattr(self, name + "_mu", block(input_channels, hidden_channels, activation=None))
+            setattr(self, name + "_logvar", block(input_channels, hidden_channels, activation=None))
+
+
+def Mutual_info_reg_2D(c, h):
+    return _MIHeads(c, h, 2, False)
+
+
+def Mutual_info_reg_3D(c, h):
+    return _MIHeads(c, h, 1, False)
+
+
+def Mutual_info_reg_2D_Event(c, h):
+    return _MIHeads(c, h, 2, True)
+
+
+def Mutual_info_reg_3D_Event(c, h):
+    return _MIHeads(c, h, 1, True)
+
+
+# ------------------------------------------------------------------ 2-D blocks (pwc2d_core.py): plain convolutions
+class ResidualBlock(nn.Module):
+    """pwc2d_core.py:6-25 (down_sample=True is the only form the pyramid uses)."""
+
+    def __init__(self, in_channels, out_channels, norm=None):
+        super().__init__()
+        self.down0 = Conv2dNormRelu(in_channels, out_channels, stride=2, norm=norm, activation=None)
+        self.conv0 = Conv2dNormRelu(in_channels, out_channels, kernel_size=3, stride=2, padding=1, norm=norm)
+        self.conv1 = Conv2dNormRelu(out_channels, out_channels, kernel_size=3, stride=1, padding=1, norm=norm, activation=None)
+        self.relu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
+
+    def forward(self, x):
+        return self.relu(self.conv1(self.conv0(x)) + self.down0(x))
+
+
+class FeaturePyramid2D(nn.Module):
+    """pwc2d_core.py:28-40."""
+
+    def __init__(self, n_channels, norm=None):
+        super().__init__()
+        self.pyramid_convs = nn.ModuleList(ResidualBlock(a, b, norm=norm) for a, b in zip(n_channels[:-1], n_channels[1:]))
+
+    def forward(self, x):
+        outputs = []
+        for conv in self.pyramid_convs:
+            x = conv(x)
+            outputs.append(x)
+        return outputs
+
+
+class FlowEstimator2D(nn.Module):
+    """pwc2d_core.py:92-135."""
+
+    def __init__(self, n_channels, norm=None, conv_last=True):
+        super().__init__()
+        for i in range(1, 6):
+            setattr(self, "conv%d" % i, Conv2dNormRelu(n_channels[i - 1], n_channels[i], kernel_size=3, padding=1, norm=norm))
+        self.flow_feat_dim = n_channels[4] + n_channels[5]
+        self.conv_last = nn.Conv2d(self.flow_feat_dim, 2, kernel_size=3, stride=1, padding=1) if conv_last else None
+
+    def forward(self, x):
+        x4 = self.conv4(self.conv3(self.conv2(self.conv1(x))))
+        flow_feat = torch.cat([self.conv5(x4), x4], dim=1)
+        return (flow_feat, self.conv_last(flow_feat)) if self.conv_last is not None else flow_feat
+
+
+class ContextNetwork2D(nn.Module):
+    """pwc2d_core.py:137-151."""
+
+    def __init__(self, n_channels, dilations, norm=None):
+        super().__init__()
+        self.convs = nn.ModuleList(
+            Conv2dNormRelu(a, b, kernel_size=3, padding=d, dilation=d, norm=norm)
+            for a, b, d in zip(n_channels[:-1], n_channels[1:], dilations))
+        self.conv_last = nn.Conv2d(n_channels[-1], 2, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x):
+        for conv in self.convs:
+            x = conv(x)
+        return x, self.conv_last(x)
+
+
+# ------------------------------------------------------------------ Bi-CLFM fusers (RPEFlow_core.py:14-162)
+class PyramidFeatureFuser2D(nn.Module):
+    def __init__(self, in_channels_2d, in_channels_3d, num_heads, norm=None):
+        super().__init__()
+        self.mlps = nn.Sequential(Conv2dNormRelu(in_channels_3d + 3, in_channels_2d, norm=norm))
+        self.mi = Mutual_info_reg_2D(in_channels_2d, in_channels_2d // 2)
+        self.fuse = CrossTransformerBlock2D(dim=in_channels_2d, num_heads=num_heads)
+
+    def forward(self, xy, feat_2d, feat_3d, nn_proj):
+        return self.fuse(feat_2d, self.mlps(project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])))
+
+
+class PyramidFeatureFuser3D(nn.Module):
+    def __init__(self, in_channels_2d, in_channels_3d, num_heads, norm=None):
+        super().__init__()
+        self.mlps = nn.Sequential(Conv1dNormRelu(in_channels_2d, in_channels_3d, norm=norm))
+        self.mi = Mutual_info_reg_3D(in_channels_3d, in_channels_3d // 2)
+        self.fuse = CrossTransformerBlock3D(dim=in_channels_3d, num_heads=num_heads)
+
+    def forward(self, xy, feat_2d, feat_3d):
+        return self.fuse(feat_3d, self.mlps(grid_sample_wrapper(feat_2d, xy)))
+
+
+class CorrFeatureFuser2D(nn.Module):
+    def __init__(self, in_channels_2d, in_channels_3d, num_heads):
+        super().__init__()
+        self.mlps = nn.Sequential(
+            Conv2dNormRelu(in_channels_3d * 2 + 5, in_channels_3d + in_channels_2d),
+            Conv2dNormRelu(in_channels_3d + in_channels_2d, in_channels_2d))
+        self.head_3d = Conv2dNormRelu(in_channels_3d + 5, in_channels_2d)
+        self.head_event = Conv2dNormRelu(in_channels_3d, in_channels_2d)
+        self.mi = Mutual_info_reg_2D_Event(in_channels_2d, in_channels_2d // 2)
+        self.fuse = CrossTransformerBlock2D(dim=in_channels_2d, num_heads=num_heads)
+
+    def forward(self, xy, feat_2d, feat_3d, efeat_2d, last_flow_2d, last_flow_3d_to_2d, nn_proj):
+        feat_3d = torch.cat([feat_3d, last_flow_3d_to_2d], dim=1)
+        feat_3d_to_2d = project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])
+        feat_3d_to_2d[:, -2:] -= last_flow_2d  # RPEFlow_core.py:82
+        return self.fuse(feat_2d, self.mlps(torch.cat([feat_3d_to_2d, efeat_2d], dim=1)))
+
+
+class CorrFeatureFuser3D(nn.Module):
+    def __init__(self, in_channels_2d, in_channels_3d, num_heads):
+        super().__init__()
+        self.mlps = nn.Sequential(
+            Conv1dNormRelu(in_channels_2d + in_channels_3d + 2, in_channels_2d + in_channels_3d),
+            Conv1dNormRelu(in_channels_2d + in_channels_3d, in_channels_3d))
+        self.head_2d = Conv1dNormRelu(in_channels_2d + 2, in_channels_3d)
+        self.mi = Mutual_info_reg_3D_Event(in_channels_3d, in_channels_3d // 2)
+        self.fuse = CrossTransformerBlock3D(dim=in_channels_3d, num_heads=num_heads)
+
+    def forward(self, xy, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d, last_flow_2d_to_3d):
+        feat_2d_to_3d = grid_sample_wrapper(torch.cat([feat_corr_2d, last_flow_2d_to_3d], dim=1), xy)
+        efeat_2d_to_3d = grid_sample_wrapper(efeat_2d, xy)
+        feat_2d_to_3d[:, -2:] -= last_flow_3d[:, :2]  # RPEFlow_core.py:110
+        return self.fuse(feat_corr_3d, self.mlps(torch.cat([feat_2d_to_3d, efeat_2d_to_3d], dim=1)))
+
+
+class DecoderFeatureFuser2D(nn.Module):
+    def __init__(self, in_channels_2d, in_channels_3d, num_heads):
+        super().__init__()
+        self.mlps = nn.Sequential(Conv2dNormRelu(in_channels_3d + 3, in_channels_2d))
+        self.mi = Mutual_info_reg_2D(in_channels_2d, in_channels_2d // 2)
+        self.fuse = CrossTransformerBlock2D(dim=in_channels_2d, num_heads=num_heads)
+
+    def forward(self, xy, feat_2d, feat_3d, nn_proj):
+        return self.fuse(feat_2d, self.mlps(project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])))
+
+
+class DecoderFeatureFuser3D(nn.Module):
+    def __init__(self, in_channels_2d, in_channels_3d, num_heads):
+        super().__init__()
+        self.mlps = nn.Sequential(Conv1dNormRelu(in_channels_2d, in_channels_3d))
+        self.mi = Mutual_info_reg_3D(in_channels_3d, in_channels_3d // 2)
+        self.fuse = CrossTransformerBlock3D(dim=in_channels_3d, num_heads=num_heads)
+
+    def forward(self, xy, feat_2d, feat_3d):
+        return self.fuse(feat_3d, self.mlps(grid_sample_wrapper(feat_2d, xy)))
+
+
+# ------------------------------------------------------------------ small geometry helpers (models/utils.py)
+def project_pc2image(pc, camera_info):
+    """utils.py:260-285."""
+    if camera_info["projection_mode"] == "parallel":
+        return torch.stack([pc[:, 0] + camera_info["cx"], pc[:, 1] + camera_info["cy"]], dim=1)
+    f, cx, cy = (camera_info[k][:, None] for k in ("f", "cx", "cy"))
+    return torch.stack([cx + (f / pc[:, 2]) * pc[:, 0], cy + (f / pc[:, 2]) * pc[:, 1]], dim=1)
+
+
+def perspect2parallel(xyz, persp, paral):
+    """IDS forward, utils.py:320-346."""
+    f, cx, cy = (persp[k][:, None] for k in ("f", "cx", "cy"))
+    x, y, z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    sw = (paral["sensor_w"] - 1) / (persp["sensor_w"] - 1)
+    sh = (paral["sensor_h"] - 1) / (persp["sensor_h"] - 1)
+    return torch.stack([
+        (cx + (f / z) * x) * sw - (paral["sensor_w"] - 1) / 2,
+        (cy + (f / z) * y) * sh - (paral["sensor_h"] - 1) / 2,
+        (f * torch.log(z) + 1) * min(sw, sh)], dim=1)
+
+
+def parallel2perspect(xyz, persp, paral):
+    """IDS inverse, utils.py:349-377."""
+    f, cx, cy = (persp[k][:, None] for k in ("f", "cx", "cy"))
+    sw = (paral["sensor_w"] - 1) / (persp["sensor_w"] - 1)
+    sh = (paral["sensor_h"] - 1) / (persp["sensor_h"] - 1)
+    x = (xyz[:, 0] + (paral["sensor_w"] - 1) / 2) / sw
+    y = (xyz[:, 1] + (paral["sensor_h"] - 1) / 2) / sh
+    z = torch.exp((xyz[:, 2] / min(sw, sh) - 1) / f)
+    return torch.stack([(x - cx) * z / f, (y - cy) * z / f, z], dim=1)
+
+
+def resize_to_64x(x):
+    """utils.py:227-241 (inputs only)."""
+    h, w = x.shape[2:]
+    if h % 64 == 0 and w % 64 == 0:
+        return x
+    return F.interpolate(x, size=((h + 63) // 64 * 64, (w + 63) // 64 * 64), mode="bilinear", align_corners=True)
+
+
+def resize_flow2d(flow, target_h, target_w):
+    """utils.py:217-224."""
+    h, w = flow.shape[2:]
+    if (h, w) == (target_h, target_w):
+        return flow
+    flow = F.interpolate(flow, size=(target_h, target_w), mode="bilinear", align_corners=True)
+    flow[:, 0] *= target_w / w
+    flow[:, 1] *= target_h / h
+    return flow
+
+
+def convex_upsample(flow, mask, scale_factor=8):
+    """utils.py:201-214 (RAFT convex upsampling)."""
+    b, _, h, w = flow.shape
+    mask = torch.softmax(mask.view(b, 1, 9, scale_factor, scale_factor, h, w), dim=2)
+    up = F.unfold(flow * scale_factor, [3, 3], padding=1).view(b, 2, 9, 1, 1, h, w)
+    up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3)
+    return up.reshape(b, 2, h * scale_factor, w * scale_factor)
+
+
+# ------------------------------------------------------------------ the core (RPEFlow_core.py:165-432)
+class RPEFlow_core(nn.Module):
+    def __init__(self, cfgs2d, cfgs3d, cfgsattention=None):
+        super().__init__()
+        self.cfgs2d, self.cfgs3d = cfgs2d, cfgs3d
+        corr_ch = (2 * cfgs2d.max_displacement + 1) ** 2
+        event_bins = cfgs2d.event_bins * 2 if cfgs2d.event_polarity else cfgs2d.event_bins
+        widths = [32, 64, 96, 128, 192]
+
+        def aligners(block):
+            return nn.ModuleList([nn.Identity()] + [block(32, 64), block(64, 64), block(96, 64), block(128, 64), block(192, 64)])
+
+        self.feature_pyramid_2d = FeaturePyramid2D([3, 16, 32, 64, 96, 128, 192], norm=cfgs2d.norm.feature_pyramid)
+        self.feature_aligners_2d = aligners(Conv2dNormRelu)
+        self.efeature_pyramid_2d = FeaturePyramid2D([event_bins, 32, 32, 64, 96, 128, 192], norm=cfgs2d.norm.feature_pyramid)
+        self.efeature_aligners_2d = aligners(Conv2dNormRelu)
+        self.flow_estimator_2d = FlowEstimator2D([64 + 64 + corr_ch + 2 + 32, 192, 128, 96, 64, 32],
+                                                 norm=cfgs2d.norm.flow_estimator, conv_last=False)
+        self.context_network_2d = ContextNetwork2D([self.flow_estimator_2d.flow_feat_dim + 2, 128, 128, 128, 96, 64, 32],
+                                                   dilations=[1, 2, 4, 8, 16, 1], norm=cfgs2d.norm.context_network)
+        self.up_mask_head_2d = nn.Sequential(nn.Conv2d(32, 256, kernel_size=3, stride=1, padding=1), nn.ReLU(inplace=True),
+                                             nn.Conv2d(256, 4 * 4 * 9, kernel_size=1, stride=1, padding=0))
+
+        self.feature_pyramid_3d = FeaturePyramid3D([16, 32, 64, 96, 128, 192], norm=cfgs3d.norm.feature_pyramid, k=cfgs3d.k)
+        self.feature_aligners_3d = aligners(Conv1dNormRelu)
+        self.correlations_3d = nn.ModuleList([nn.Identity()] + [Correlation3D(c, c, k=cfgs3d.k) for c in widths])
+        self.correlation_aligners_3d = aligners(Conv1dNormRelu)
+        self.flow_estimator_3d = FlowEstimator3D([64 + 64 + 3 + 64, 128, 128, 64], cfgs3d.norm.flow_estimator,
+                                                 conv_last=False, k=cfgs3d.k)
+
+        heads_p = [1, 2, 2, 4, 4]
+        self.pyramid_feat_fusers_2d = nn.ModuleList([nn.Identity()] + [
+            PyramidFeatureFuser2D(c, c, num_heads=h, norm=cfgs2d.norm.feature_pyramid) for c, h in zip(widths, heads_p)])
+        self.pyramid_feat_fusers_3d = nn.ModuleList([nn.Identity()] + [
+            PyramidFeatureFuser3D(c, c, num_heads=h, norm=cfgs3d.norm.feature_pyramid) for c, h in zip(widths, heads_p)])
+        self.corr_feat_fusers_2d = nn.ModuleList([nn.Identity()] + [
+            CorrFeatureFuser2D(corr_ch, c, num_heads=h) for c, h in zip(widths, [1, 1, 3, 3, 3])])
+        self.corr_feat_fusers_3d = nn.ModuleList([nn.Identity()] + [
+            CorrFeatureFuser3D(corr_ch, c, num_heads=h) for c, h in zip(widths, heads_p)])
+        self.estimator_feat_fuser_2d = DecoderFeatureFuser2D(self.flow_estimator_2d.flow_feat_dim, 64, num_heads=2)
+        self.estimator_feat_fuser_3d = DecoderFeatureFuser3D(self.flow_estimator_2d.flow_feat_dim, 64, num_heads=2)
+
+        self.conv_last_2d = nn.Conv2d(self.flow_estimator_2d.flow_feat_dim, 2, kernel_size=3, stride=1, padding=1)
+        self.conv_last_3d = nn.Conv1d(64, 3, kernel_size=1)
+
+    def encode(self, image, xyzs):
+        return self.feature_pyramid_2d(image), self.feature_pyramid_3d(xyzs)
+
+    def encode_event(self, event_voxel):
+        return self.efeature_pyramid_2d(event_voxel)
+
+    def decode(self, xyzs1, xyzs2, feats1_2d, feats2_2d, feats1_3d, feats2_3d, efeats_2d, camera_info):
+        """RPEFlow_core.py:302-432 without the MI loss bookkeeping."""
+        flows_2d, flows_3d, flow_feats_2d, flow_feats_3d = [], [], [], []
+        sensor_h, sensor_w = camera_info["sensor_h"], camera_info["sensor_w"]
+        md, k = self.cfgs2d.max_displacement, self.cfgs3d.k
+        top = len(xyzs1) - 1
+        for level in range(top, 0, -1):
+            xyz1, feat1_2d, feat1_3d = xyzs1[level], feats1_2d[level], feats1_3d[level]
+            xyz2, feat2_2d, feat2_3d = xyzs2[level], feats2_2d[level], feats2_3d[level]
+            efeat_2d = efeats_2d[level]
+            batch_size, image_h, image_w = feat1_2d.shape[0], feat1_2d.shape[2], feat1_2d.shape[3]
+            n_points = xyz1.shape[-1]
+            sx, sy = (image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1)
+
+            xy1, xy2 = project_pc2image(xyz1, camera_info), project_pc2image(xyz2, camera_info)
+            xy1[:, 0] *= sx; xy1[:, 1] *= sy
+            xy2[:, 0] *= sx; xy2[:, 1] *= sy
+
+            grid = mesh_grid(batch_size, image_h, image_w, xy1.device).reshape(batch_size, 2, -1)
+            nn_proj1 = k_nearest_neighbor(xy1, grid, k=1)
+            nn_proj2 = k_nearest_neighbor(xy2, grid, k=1)
+            knn_1in1 = k_nearest_neighbor(xyz1, xyz1, k=k)
+
+            fuse2d, fuse3d = self.pyramid_feat_fusers_2d[level], self.pyramid_feat_fusers_3d[level]
+            feat1_2d, feat1_3d = fuse2d(xy1, feat1_2d, feat1_3d, nn_proj1), fuse3d(xy1, feat1_2d, feat1_3d)
+            feat2_2d, feat2_3d = fuse2d(xy2, feat2_2d, feat2_3d, nn_proj2), fuse3d(xy2, feat2_2d, feat2_3d)
+
+            if level == top:
+                zeros = lambda *s: torch.zeros(s, dtype=xy1.dtype, device=xy1.device)
+                last_flow_2d, last_flow_3d = zeros(batch_size, 2, image_h, image_w), zeros(batch_size, 3, n_points)
+                last_flow_feat_2d, last_flow_feat_3d = zeros(batch_size, 32, image_h, image_w), zeros(batch_size, 64, n_points)
+                xyz2_warp, feat2_2d_warp = xyz2, feat2_2d
+            else:
+                last_flow_2d = F.interpolate(flows_2d[-1] * 2, scale_factor=2, mode="bilinear", align_corners=True)
+                last_flow_feat_2d = F.interpolate(flow_feats_2d[-1], scale_factor=2, mode="bilinear", align_corners=True)
+                feat2_2d_warp = backwarp_2d(feat2_2d, last_flow_2d, padding_mode="border")
+                up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], dim=1), xyz1)
+                last_flow_3d, last_flow_feat_3d = up[:, :3, :], up[:, 3:, :]
+                xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
+
+            feat_corr_3d = self.correlations_3d[level](xyz1, feat1_3d, xyz2_warp, feat2_3d, knn_1in1)
+            feat_corr_2d = F.leaky_relu(correlation2d(feat1_2d, feat2_2d_warp, md), 0.1)
+
+            last_flow_3d_to_2d = torch.cat([last_flow_3d[:, 0:1] * sx, last_flow_3d[:, 1:2] * sy], dim=1)
+            last_flow_2d_to_3d = torch.cat([last_flow_2d[:, 0:1] * ((sensor_w - 1) / (image_w - 1)),
+                                            last_flow_2d[:, 1:2] * ((sensor_h - 1) / (image_h - 1))], dim=1)
+            corr_2d_fused = self.corr_feat_fusers_2d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_2d,
+                                                            last_flow_3d_to_2d, nn_proj1)
+            corr_3d_fused = self.corr_feat_fusers_3d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d,
+                                                            last_flow_2d_to_3d)
+
+            x_2d = torch.cat([corr_2d_fused, self.feature_aligners_2d[level](feat1_2d), self.efeature_aligners_2d[level](efeat_2d),
+                              last_flow_2d, last_flow_feat_2d], dim=1)
+            x_3d = torch.cat([self.correlation_aligners_3d[level](corr_3d_fused), self.feature_aligners_3d[level](feat1_3d),
+                              last_flow_3d, last_flow_feat_3d], dim=1)
+            flow_feat_2d = self.flow_estimator_2d(x_2d)
+            flow_feat_3d = self.flow_estimator_3d(xyz1, x_3d, knn_1in1)
+
+            flow_feat_2d, flow_feat_3d = (self.estimator_feat_fuser_2d(xy1, flow_feat_2d, flow_feat_3d, nn_proj1),
+                                          self.estimator_feat_fuser_3d(xy1, flow_feat_2d, flow_feat_3d))
+
+            flow_2d = last_flow_2d + self.conv_last_2d(flow_feat_2d)
+            flow_3d = last_flow_3d + self.conv_last_3d(flow_feat_3d)
+            flow_feat_2d, flow_delta_2d = self.context_network_2d(torch.cat([flow_feat_2d, flow_2d], dim=1))
+            flow_2d = flow_delta_2d + flow_2d
+
+            flows_2d.append(flow_2d); flows_3d.append(flow_3d)
+            flow_feats_2d.append(flow_feat_2d); flow_feats_3d.append(flow_feat_3d)
+
+        flows_2d = [f.float() for f in flows_2d][::-1]
+        flows_3d = [f.float() for f in flows_3d][::-1]
+        flows_2d[0] = convex_upsample(flows_2d[0], self.up_mask_head_2d(flow_feats_2d[-1]), scale_factor=4)
+        for i in range(1, len(flows_2d)):
+            flows_2d[i] = F.interpolate(flows_2d[i] * 4, scale_factor=4, mode="bilinear", align_corners=True)
+        for i in range(len(flows_3d)):
+            flows_3d[i] = knn_interpolation(xyzs1[i + 1], flows_3d[i], xyzs1[i])
+        return flows_2d, flows_3d
+
+
+class RPEFlow(nn.Module):
+    """models/RPEFlow.py:9-99, inference branch: forward(inputs) -> {'flow_2d', 'flow_3d'}.
+
+    ``ids_on_host``: compute the IDS transform (log/div of 2*B*3*N floats) on the CPU, as the
+    reference's CPU path does, so that FPS/KNN see bit-identical coordinates."""
+
+    def __init__(self, cfgs=None, ids_on_host=False):
+        super().__init__()
+        self.cfgs = cfgs or things_config()
+        self.ids_on_host = ids_on_host
+        self.pwc_fusion_core = RPEFlow_core(self.cfgs.pwc2d, self.cfgs.pwc3d, self.cfgs.get("attention"))
+
+    @torch.no_grad()
+    def forward(self, inputs, is_Train=False):
+        images = inputs["images"].float() / 255.0
+        pc1, pc2 = inputs["pcs"][:, :3], inputs["pcs"][:, 3:]
+        intrinsics = inputs["intrinsics"]
+        origin_h, origin_w = images.shape[2:]
+        images = resize_to_64x(images)
+        event_voxel = resize_to_64x(inputs["event_voxel"])
+        image1, image2 = images[:, :3], images[:, 3:]
+
+        persp = {"projection_mode": "perspective", "sensor_h": origin_h, "sensor_w": origin_w,
+                 "f": intrinsics[:, 0], "cx": intrinsics[:, 1], "cy": intrinsics[:, 2]}
+        paral = None
+        if self.cfgs.ids.enabled:
+            div = self.cfgs.ids.sensor_size_divisor
+            ph, pw = images.shape[2] // div, images.shape[3] // div
+            paral = {"projection_mode": "parallel", "sensor_h": ph, "sensor_w": pw, "cx": (pw - 1) / 2, "cy": (ph - 1) / 2}
+            if self.ids_on_host:
+                host = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in persp.items()}
+                pc1 = perspect2parallel(pc1.cpu(), host, paral).to(images.device)
+                pc2 = perspect2parallel(pc2.cpu(), host, paral).to(images.device)
+            else:
+                pc1, pc2 = perspect2parallel(pc1, persp, paral), perspect2parallel(pc2, persp, paral)
+
+        core = self.pwc_fusion_core
+        xyzs1, xyzs2, _, _ = build_pc_pyramid(pc1, pc2, [4096, 2048, 1024, 512, 256])
+        feats1_2d, feats1_3d = core.encode(image1, xyzs1)
+        feats2_2d, feats2_3d = core.encode(image2, xyzs2)
+        efeats_2d = core.encode_event(event_voxel)
+        flows_2d, flows_3d = core.decode(xyzs1, xyzs2, feats1_2d, feats2_2d, feats1_3d, feats2_3d, efeats_2d,
+                                         paral if self.cfgs.ids.enabled else persp)
+        flow_3d = flows_3d[0]
+        if self.cfgs.ids.enabled:
+            xyz1 = xyzs1[0]
+            flow_3d = parallel2perspect(xyz1 + flow_3d, persp, paral) - parallel2perspect(xyz1, persp, paral)
+        return {"flow_2d": resize_flow2d(flows_2d[0], origin_h, origin_w), "flow_3d": flow_3d}

@@ -116,8 +116,52 @@ def gen_blocks():
     save("correlation3d", out=m(T(x["xyz1"]), T(x["feat1"]), T(x["xyz2"]), T(x["feat2"])).numpy())
 
 
+def reference_model():
+    """The reference RPEFlow on CPU: things.yaml model section, MI noise drawn on the CPU (the reference
+    hard-codes torch.cuda.FloatTensor in mutual_info.py:32,84,155,211; its output never reaches the flows)."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models import mutual_info as mi
+        from models.RPEFlow import RPEFlow
+    for cls in (mi.Mutual_info_reg_2D, mi.Mutual_info_reg_2D_Event, mi.Mutual_info_reg_3D, mi.Mutual_info_reg_3D_Event):
+        cls.reparametrize = lambda self, mu, logvar: torch.randn_like(mu) * logvar.mul(0.5).exp() + mu
+    from rpeflow_amd.model import things_config
+    return RPEFlow(things_config())
+
+
+MODEL_SEED = 4242
+
+
+def model_params(module):
+    shapes = [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+    params = I.fill_params(shapes, MODEL_SEED)
+    # keep the random-init flows small: exp() in the IDS inverse overflows on O(1) z-flow (SURVEY.md H7)
+    for k in params:
+        if k.startswith("pwc_fusion_core.conv_last_"):
+            params[k] = (params[k] * 0.05).astype(np.float32)
+    return params
+
+
+@torch.no_grad()
+def gen_model():
+    import json
+    m = reference_model()
+    keys = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f)
+    print("state_dict_keys.json:", len(keys), "entries")
+    m.load_state_dict({k: T(v) for k, v in model_params(m).items()}, strict=True)
+    m.eval()
+    sample = I.frame_pair(1000, H=128, W=192, N=8192)
+    batch = {k: T(v)[None] for k, v in sample.items()}
+    out = m(batch, is_Train=False)
+    f2, f3 = out["flow_2d"].numpy(), out["flow_3d"].numpy()
+    assert np.isfinite(f2).all() and np.isfinite(f3).all()
+    print("flow_2d |max|", np.abs(f2).max(), "flow_3d |max|", np.abs(f3).max())
+    save("model_128x192", flow_2d=f2, flow_3d=f3)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks"]
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model"]
     for w in which:
         globals()["gen_" + w]()

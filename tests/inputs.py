@@ -46,20 +46,22 @@ def flow_field(r, B, H, W, std=3.0):
 
 
 def fill_params(shapes, seed):
-    """Deterministic parameters for a module, in state-dict order.
-    ``shapes``: list of (key, shape).  Weights ~ N(0, 1/fan_in), biases ~ N(0, 0.1),
-    running_var in [0.5, 1.5), integer buffers (num_batches_tracked) zero."""
-    r = rng(seed)
+    """Deterministic parameters for a module.  ``shapes``: list of (key, shape).  Every key draws from
+    its own stream, default_rng(seed + crc32(key)), so the values do not depend on the order in which
+    a module registers its parameters.  Weights ~ N(0, 1/fan_in), biases ~ N(0, 0.1), running_var and
+    norm scales in [0.5, 1.5), integer buffers (num_batches_tracked) zero."""
+    import zlib
     out = {}
     for key, shape in shapes:
         shape = tuple(shape)
+        r = rng(seed + zlib.crc32(key.encode()))
         if key.endswith("num_batches_tracked"):
             out[key] = np.zeros(shape, np.int64)
         elif key.endswith("running_var"):
             out[key] = r.uniform(0.5, 1.5, shape).astype(np.float32)
         elif key.endswith("running_mean") or key.endswith("bias"):
             out[key] = (r.standard_normal(shape) * 0.1).astype(np.float32)
-        elif key.endswith("norm_fn.weight"):
+        elif key.endswith("norm_fn.weight") or key.endswith("body.weight") or key.endswith("temperature"):
             out[key] = r.uniform(0.5, 1.5, shape).astype(np.float32)
         else:
             fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
@@ -67,24 +69,8 @@ def fill_params(shapes, seed):
     return out
 
 
-def frame_pair(seed, H=544, W=960, N=8192, f=1050.0):
-    """One synthetic evaluation sample, SURVEY.md section 8(d): uint8 RGB pair, 20-channel
-    event voxel, two back-projected clouds (pc2 = pc1 + N(0,0.05^2)), targets."""
-    r = rng(seed)
-    cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
-    images = r.integers(0, 256, (6, H, W), dtype=np.uint8)
-    event_voxel = r.standard_normal((20, H, W), dtype=np.float32)
-    z = r.uniform(2.0, 35.0, N)
-    u = r.uniform(0.0, W - 1.0, N)
-    v = r.uniform(0.0, H - 1.0, N)
-    pc1 = np.stack([(u - cx) * z / f, (v - cy) * z / f, z]).astype(np.float32)
-    pc2 = (pc1 + r.standard_normal((3, N)) * 0.05).astype(np.float32)
-    flow_2d = np.concatenate([r.standard_normal((2, H, W)) * 5.0, np.ones((1, H, W))]).astype(np.float32)
-    flow_3d = (pc2 - pc1).astype(np.float32)
-    occ = (r.random(N) < 0.2).astype(np.float32)
-    return {
-        "images": images, "event_voxel": event_voxel,
-        "pcs": np.concatenate([pc1, pc2]).astype(np.float32),
-        "flow_2d": flow_2d, "flow_3d": flow_3d, "occ_mask_3d": occ,
-        "intrinsics": np.array([f, cx, cy], np.float32),
-    }
+def frame_pair(seed, H=544, W=960, N=8192, f=1050.0, dsec=False):
+    """One synthetic evaluation sample; the generator lives in the package
+    because bench and the harness use it too."""
+    from rpeflow_amd.synthetic import frame_pair as gen
+    return gen(seed, H, W, N, f, dsec)

@@ -1,0 +1,123 @@
+"""Eval accumulators (eval_withocc.py:65-135, eval_noocc.py:57-116) and the sharded harness:
+CPU tests, including the 2-process gloo run of the one collective."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from rpeflow_amd import evaluate as E
+from rpeflow_amd.synthetic import SyntheticPairs, frame_pair
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def reference_style(outputs, inputs):
+    """The reference's per-sample loop, restated with numpy and Python floats (eval_withocc.py:65-108)."""
+    m2 = dict(c=0, e=0.0, a=0.0, f=0.0); m3 = dict(c=0, e=0.0, a=0.0, b=0.0); mn = dict(c=0, e=0.0, a=0.0, b=0.0)
+    for i in range(outputs["flow_2d"].shape[0]):
+        p2, p3 = outputs["flow_2d"][i].numpy(), outputs["flow_3d"][i].numpy()
+        t2, t3 = inputs["flow_2d"][i].numpy(), inputs["flow_3d"][i].numpy()
+        k2 = t2[2] > 0 if t2.shape[0] > 2 else np.ones(t2.shape[1:], bool)
+        k3 = t3[3] > 0 if t3.shape[0] > 3 else np.ones(t3.shape[1], bool)
+        t2, t3 = t2[:2], t3[:3]
+        e2 = np.sqrt(((p2 - t2) ** 2).sum(0)); e3 = np.sqrt(((p3 - t3) ** 2).sum(0))
+        k2 &= ~np.isnan(e2); k3 &= ~np.isnan(e3)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            fl = (e2 > 3.0) & (e2 / np.linalg.norm(t2, axis=0) > 0.05)
+        m2["c"] += int(k2.sum()); m2["e"] += float(e2[k2].sum()); m2["a"] += int((e2[k2] < 1.0).sum()); m2["f"] += float(fl[k2].sum())
+        m3["c"] += int(k3.sum()); m3["e"] += float(e3[k3].sum()); m3["a"] += int((e3[k3] < 0.05).sum()); m3["b"] += int((e3[k3] < 0.1).sum())
+        if "occ_mask_3d" in inputs:
+            kn = k3 & (inputs["occ_mask_3d"][i].numpy() == 0)
+            mn["c"] += int(kn.sum()); mn["e"] += float(e3[kn].sum()); mn["a"] += int((e3[kn] < 0.05).sum()); mn["b"] += int((e3[kn] < 0.1).sum())
+    return np.array([m2["c"], m2["e"], m2["a"], m2["f"], m3["c"], m3["e"], m3["a"], m3["b"], mn["c"], mn["e"], mn["a"], mn["b"]], np.float64)
+
+
+def fake_model(batch):
+    """Deterministic stand-in: the targets plus a sample-dependent error (and a few NaNs to exercise the mask)."""
+    f2 = batch["flow_2d"][:, :2].float() + 0.8 * torch.sin(batch["event_voxel"][:, :2].float() * 3.0)
+    f3 = batch["flow_3d"][:, :3].float() + 0.06 * torch.cos(batch["pcs"][:, :3].float() * 5.0)
+    f3[:, :, ::97] = float("nan")
+    return {"flow_2d": f2, "flow_3d": f3}
+
+
+@pytest.mark.parametrize("dsec", [False, True])
+def test_accumulators_match_reference_style_loop(dsec):
+    data = SyntheticPairs(3, H=24, W=40, N=512, dsec=dsec)
+    batch = E.collate([data[i] for i in range(3)])
+    out = fake_model(batch)
+    acc = E.accumulate(E.new_accumulator("cpu"), out, batch)
+    ref = reference_style(out, batch)
+    counts = [0, 2, 3, 4, 6, 7, 8, 10, 11]
+    assert np.array_equal(acc.numpy()[counts], ref[counts])  # counts and threshold hits: exact
+    np.testing.assert_allclose(acc.numpy()[[1, 5, 9]], ref[[1, 5, 9]], rtol=1e-6)  # fp32 maps, float64 sums
+    m = E.finalize(acc)
+    assert ("EPE3D_noc" in m) == (not dsec)
+    assert abs(m["EPE2D"] - ref[1] / ref[0]) < 1e-6
+
+
+def test_known_answer():
+    inputs = {"flow_2d": torch.tensor([[[[3.0, 0.0]], [[4.0, 0.0]], [[1.0, 0.0]]]]),  # [1,3,1,2]: second pixel masked out
+              "flow_3d": torch.zeros(1, 3, 4), "occ_mask_3d": torch.tensor([[0.0, 1.0, 0.0, 0.0]])}
+    outputs = {"flow_2d": torch.zeros(1, 2, 1, 2), "flow_3d": torch.tensor([[[0.03, 0.0, 0.2, 0.0], [0.0, 0.08, 0.0, 0.0], [0.0, 0.0, 0.0, float("nan")]]])}
+    a = E.accumulate(E.new_accumulator("cpu"), outputs, inputs).tolist()
+    assert a[:4] == [1.0, 5.0, 0.0, 1.0]                       # one valid pixel, EPE 5, not <1px, Fl hit
+    assert a[4] == 3.0 and abs(a[5] - 0.31) < 1e-6 and a[6:8] == [1.0, 2.0]   # NaN point dropped
+    assert a[8] == 2.0 and abs(a[9] - 0.23) < 1e-6 and a[10:12] == [1.0, 1.0]  # occluded point dropped too
+
+
+def test_shards_partition_the_dataset_without_padding():
+    for n in (0, 1, 5, 8, 13):
+        for w in (1, 2, 3, 8):
+            parts = [E.shard_indices(n, r, w) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+
+
+def test_single_process_evaluate():
+    data = SyntheticPairs(5, H=24, W=40, N=512)
+    metrics, acc = E.evaluate(fake_model, data, batch_size=2, device="cpu")
+    whole = E.collate([data[i] for i in range(5)])
+    ref = reference_style(fake_model(whole), whole)
+    np.testing.assert_allclose(acc.numpy(), ref, rtol=1e-6)
+    assert metrics["counts"]["2d"] == 5 * 24 * 40
+
+
+WORKER = r'''
+import os, sys, json, torch
+sys.path.insert(0, os.environ["RPE_ROOT"])
+import torch.distributed as dist
+from rpeflow_amd import evaluate as E
+from rpeflow_amd.synthetic import SyntheticPairs
+from tests.test_evaluate import fake_model
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+data = SyntheticPairs(5, H=24, W=40, N=512)            # 5 samples over 2 ranks: shards of 3 and 2
+metrics, acc = E.evaluate(fake_model, data, batch_size=2, device="cpu", rank=rank, world_size=world)
+print("RESULT", rank, json.dumps(acc.tolist()))
+dist.destroy_process_group()
+'''
+
+
+def test_two_process_gloo_all_reduce_equals_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RPE_ROOT=ROOT,
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-500:] for o in outs]
+    import json
+    accs = [json.loads(next(l for l in o[0].splitlines() if l.startswith("RESULT")).split(" ", 2)[2]) for o in outs]
+    assert accs[0] == accs[1]  # every rank holds the global sums
+    data = SyntheticPairs(5, H=24, W=40, N=512)
+    _, single = E.evaluate(fake_model, data, batch_size=2, device="cpu")
+    np.testing.assert_allclose(np.array(accs[0]), single.numpy(), rtol=1e-12)
+    assert accs[0][0] == single[0].item() and accs[0][4] == single[4].item()
