@@ -128,17 +128,8 @@ def reference_model():
     return RPEFlow(things_config())
 
 
-MODEL_SEED = 4242
-
-
 def model_params(module):
-    shapes = [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
-    params = I.fill_params(shapes, MODEL_SEED)
-    # keep the random-init flows small: exp() in the IDS inverse overflows on O(1) z-flow
-    for k in params:
-        if k.startswith("pwc_fusion_core.conv_last_"):
-            params[k] = (params[k] * 0.05).astype(np.float32)
-    return params
+    return I.model_params([(k, tuple(v.shape)) for k, v in module.state_dict().items()])
 
 
 @torch.no_grad()

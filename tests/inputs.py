@@ -69,6 +69,23 @@ def fill_params(shapes, seed):
     return out
 
 
+MODEL_SEED = 4242
+# Down-scaling of a few weight groups so that a random-init RPEFlow stays well conditioned: with plain
+# N(0, 1/fan_in) weights the k-sums of PointConv / Correlation3D amplify ~10x per pyramid level and the
+# 3-D decoder features reach 1e8, where fp32 rounding alone moves the 2-D flow by 1e-2.
+MODEL_SCALES = [("conv_last_", 0.05), ("linear.", 0.25), ("weight_net1.convs.2", 0.15), ("weight_net2.convs.2", 0.15)]
+
+
+def model_params(shapes):
+    """Seeded parameters for the full model (reference and counterpart alike), keyed by state-dict name."""
+    params = fill_params(shapes, MODEL_SEED)
+    for k in params:
+        for pattern, scale in MODEL_SCALES:
+            if pattern in k and k.endswith("weight") and params[k].ndim > 1:
+                params[k] = (params[k] * np.float32(scale)).astype(np.float32)
+    return params
+
+
 def frame_pair(seed, H=544, W=960, N=8192, f=1050.0, dsec=False):
     """One synthetic evaluation sample; the generator lives in the package
     because bench and the harness use it too."""
