@@ -1,15 +1,18 @@
 #!/usr/bin/env python3
-"""bench.py -- frame-pairs/s of RPEFlow's hot path on N MI355X (one process per GPU).
+"""bench.py -- frame-pairs/s of RPEFlow inference on N MI355X (one process per GPU).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot-path operator sequence of one forward
-(rpeflow_amd/hotpath.py) over a batch of B synthetic 544x960 frame pairs with
-8192-point clouds, inputs resident in HBM.  Frame pairs are independent, so ranks
-shard them with no data-path collective (weak scaling: B per GPU); the only
-collective is the MAX over ranks of the timed region.  Rank 0 prints ONE JSON line.
+Default workload ("forward", BASELINE config 3): a step = one full RPEFlow forward
+(rpeflow_amd/model.py: every hot-path call on the HIP kernels, dense convs/attention on
+PyTorch-ROCm) over a batch of B synthetic 544x960 frame pairs (RGB pair + 20-channel event
+voxel + two 8192-point clouds), random-init weights, inputs resident in HBM.
+--workload hotpath times the hot-path operator sequence alone (rpeflow_amd/hotpath.py).
+Frame pairs are independent, so ranks shard them with no data-path collective (weak
+scaling: B per GPU); the only collective is the MAX over ranks of the timed region.
+Rank 0 prints ONE JSON line.
 
 Extra objects on the line ("Measurement"):
   roofline       the dominant single-kernel category of the step: algorithmic bytes per
@@ -43,6 +46,7 @@ def parse():
     p.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--no-corr-microbench", action="store_true")
     p.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
+    p.add_argument("--workload", choices=["forward", "hotpath"], default="forward")
     return p.parse_args()
 
 
@@ -68,12 +72,12 @@ def algorithmic_bytes(workload, B):
     return out
 
 
-def corr_microbench(dev, iters=10):
+def corr_microbench(dev, iters=30):
     """BASELINE config 2: correlation2d 1x256x544x960, md=4, fp32, NCHW in/out."""
     import rpeflow_amd.csrc as ops
     a = torch.randn(1, 256, H, W, device=dev)
     b = torch.randn(1, 256, H, W, device=dev)
-    for _ in range(3):
+    for _ in range(10):  # also lets the clocks settle after the latency-bound steps before it
         ops.correlation2d(a, b, 4)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -85,7 +89,7 @@ def corr_microbench(dev, iters=10):
     us = s.elapsed_time(e) / iters * 1e3
     alg = 2 * a.numel() * 4 + 81 * H * W * 4  # 1 238 753 280 B
     gbs = alg / us / 1e3
-    return {"kernel": "corr_mfma_kernel", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"kernel": "corr_mfma_dma_kernel<2,8,2,3,3,true>", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "us_per_launch": round(us, 1),
             "algorithmic_bytes": alg, "workload": "correlation2d 1x256x544x960 md=4 fp32 NCHW (BASELINE config 2)"}
 
@@ -103,8 +107,14 @@ def usable_cores():
     return n
 
 
-def cpu_baseline_worker():
-    """Child process (never touches the GPU): the reference's CPU/PyTorch fallback, restated in
+def make_batch(B, device, first_seed=1000):
+    from rpeflow_amd.synthetic import frame_pair
+    samples = [frame_pair(first_seed + i, H, W, NPTS) for i in range(B)]
+    return {k: torch.stack([torch.from_numpy(s[k]) for s in samples]).to(device) for k in samples[0]}
+
+
+def cpu_baseline_worker(workload):
+    """Child process (never touches the GPU): the reference's CPU/PyTorch fallback path, restated in
     oracle/torch_ref.py, on the host cores.  Sample: batch 1, full size, 1 untimed + 2 timed steps."""
     from types import SimpleNamespace
     from oracle import torch_ref
@@ -112,23 +122,32 @@ def cpu_baseline_worker():
     cores = usable_cores()
     torch.set_num_threads(cores)
     ops = SimpleNamespace(**{n: getattr(torch_ref, n) for n in OP_NAMES})
-    wl = HotPathWorkload(batch=1, height=H, width=W, n_points=NPTS, device="cpu", ops=ops)
-    wl()
+    if workload == "forward":
+        from rpeflow_amd.model import RPEFlow
+        torch.manual_seed(0)
+        model = RPEFlow(ops=ops).eval()
+        batch = make_batch(1, "cpu")
+        step, what = (lambda: model(batch)), "full RPEFlow forward"
+    else:
+        wl = HotPathWorkload(batch=1, height=H, width=W, n_points=NPTS, device="cpu", ops=ops)
+        step, what = wl, "hot-path operator sequence"
+    step()
     steps = 2
     t0 = time.time()
     for _ in range(steps):
-        wl()
+        step()
     dt = (time.time() - t0) / steps
     print(json.dumps({"value": round(1.0 / dt, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-                      "sample": f"{steps} timed steps (+1 warm-up) of the hot-path sequence, batch 1, 544x960 + 8192 pts, "
-                                f"PyTorch-CPU port of the reference fallback (matmul+topk KNN, Python-loop FPS, "
-                                f"81-slice correlation), {dt:.2f} s/step, host cpu_count={os.cpu_count()}"}))
+                      "sample": f"{steps} timed steps (+1 warm-up) of the {what}, batch 1, 544x960 + 8192 pts, "
+                                f"PyTorch-CPU port of the reference fallback path (matmul+topk KNN, Python-loop FPS, "
+                                f"81-slice correlation, stock CPU convs/attention), {dt:.2f} s/step, "
+                                f"host cpu_count={os.cpu_count()}"}))
 
 
-def cpu_baseline(timeout_s=420):
+def cpu_baseline(workload, timeout_s=420):
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], capture_output=True,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--workload", workload], capture_output=True,
                            text=True, timeout=timeout_s, cwd=ROOT)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode == 0 and lines:
@@ -143,7 +162,7 @@ def cpu_baseline(timeout_s=420):
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        return cpu_baseline_worker()
+        return cpu_baseline_worker(args.workload)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,34 +181,64 @@ def main():
     from rpeflow_amd.hotpath import HotPathWorkload, SegmentGraphs, Timer
     _lib.lib()  # fail loudly now if librpeflow_hip.so is missing
 
-    wl = HotPathWorkload(batch=args.batch, height=H, width=W, n_points=NPTS, device=dev, seed=1000 + rank)
-    for _ in range(max(args.warmup, 1)):
-        wl()
-    if args.eager:
-        timer = Timer(True)
-        step = lambda: wl(timer)
-    else:
-        timer = SegmentGraphs()
-        timer.capture(wl)          # one graph per span, shared pool
-        timer.replay(timed=False)  # untimed replay: graph upload
-        step = timer.replay
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def timed(step):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # ---- hot-path sequence: per-category events (and the timed workload if --workload hotpath)
+    wl = HotPathWorkload(batch=args.batch, height=H, width=W, n_points=NPTS, device=dev, seed=1000 + rank)
+    for _ in range(max(args.warmup, 1)):
+        wl()
+    if args.eager:
+        timer = Timer(True)
+        hot_step = lambda: wl(timer)
+    else:
+        timer = SegmentGraphs()
+        timer.capture(wl)          # one graph per span, shared pool
+        timer.replay(timed=False)  # untimed replay: graph upload
+        hot_step = timer.replay
+    launch = "eager" if args.eager else "HIP graphs, one per operator span"
+    dt_hot = timed(hot_step)
+    dt = dt_hot
+
+    # ---- full forward
+    if args.workload == "forward":
+        from rpeflow_amd.model import RPEFlow
+        torch.manual_seed(0)
+        model = RPEFlow().to(dev).eval()
+        batch = make_batch(args.batch, dev, first_seed=1000 + rank * args.batch)
+        for _ in range(max(args.warmup, 1)):
+            out = model(batch)
+        torch.cuda.synchronize()
+        assert torch.isfinite(out["flow_2d"]).all() and torch.isfinite(out["flow_3d"]).all(), "non-finite flow"
+        fwd_step, launch = (lambda: model(batch)), "eager"
+        if not args.eager:
+            try:  # the whole forward as ONE HIP graph: ~3000 launches and the Python between them replayed in one call
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = model(batch)
+                graph.replay()
+                torch.cuda.synchronize()
+                fwd_step, launch = graph.replay, "one HIP graph per forward"
+            except Exception as e:  # noqa: BLE001 -- capture is an optimisation, not a requirement
+                torch.cuda.synchronize()
+                launch = "eager (graph capture failed: %s)" % type(e).__name__
+        dt = timed(fwd_step)
 
     totals = timer.totals_ms()
     if rank == 0:
@@ -201,24 +250,29 @@ def main():
         dom_us = single[dom][0] / single[dom][1] * 1e3
         gbs = alg[dom] / dom_us / 1e3
         line = {
-            "metric": "frame-pairs/sec (544x960 + 8192 pts), hot-path operator sequence of one RPEFlow forward",
+            "metric": "frame-pairs/sec (544x960 + 8192 pts)",
             "value": round(pairs / dt, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "RPEFlow hot path (FPS, 43 KNN, correlation2d, warps, gathers, PointConv, Correlation3D) "
-                                   "at FlyingThings3D shapes; dense 2D convs/attention excluded",
+            "config": {"workload": ("full RPEFlow forward (RGB pair + 20-ch event voxel + 2x8192 pts), random-init weights, "
+                                    "FlyingThings3D val shapes (BASELINE config 3)") if args.workload == "forward" else
+                                   ("RPEFlow hot path only (FPS, 43 KNN, correlation2d, warps, gathers, PointConv, Correlation3D) "
+                                    "at FlyingThings3D shapes; dense 2D convs/attention excluded"),
                        "frame": [H, W], "points": NPTS, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "sharding": f"frame pairs over {world} rank(s), no data-path collective",
-                       "launch": "eager" if args.eager else "HIP graphs, one per operator span"},
+                       "launch": launch},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "us_per_launch": round(dom_us, 1),
                          "launches_per_step": single[dom][1] // args.steps},
-            "breakdown_ms_per_step": breakdown,
+            "hotpath": {"frame_pairs_per_s": round(pairs / dt_hot, 3), "ms_per_step": round(dt_hot / args.steps * 1e3, 3),
+                        "breakdown_ms_per_step": breakdown,
+                        "note": "the hot-path operator sequence of one forward alone (rpeflow_amd/hotpath.py), timed in this run; "
+                                "the roofline kernel is its dominant single-kernel category"},
         }
         if world == 1 and not args.no_corr_microbench:
             line["roofline_corr"] = corr_microbench(dev)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

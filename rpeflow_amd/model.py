@@ -15,10 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .csrc import correlation2d, k_nearest_neighbor
-from .pwc3d_core import Correlation3D, FeaturePyramid3D, FlowEstimator3D, build_pc_pyramid
-from .utils import (Conv1dNormRelu, Conv2dNormRelu, backwarp_2d, backwarp_3d, grid_sample_wrapper,
-                    knn_interpolation, mesh_grid, project_feat_with_nn_corr)
+from .hotpath import native_ops
+from .utils import Conv1dNormRelu, Conv2dNormRelu, mesh_grid
 
 
 class Config(dict):
@@ -222,30 +220,33 @@ class ContextNetwork2D(nn.Module):
 
 # ------------------------------------------------------------------ Bi-CLFM fusers (RPEFlow_core.py:14-162)
 class PyramidFeatureFuser2D(nn.Module):
-    def __init__(self, in_channels_2d, in_channels_3d, num_heads, norm=None):
+    def __init__(self, ops, in_channels_2d, in_channels_3d, num_heads, norm=None):
         super().__init__()
+        self._ops = ops
         self.mlps = nn.Sequential(Conv2dNormRelu(in_channels_3d + 3, in_channels_2d, norm=norm))
         self.mi = Mutual_info_reg_2D(in_channels_2d, in_channels_2d // 2)
         self.fuse = CrossTransformerBlock2D(dim=in_channels_2d, num_heads=num_heads)
 
     def forward(self, xy, feat_2d, feat_3d, nn_proj):
-        return self.fuse(feat_2d, self.mlps(project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])))
+        return self.fuse(feat_2d, self.mlps(self._ops.project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])))
 
 
 class PyramidFeatureFuser3D(nn.Module):
-    def __init__(self, in_channels_2d, in_channels_3d, num_heads, norm=None):
+    def __init__(self, ops, in_channels_2d, in_channels_3d, num_heads, norm=None):
         super().__init__()
+        self._ops = ops
         self.mlps = nn.Sequential(Conv1dNormRelu(in_channels_2d, in_channels_3d, norm=norm))
         self.mi = Mutual_info_reg_3D(in_channels_3d, in_channels_3d // 2)
         self.fuse = CrossTransformerBlock3D(dim=in_channels_3d, num_heads=num_heads)
 
     def forward(self, xy, feat_2d, feat_3d):
-        return self.fuse(feat_3d, self.mlps(grid_sample_wrapper(feat_2d, xy)))
+        return self.fuse(feat_3d, self.mlps(self._ops.grid_sample_wrapper(feat_2d, xy)))
 
 
 class CorrFeatureFuser2D(nn.Module):
-    def __init__(self, in_channels_2d, in_channels_3d, num_heads):
+    def __init__(self, ops, in_channels_2d, in_channels_3d, num_heads):
         super().__init__()
+        self._ops = ops
         self.mlps = nn.Sequential(
             Conv2dNormRelu(in_channels_3d * 2 + 5, in_channels_3d + in_channels_2d),
             Conv2dNormRelu(in_channels_3d + in_channels_2d, in_channels_2d))
@@ -256,14 +257,15 @@ class CorrFeatureFuser2D(nn.Module):
 
     def forward(self, xy, feat_2d, feat_3d, efeat_2d, last_flow_2d, last_flow_3d_to_2d, nn_proj):
         feat_3d = torch.cat([feat_3d, last_flow_3d_to_2d], dim=1)
-        feat_3d_to_2d = project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])
+        feat_3d_to_2d = self._ops.project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])
         feat_3d_to_2d[:, -2:] -= last_flow_2d  # RPEFlow_core.py:82
         return self.fuse(feat_2d, self.mlps(torch.cat([feat_3d_to_2d, efeat_2d], dim=1)))
 
 
 class CorrFeatureFuser3D(nn.Module):
-    def __init__(self, in_channels_2d, in_channels_3d, num_heads):
+    def __init__(self, ops, in_channels_2d, in_channels_3d, num_heads):
         super().__init__()
+        self._ops = ops
         self.mlps = nn.Sequential(
             Conv1dNormRelu(in_channels_2d + in_channels_3d + 2, in_channels_2d + in_channels_3d),
             Conv1dNormRelu(in_channels_2d + in_channels_3d, in_channels_3d))
@@ -272,32 +274,34 @@ class CorrFeatureFuser3D(nn.Module):
         self.fuse = CrossTransformerBlock3D(dim=in_channels_3d, num_heads=num_heads)
 
     def forward(self, xy, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d, last_flow_2d_to_3d):
-        feat_2d_to_3d = grid_sample_wrapper(torch.cat([feat_corr_2d, last_flow_2d_to_3d], dim=1), xy)
-        efeat_2d_to_3d = grid_sample_wrapper(efeat_2d, xy)
+        feat_2d_to_3d = self._ops.grid_sample_wrapper(torch.cat([feat_corr_2d, last_flow_2d_to_3d], dim=1), xy)
+        efeat_2d_to_3d = self._ops.grid_sample_wrapper(efeat_2d, xy)
         feat_2d_to_3d[:, -2:] -= last_flow_3d[:, :2]  # RPEFlow_core.py:110
         return self.fuse(feat_corr_3d, self.mlps(torch.cat([feat_2d_to_3d, efeat_2d_to_3d], dim=1)))
 
 
 class DecoderFeatureFuser2D(nn.Module):
-    def __init__(self, in_channels_2d, in_channels_3d, num_heads):
+    def __init__(self, ops, in_channels_2d, in_channels_3d, num_heads):
         super().__init__()
+        self._ops = ops
         self.mlps = nn.Sequential(Conv2dNormRelu(in_channels_3d + 3, in_channels_2d))
         self.mi = Mutual_info_reg_2D(in_channels_2d, in_channels_2d // 2)
         self.fuse = CrossTransformerBlock2D(dim=in_channels_2d, num_heads=num_heads)
 
     def forward(self, xy, feat_2d, feat_3d, nn_proj):
-        return self.fuse(feat_2d, self.mlps(project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])))
+        return self.fuse(feat_2d, self.mlps(self._ops.project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])))
 
 
 class DecoderFeatureFuser3D(nn.Module):
-    def __init__(self, in_channels_2d, in_channels_3d, num_heads):
+    def __init__(self, ops, in_channels_2d, in_channels_3d, num_heads):
         super().__init__()
+        self._ops = ops
         self.mlps = nn.Sequential(Conv1dNormRelu(in_channels_2d, in_channels_3d))
         self.mi = Mutual_info_reg_3D(in_channels_3d, in_channels_3d // 2)
         self.fuse = CrossTransformerBlock3D(dim=in_channels_3d, num_heads=num_heads)
 
     def forward(self, xy, feat_2d, feat_3d):
-        return self.fuse(feat_3d, self.mlps(grid_sample_wrapper(feat_2d, xy)))
+        return self.fuse(feat_3d, self.mlps(self._ops.grid_sample_wrapper(feat_2d, xy)))
 
 
 # ------------------------------------------------------------------ small geometry helpers (models/utils.py)
@@ -362,9 +366,11 @@ def convex_upsample(flow, mask, scale_factor=8):
 
 # ------------------------------------------------------------------ the core (RPEFlow_core.py:165-432)
 class RPEFlow_core(nn.Module):
-    def __init__(self, cfgs2d, cfgs3d, cfgsattention=None):
+    def __init__(self, cfgs2d, cfgs3d, cfgsattention=None, ops=None):
         super().__init__()
         self.cfgs2d, self.cfgs3d = cfgs2d, cfgs3d
+        self.ops = ops = ops or native_ops()
+        FeaturePyramid3D, Correlation3D, FlowEstimator3D = ops.FeaturePyramid3D, ops.Correlation3D, ops.FlowEstimator3D
         corr_ch = (2 * cfgs2d.max_displacement + 1) ** 2
         event_bins = cfgs2d.event_bins * 2 if cfgs2d.event_polarity else cfgs2d.event_bins
         widths = [32, 64, 96, 128, 192]
@@ -392,15 +398,15 @@ class RPEFlow_core(nn.Module):
 
         heads_p = [1, 2, 2, 4, 4]
         self.pyramid_feat_fusers_2d = nn.ModuleList([nn.Identity()] + [
-            PyramidFeatureFuser2D(c, c, num_heads=h, norm=cfgs2d.norm.feature_pyramid) for c, h in zip(widths, heads_p)])
+            PyramidFeatureFuser2D(ops, c, c, num_heads=h, norm=cfgs2d.norm.feature_pyramid) for c, h in zip(widths, heads_p)])
         self.pyramid_feat_fusers_3d = nn.ModuleList([nn.Identity()] + [
-            PyramidFeatureFuser3D(c, c, num_heads=h, norm=cfgs3d.norm.feature_pyramid) for c, h in zip(widths, heads_p)])
+            PyramidFeatureFuser3D(ops, c, c, num_heads=h, norm=cfgs3d.norm.feature_pyramid) for c, h in zip(widths, heads_p)])
         self.corr_feat_fusers_2d = nn.ModuleList([nn.Identity()] + [
-            CorrFeatureFuser2D(corr_ch, c, num_heads=h) for c, h in zip(widths, [1, 1, 3, 3, 3])])
+            CorrFeatureFuser2D(ops, corr_ch, c, num_heads=h) for c, h in zip(widths, [1, 1, 3, 3, 3])])
         self.corr_feat_fusers_3d = nn.ModuleList([nn.Identity()] + [
-            CorrFeatureFuser3D(corr_ch, c, num_heads=h) for c, h in zip(widths, heads_p)])
-        self.estimator_feat_fuser_2d = DecoderFeatureFuser2D(self.flow_estimator_2d.flow_feat_dim, 64, num_heads=2)
-        self.estimator_feat_fuser_3d = DecoderFeatureFuser3D(self.flow_estimator_2d.flow_feat_dim, 64, num_heads=2)
+            CorrFeatureFuser3D(ops, corr_ch, c, num_heads=h) for c, h in zip(widths, heads_p)])
+        self.estimator_feat_fuser_2d = DecoderFeatureFuser2D(ops, self.flow_estimator_2d.flow_feat_dim, 64, num_heads=2)
+        self.estimator_feat_fuser_3d = DecoderFeatureFuser3D(ops, self.flow_estimator_2d.flow_feat_dim, 64, num_heads=2)
 
         self.conv_last_2d = nn.Conv2d(self.flow_estimator_2d.flow_feat_dim, 2, kernel_size=3, stride=1, padding=1)
         self.conv_last_3d = nn.Conv1d(64, 3, kernel_size=1)
@@ -416,6 +422,9 @@ class RPEFlow_core(nn.Module):
         flows_2d, flows_3d, flow_feats_2d, flow_feats_3d = [], [], [], []
         sensor_h, sensor_w = camera_info["sensor_h"], camera_info["sensor_w"]
         md, k = self.cfgs2d.max_displacement, self.cfgs3d.k
+        o = self.ops
+        correlation2d, k_nearest_neighbor = o.correlation2d, o.k_nearest_neighbor
+        backwarp_2d, backwarp_3d, knn_interpolation = o.backwarp_2d, o.backwarp_3d, o.knn_interpolation
         top = len(xyzs1) - 1
         for level in range(top, 0, -1):
             xyz1, feat1_2d, feat1_3d = xyzs1[level], feats1_2d[level], feats1_3d[level]
@@ -496,11 +505,13 @@ class RPEFlow(nn.Module):
     ``ids_on_host``: compute the IDS transform (log/div of 2*B*3*N floats) on the CPU, as the
     reference's CPU path does, so that FPS/KNN see bit-identical coordinates."""
 
-    def __init__(self, cfgs=None, ids_on_host=False):
+    def __init__(self, cfgs=None, ids_on_host=False, ops=None):
+        """``ops``: namespace of hot-path callables/classes (rpeflow_amd.hotpath.OP_NAMES); default = this
+        package's HIP-backed ones.  Tests and bench's cpu_baseline leg pass a CPU port instead."""
         super().__init__()
         self.cfgs = cfgs or things_config()
         self.ids_on_host = ids_on_host
-        self.pwc_fusion_core = RPEFlow_core(self.cfgs.pwc2d, self.cfgs.pwc3d, self.cfgs.get("attention"))
+        self.pwc_fusion_core = RPEFlow_core(self.cfgs.pwc2d, self.cfgs.pwc3d, self.cfgs.get("attention"), ops=ops)
 
     @torch.no_grad()
     def forward(self, inputs, is_Train=False):
@@ -527,7 +538,7 @@ class RPEFlow(nn.Module):
                 pc1, pc2 = perspect2parallel(pc1, persp, paral), perspect2parallel(pc2, persp, paral)
 
         core = self.pwc_fusion_core
-        xyzs1, xyzs2, _, _ = build_pc_pyramid(pc1, pc2, [4096, 2048, 1024, 512, 256])
+        xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, [4096, 2048, 1024, 512, 256])
         feats1_2d, feats1_3d = core.encode(image1, xyzs1)
         feats2_2d, feats2_3d = core.encode(image2, xyzs2)
         efeats_2d = core.encode_event(event_voxel)

@@ -42,14 +42,12 @@ def test_state_dict_matches_reference(golden_dir):
 
 
 @torch.no_grad()
-def test_model_wiring_on_cpu_with_ported_ops(golden_dir, monkeypatch):
+def test_model_wiring_on_cpu_with_ported_ops(golden_dir):
+    from types import SimpleNamespace
     from oracle import torch_ref as R
     import rpeflow_amd.model as M
-    for name in ["correlation2d", "k_nearest_neighbor", "build_pc_pyramid", "FeaturePyramid3D", "Correlation3D",
-                 "FlowEstimator3D", "backwarp_2d", "backwarp_3d", "grid_sample_wrapper", "knn_interpolation",
-                 "project_feat_with_nn_corr"]:
-        monkeypatch.setattr(M, name, getattr(R, name))
-    model = M.RPEFlow().eval()
+    from rpeflow_amd.hotpath import OP_NAMES
+    model = M.RPEFlow(ops=SimpleNamespace(**{n: getattr(R, n) for n in OP_NAMES})).eval()
     model.load_state_dict(seeded_state(model), strict=True)
     out = model(sample_batch("cpu"))
     g = np.load(os.path.join(golden_dir, "model_128x192.npz"))
