@@ -219,6 +219,7 @@ def main():
     # ---- full forward
     if args.workload == "forward":
         from rpeflow_amd.model import RPEFlow
+        torch.backends.cudnn.benchmark = True  # as eval_withocc.py:159: let MIOpen search its conv solvers during warm-up
         torch.manual_seed(0)
         model = RPEFlow().to(dev).eval()
         batch = make_batch(args.batch, dev, first_seed=1000 + rank * args.batch)

@@ -93,8 +93,10 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(
                     const int ni = base + l;
                     // every listed entry has a smaller index than ni, so "nd < entry"
                     // (strict) keeps equal distances in index order
-                    const float upd = __shfl_up(Ld[j], 1);
-                    const int upi = __shfl_up(Li[j], 1);
+                    // lane r <- lane r-1 across the whole wave: DPP wave_shr:1 (a register move, ~10 cycles)
+                    // instead of __shfl_up's ds_bpermute round trip; lane 0 keeps its own value
+                    const float upd = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Ld[j]), __float_as_int(Ld[j]), 0x138, 0xf, 0xf, false));
+                    const int upi = __builtin_amdgcn_update_dpp(Li[j], Li[j], 0x138, 0xf, 0xf, false);
                     const bool gt = nd < Ld[j];
                     const bool gtp = (lane > 0) && (nd < upd);
                     Ld[j] = gt ? (gtp ? upd : nd) : Ld[j];
