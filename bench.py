@@ -89,8 +89,13 @@ def corr_microbench(dev, iters=30):
     us = s.elapsed_time(e) / iters * 1e3
     alg = 2 * a.numel() * 4 + 81 * H * W * 4  # 1 238 753 280 B
     gbs = alg / us / 1e3
+    traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process)
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith("corr_microbench_pmc.json"):
+            traffic = int(json.load(open(os.path.join(ROOT, "profiles", name)))["derived"]["hbm_traffic_bytes"])
+            break
     return {"kernel": "corr_mfma_dma_kernel<2,8,2,3,3,true>", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "us_per_launch": round(us, 1),
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "us_per_launch": round(us, 1),
             "algorithmic_bytes": alg, "workload": "correlation2d 1x256x544x960 md=4 fp32 NCHW (BASELINE config 2)"}
 
 
