@@ -1,0 +1,29 @@
+"""Full forward only, for rocprofv3 --kernel-trace: warm-up (MIOpen find), a marker kernel, N steady-state steps,
+a marker.  tools/trace_window.py sums kernels between the markers.  Usage: python tools/prof_forward.py [steps]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+sys.argv = [sys.argv[0]] + sys.argv[1:]
+import bench
+from rpeflow_amd.model import RPEFlow
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+model = RPEFlow().to(dev).eval()
+batch = bench.make_batch(4, dev)
+for _ in range(3):
+    model(batch)
+torch.cuda.synchronize()
+from rpeflow_amd import _lib
+probe = torch.zeros(256, device=dev)
+mark = lambda: _lib.lib().rpe_probe_mfma4x4(probe.data_ptr(), torch.cuda.current_stream().cuda_stream)  # marker kernel
+mark()
+for _ in range(steps):
+    model(batch)
+mark()
+torch.cuda.synchronize()
+print("done", steps)
