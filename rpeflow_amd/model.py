@@ -511,7 +511,15 @@ class RPEFlow(nn.Module):
         super().__init__()
         self.cfgs = cfgs or things_config()
         self.ids_on_host = ids_on_host
+        self.overlap_streams = True
+        self._streams = {}
         self.pwc_fusion_core = RPEFlow_core(self.cfgs.pwc2d, self.cfgs.pwc3d, self.cfgs.get("attention"), ops=ops)
+
+    def _side_stream(self, device):
+        key = torch.device(device).index
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
 
     @torch.no_grad()
     def forward(self, inputs, is_Train=False):
@@ -538,10 +546,29 @@ class RPEFlow(nn.Module):
                 pc1, pc2 = perspect2parallel(pc1, persp, paral), perspect2parallel(pc2, persp, paral)
 
         core = self.pwc_fusion_core
-        xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, [4096, 2048, 1024, 512, 256])
-        feats1_2d, feats1_3d = core.encode(image1, xyzs1)
-        feats2_2d, feats2_3d = core.encode(image2, xyzs2)
-        efeats_2d = core.encode_event(event_voxel)
+        n_samples = [4096, 2048, 1024, 512, 256]
+        if pc1.is_cuda and self.overlap_streams:
+            # The 3-D encoder (FPS: 4096 dependent samples on 2B workgroups, then small PointConv kernels) and
+            # the three 2-D pyramids (large convolutions) share no data until decode(): run them on two HIP
+            # streams.  FPS alone keeps 2B of 256 CUs busy for ~4.8 ms; here it hides behind the convolutions.
+            main = torch.cuda.current_stream(pc1.device)
+            side = self._side_stream(pc1.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, n_samples)
+                feats1_3d = core.feature_pyramid_3d(xyzs1)
+                feats2_3d = core.feature_pyramid_3d(xyzs2)
+            feats1_2d = core.feature_pyramid_2d(image1)
+            feats2_2d = core.feature_pyramid_2d(image2)
+            efeats_2d = core.encode_event(event_voxel)
+            main.wait_stream(side)
+            for t in list(xyzs1) + list(xyzs2) + list(feats1_3d) + list(feats2_3d):
+                t.record_stream(main)  # allocated on the side stream, consumed on the main one
+        else:
+            xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, n_samples)
+            feats1_2d, feats1_3d = core.encode(image1, xyzs1)
+            feats2_2d, feats2_3d = core.encode(image2, xyzs2)
+            efeats_2d = core.encode_event(event_voxel)
         flows_2d, flows_3d = core.decode(xyzs1, xyzs2, feats1_2d, feats2_2d, feats1_3d, feats2_3d, efeats_2d,
                                          paral if self.cfgs.ids.enabled else persp)
         flow_3d = flows_3d[0]
