@@ -163,6 +163,22 @@ int rpe_corr3d_weighted_sum(const float *vals, int gather,
                             const int64_t *knn, int64_t knn_row_stride, int B, int C, int N, int M,
                             float *out, rpe_stream_t stream);
 
+/* ---- Restormer-block pieces (models/restormer_arch.py) -------
+ * rpe_dwconv3: depth-wise convolution, stride 1, zero padding 1: kh = 3 -> 3x3 over [B,C,H,W] (weight
+ *   [C,1,3,3]); kh = 1 -> 3-tap over [B,C,W] with H = 1 (weight [C,1,3]).  The input is the channel
+ *   concatenation of up to three contiguous tensors in0 [B,C0,H,W], in1 [B,C1,H,W], in2 [B,C2,H,W]
+ *   (C1 = C2 = 0 for one tensor): qkv_dwconv(torch.cat((x, y, y))) of :182/:263 without the cat.
+ *   bias [C] or NULL.  gate = 1: out[b][c] = gelu(conv[c]) * conv[c + C/2] for c < C/2 (the GDFN
+ *   gate, :104-105/:244-245; erf GELU), out [B,C/2,H,W]; gate = 0: out [B,C,H,W].
+ * rpe_channel_layernorm: out[b][c][p] = (x - mean_c) / sqrt(var_c + eps) * weight[c] + bias[c] over the
+ *   channel axis of [B,C,P] (biased variance; WithBias_LayerNorm :47-63); bias = NULL gives BiasFree
+ *   (:31-44: x / sqrt(var + eps) * weight, no mean subtraction).                                  */
+int rpe_dwconv3(const float *in0, int C0, const float *in1, int C1, const float *in2, int C2,
+                const float *weight, const float *bias, int B, int H, int W, int kh, int gate,
+                float *out, rpe_stream_t stream);
+int rpe_channel_layernorm(const float *x, const float *weight, const float *bias, int B, int C, int64_t P,
+                          float eps, float *out, rpe_stream_t stream);
+
 /* ---- diagnostics -------------------------------------------------------------
  * Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation
  * kernel relies on: out[64*4] = D for A[lane]=lane, B[lane]=100*lane (one K).   */

@@ -28,6 +28,9 @@ _PROTOTYPES = {
     "rpe_correlation2d_forward": [_c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_float, _c_int, _c_ptr, _c_ptr],
     "rpe_probe_mfma4x4": [_c_ptr, _c_ptr],
+    "rpe_dwconv3": [_c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
+                    _c_ptr, _c_ptr],
+    "rpe_channel_layernorm": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_float, _c_ptr, _c_ptr],
     "rpe_corr3d_hidden": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                           _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
     "rpe_corr3d_weighted_sum": [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,

@@ -59,6 +59,9 @@ class _ChannelNorm(nn.Module):
         self.body = self._Affine(dim, self.with_bias)
 
     def forward(self, x):
+        if x.is_cuda:  # one kernel instead of mean / var / sub / sqrt / div / mul / add
+            from .restormer_ops import channel_layernorm
+            return channel_layernorm(x, self.body.weight, self.body.bias if self.with_bias else None)
         shape = [1, -1] + [1] * (x.dim() - 2)
         var = x.var(1, keepdim=True, unbiased=False)
         if self.with_bias:
@@ -80,7 +83,12 @@ class _MutualAttention(nn.Module):
 
     def forward(self, x, y):
         shape = x.shape
-        q, k, v = self.qkv_dwconv(torch.cat((x, y, y), dim=1)).chunk(3, dim=1)
+        if x.is_cuda:  # depth-wise conv reading x | y | y in place of the concatenation
+            from .restormer_ops import dwconv3
+            qkv = dwconv3([x, y, y], self.qkv_dwconv.weight, self.qkv_dwconv.bias)
+        else:
+            qkv = self.qkv_dwconv(torch.cat((x, y, y), dim=1))
+        q, k, v = qkv.chunk(3, dim=1)
         heads = lambda t: t.reshape(shape[0], self.num_heads, shape[1] // self.num_heads, -1)
         q, k, v = F.normalize(heads(q), dim=-1), F.normalize(heads(k), dim=-1), heads(v)
         attn = ((q @ k.transpose(-2, -1)) * self.temperature).softmax(dim=-1)
@@ -99,6 +107,9 @@ class _GatedFeedForward(nn.Module):
         self.project_out = conv(hidden, dim, kernel_size=1, bias=bias)
 
     def forward(self, x):
+        if x.is_cuda:  # depth-wise conv + gelu gate in one kernel
+            from .restormer_ops import dwconv3
+            return self.project_out(dwconv3([self.project_in(x)], self.dwconv.weight, self.dwconv.bias, gate=True))
         a, b = self.dwconv(self.project_in(x)).chunk(2, dim=1)
         return self.project_out(F.gelu(a) * b)
 

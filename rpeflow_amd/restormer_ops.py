@@ -1,0 +1,52 @@
+"""Host side of the Restormer-block kernels (csrc/restormer.hip): depth-wise 3x3 / 3-tap convolution with
+fused channel concatenation and GDFN gate, and channel LayerNorm.  GPU tensors only."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_NULL = ctypes.c_void_p(0)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else _NULL
+
+
+def dwconv3(inputs, weight, bias=None, gate=False):
+    """Depth-wise conv (stride 1, padding 1) of cat(inputs, dim=1) with ``weight`` [C,1,3,3] (2-D inputs
+    [B,Ci,H,W]) or [C,1,3] (1-D inputs [B,Ci,N]); gate: gelu(first half) * second half."""
+    assert 1 <= len(inputs) <= 3
+    _lib.require_gpu(*inputs, weight, op="dwconv3")
+    xs = [t.contiguous().float() for t in inputs]
+    two_d = xs[0].dim() == 4
+    B = xs[0].shape[0]
+    H, W = (xs[0].shape[2], xs[0].shape[3]) if two_d else (1, xs[0].shape[2])
+    chans = [t.shape[1] for t in xs] + [0] * (3 - len(xs))
+    C = sum(chans)
+    assert weight.shape[0] == C and weight.shape[-1] == 3
+    w = weight.detach().contiguous().float()
+    b = bias.detach().contiguous().float() if bias is not None else None
+    c_out = C // 2 if gate else C
+    out = torch.empty((B, c_out, H, W) if two_d else (B, c_out, W), dtype=torch.float32, device=xs[0].device)
+    ptrs = [_ptr(t) for t in xs] + [_NULL] * (3 - len(xs))
+    with torch.cuda.device(xs[0].device):
+        rc = _lib.lib().rpe_dwconv3(ptrs[0], chans[0], ptrs[1], chans[1], ptrs[2], chans[2], _ptr(w), _ptr(b),
+                                    B, H, W, 3 if two_d else 1, int(gate), _ptr(out), _lib.stream_of(xs[0]))
+    _lib.check(rc, "dwconv3")
+    return out
+
+
+def channel_layernorm(x, weight, bias=None, eps=1e-5):
+    """LayerNorm over dim 1 of [B,C,...] (biased variance); bias None = BiasFree form (no mean subtraction)."""
+    _lib.require_gpu(x, weight, op="channel_layernorm")
+    x = x.contiguous().float()
+    B, C = x.shape[:2]
+    P = x.numel() // (B * C)
+    out = torch.empty_like(x)
+    w = weight.detach().contiguous().float()
+    b = bias.detach().contiguous().float() if bias is not None else None
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().rpe_channel_layernorm(_ptr(x), _ptr(w), _ptr(b), B, C, P, float(eps), _ptr(out), _lib.stream_of(x))
+    _lib.check(rc, "channel_layernorm")
+    return out

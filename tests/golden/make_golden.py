@@ -151,8 +151,26 @@ def gen_model():
     save("model_128x192", flow_2d=f2, flow_3d=f3)
 
 
+@torch.no_grad()
+def gen_model_dsec():
+    """DSEC-shaped sample (conf/test/dsec.yaml: 480x640 frames -> resize_to_64x 512x640, sensor 16x20).
+    flow_2d is stored on a stride-8 grid (the full map is 2.4 MB) together with the EPE scalars."""
+    m = reference_model()
+    m.load_state_dict({k: T(v) for k, v in model_params(m).items()}, strict=True)
+    m.eval()
+    sample = I.frame_pair(2000, H=480, W=640, N=8192, dsec=True)
+    batch = {k: T(v)[None] for k, v in sample.items()}
+    out = m(batch, is_Train=False)
+    f2, f3 = out["flow_2d"].numpy(), out["flow_3d"].numpy()
+    assert np.isfinite(f2).all() and np.isfinite(f3).all()
+    epe2 = float(np.sqrt(((f2 - sample["flow_2d"][None, :2]) ** 2).sum(1)).mean())
+    epe3 = float(np.sqrt(((f3 - sample["flow_3d"][None, :3]) ** 2).sum(1)).mean())
+    print("dsec flow_2d |max|", np.abs(f2).max(), "flow_3d |max|", np.abs(f3).max(), "EPE", epe2, epe3)
+    save("model_dsec_480x640", flow_2d_s8=f2[:, :, ::8, ::8].copy(), flow_3d=f3, epe2d=np.float64(epe2), epe3d=np.float64(epe3))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model"]
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec"]
     for w in which:
         globals()["gen_" + w]()

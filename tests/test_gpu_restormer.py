@@ -1,0 +1,54 @@
+"""GPU: the Restormer-block kernels against plain PyTorch fp32."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from rpeflow_amd.restormer_ops import channel_layernorm, dwconv3  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 9, 7, 11), (1, 96, 36, 60), (3, 5, 1, 1), (2, 30, 2, 130)])
+def test_dwconv_2d(B, C, H, W):
+    torch.manual_seed(C)
+    x, y = torch.randn(B, C, H, W), torch.randn(B, C, H, W)
+    w, b = torch.randn(3 * C, 1, 3, 3), torch.randn(3 * C)
+    ref = F.conv2d(torch.cat((x, y, y), 1), w, b, padding=1, groups=3 * C)
+    got = dwconv3([x.to(DEV), y.to(DEV), y.to(DEV)], w.to(DEV), b.to(DEV)).cpu()
+    assert (got - ref).abs().max() < 1e-5
+    got = dwconv3([x.to(DEV)], w[:C].to(DEV)).cpu()
+    assert (got - F.conv2d(x, w[:C], None, padding=1, groups=C)).abs().max() < 1e-5
+    # gate: gelu(first half) * second half (restormer_arch.py:104-105)
+    w2 = torch.randn(2 * C, 1, 3, 3)
+    a, g = F.conv2d(torch.cat((x, y), 1), w2, None, padding=1, groups=2 * C).chunk(2, dim=1)
+    got = dwconv3([x.to(DEV), y.to(DEV)], w2.to(DEV), gate=True).cpu()
+    assert (got - F.gelu(a) * g).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("B,C,N", [(2, 7, 33), (1, 64, 4096), (2, 3, 1)])
+def test_dwconv_1d(B, C, N):
+    torch.manual_seed(N)
+    x, y = torch.randn(B, C, N), torch.randn(B, C, N)
+    w = torch.randn(3 * C, 1, 3)
+    ref = F.conv1d(torch.cat((x, y, y), 1), w, None, padding=1, groups=3 * C)
+    got = dwconv3([x.to(DEV), y.to(DEV), y.to(DEV)], w.to(DEV)).cpu()
+    assert (got - ref).abs().max() < 1e-5
+    w2 = torch.randn(2 * C, 1, 3)
+    a, g = F.conv1d(torch.cat((x, y), 1), w2, None, padding=1, groups=2 * C).chunk(2, dim=1)
+    assert (dwconv3([x.to(DEV), y.to(DEV)], w2.to(DEV), gate=True).cpu() - F.gelu(a) * g).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 9, 15), (1, 192, 300), (3, 1, 5), (2, 96, 36, 60)])
+def test_channel_layernorm(shape):
+    torch.manual_seed(shape[1])
+    x = torch.randn(*shape) * 3 + 1
+    w, b = torch.rand(shape[1]) + 0.5, torch.randn(shape[1])
+    view = [1, -1] + [1] * (len(shape) - 2)
+    var = x.var(1, keepdim=True, unbiased=False)
+    ref = (x - x.mean(1, keepdim=True)) / torch.sqrt(var + 1e-5) * w.view(view) + b.view(view)  # restormer_arch.py:60-63
+    assert (channel_layernorm(x.to(DEV), w.to(DEV), b.to(DEV)).cpu() - ref).abs().max() < 2e-5
+    ref = x / torch.sqrt(var + 1e-5) * w.view(view)  # BiasFree, :43-44
+    assert (channel_layernorm(x.to(DEV), w.to(DEV), None).cpu() - ref).abs().max() < 2e-5

@@ -82,3 +82,22 @@ def test_model_on_gpu_matches_reference_golden(golden_dir):
     # element-wise the two runs cannot be identical: KNNs on warped clouds depend on conv outputs, and a
     # 1e-6 difference there flips a near-tied neighbour now and then; bound the mean.
     assert d2.mean() < 1e-3 and d3.mean() < 1e-3
+
+
+@pytest.mark.gpu
+@torch.no_grad()
+def test_model_on_gpu_dsec_shape(golden_dir):
+    """BASELINE config 5 shapes: 480x640 frames (resized to 512x640 inside the model), 4-channel flow_3d target."""
+    from rpeflow_amd.model import RPEFlow
+    model = RPEFlow(ids_on_host=True).eval()
+    model.load_state_dict(seeded_state(model), strict=True)
+    model = model.to("cuda:0")
+    s = I.frame_pair(2000, H=480, W=640, N=8192, dsec=True)
+    out = model({k: torch.from_numpy(v)[None].to("cuda:0") for k, v in s.items()})
+    g = np.load(os.path.join(golden_dir, "model_dsec_480x640.npz"))
+    f2, f3 = out["flow_2d"].cpu().numpy(), out["flow_3d"].cpu().numpy()
+    assert f2.shape == (1, 2, 480, 640)
+    e2, e3 = epe(f2, s["flow_2d"][None, :2]), epe(f3, s["flow_3d"][None, :3])
+    print("dsec EPE2D diff", abs(e2 - float(g["epe2d"])), "EPE3D diff", abs(e3 - float(g["epe3d"])))
+    assert abs(e2 - float(g["epe2d"])) < 1e-4 and abs(e3 - float(g["epe3d"])) < 1e-4
+    assert np.abs(f2[:, :, ::8, ::8] - g["flow_2d_s8"]).mean() < 1e-3 and np.abs(f3 - g["flow_3d"]).mean() < 1e-3
