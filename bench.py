@@ -224,7 +224,7 @@ def main():
     # ---- full forward
     if args.workload == "forward":
         from rpeflow_amd.model import RPEFlow
-        torch.backends.cudnn.benchmark = True  # as eval_withocc.py:159: let MIOpen search its conv solvers during warm-up
+        # (eval_withocc.py:159 sets cudnn.benchmark; measured here it buys <1 % and costs minutes of MIOpen search per process)
         torch.manual_seed(0)
         model = RPEFlow().to(dev).eval()
         batch = make_batch(args.batch, dev, first_seed=1000 + rank * args.batch)

@@ -178,6 +178,11 @@ int rpe_dwconv3(const float *in0, int C0, const float *in1, int C1, const float 
                 float *out, rpe_stream_t stream);
 int rpe_channel_layernorm(const float *x, const float *weight, const float *bias, int B, int C, int64_t P,
                           float eps, float *out, rpe_stream_t stream);
+/* rpe_channel_affine_act: y[b][c][p] = act(scale[c]*y[b][c][p] + shift[c]) IN PLACE over [B,C,P] -- the bias add,
+ *   eval-mode BatchNorm and activation after a Conv{1,2}dNormRelu convolution (models/utils.py:7-62) in one pass.
+ *   scale / shift may be NULL (1 / 0).  act: 0 none, 1 relu, 2 leaky_relu(slope).                              */
+int rpe_channel_affine_act(float *y, const float *scale, const float *shift, int B, int C, int64_t P,
+                           int act, float slope, rpe_stream_t stream);
 
 /* ---- diagnostics -------------------------------------------------------------
  * Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation

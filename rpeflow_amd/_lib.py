@@ -31,6 +31,7 @@ _PROTOTYPES = {
     "rpe_dwconv3": [_c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                     _c_ptr, _c_ptr],
     "rpe_channel_layernorm": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_float, _c_ptr, _c_ptr],
+    "rpe_channel_affine_act": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_int, _c_float, _c_ptr],
     "rpe_corr3d_hidden": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                           _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
     "rpe_corr3d_weighted_sum": [_c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr,

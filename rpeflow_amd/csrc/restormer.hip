@@ -7,8 +7,8 @@
 //                       (qkv_dwconv, restormer_arch.py:175-176, 256-257; dwconv :96-97, 234-235).  The input may be
 //                       given as up to three channel segments, which fuses torch.cat((x, y, y)) (:182, 263);
 //                       gate = 1 fuses the GDFN gate gelu(x1) * x2 over the two halves of the channels (:104-105, 244-245).
-//   channel_norm_kernel LayerNorm over the channel axis of [B,C,P] (WithBias / BiasFree, :31-63): mean and biased
-//                       variance per position in one pass (Welford), normalise + affine in a second.
+//   channel_norm_kernel LayerNorm over the channel axis of [B,C,P] (WithBias / BiasFree, :31-63), C <= 256: x read once
+//                       into registers, exact two-pass mean / biased variance, normalise + affine.
 #include <math.h>
 
 #include "common.h"
@@ -66,26 +66,70 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(Segments seg, const float 
     out[((int64_t)b * Cout + c) * HW + p] = v;
 }
 
+// 64 positions x 4 channel groups per workgroup: thread (pl, cg) keeps channels cg, cg+4, ... of its position in
+// registers (x is read once), the two reductions over the four groups (mean, then sum of squared deviations:
+// the exact two-pass variance) go through LDS.
+template <int CPT>  // channels per thread: C <= 4 * CPT
 __global__ __launch_bounds__(256) void channel_norm_kernel(const float *__restrict__ x, const float *__restrict__ weight,
                                                            const float *__restrict__ bias, int C, int64_t P, float eps,
                                                            float *__restrict__ out) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float part[2][4][64];
+    const int pl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * 64 + pl;
     const int b = blockIdx.y;
-    if (p >= P) return;
-    const float *xb = x + (int64_t)b * C * P + p;
-    float mean = 0.f, m2 = 0.f;
-    for (int c = 0; c < C; ++c) {  // Welford: biased variance = m2 / C
-        const float v = xb[(int64_t)c * P];
-        const float d = v - mean;
-        mean += d / (float)(c + 1);
-        m2 += d * (v - mean);
+    const bool live = p < P;
+    const float *xb = x + (int64_t)b * C * P + (live ? p : 0);
+    float v[CPT];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = cg + 4 * i;
+        v[i] = (live && c < C) ? xb[(int64_t)c * P] : 0.f;
+        s += v[i];
     }
-    const float inv = 1.0f / sqrtf(m2 / (float)C + eps);
+    part[0][cg][pl] = s;
+    __syncthreads();
+    const float mean = (part[0][0][pl] + part[0][1][pl] + part[0][2][pl] + part[0][3][pl]) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = cg + 4 * i;
+        const float d = v[i] - mean;
+        q += (c < C) ? d * d : 0.f;
+    }
+    part[1][cg][pl] = q;
+    __syncthreads();
+    const float var = (part[1][0][pl] + part[1][1][pl] + part[1][2][pl] + part[1][3][pl]) / (float)C;
+    const float inv = 1.0f / sqrtf(var + eps);
+    if (!live) return;
     float *ob = out + (int64_t)b * C * P + p;
-    if (bias) {
-        for (int c = 0; c < C; ++c) ob[(int64_t)c * P] = (xb[(int64_t)c * P] - mean) * inv * weight[c] + bias[c];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = cg + 4 * i;
+        if (c < C) ob[(int64_t)c * P] = bias ? (v[i] - mean) * inv * weight[c] + bias[c] : v[i] * inv * weight[c];
+    }
+}
+
+// y[b][c][p] = act(scale[c] * y + shift[c]), in place: the bias add, eval-mode BatchNorm and activation that
+// follow every Conv{1,2}dNormRelu convolution (models/utils.py:7-62) as one pass instead of three kernels.
+// act: 0 none, 1 relu, 2 leaky_relu(slope)
+__global__ __launch_bounds__(256) void affine_act_kernel(float *__restrict__ y, const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, int C, int64_t P, int act, float slope) {
+    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (p >= P) return;
+    const float a = scale ? scale[c] : 1.0f, s = shift ? shift[c] : 0.0f;
+    float *row = y + ((int64_t)b * C + c) * P + p;
+    auto f = [&](float v) {
+        v = a * v + s;
+        return act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v >= 0.f ? v : v * slope) : v);
+    };
+    if (p + 4 <= P && ((reinterpret_cast<uintptr_t>(row) & 15) == 0)) {
+        float4 v = *reinterpret_cast<float4 *>(row);
+        v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
+        *reinterpret_cast<float4 *>(row) = v;
     } else {
-        for (int c = 0; c < C; ++c) ob[(int64_t)c * P] = xb[(int64_t)c * P] * inv * weight[c];
+        for (int i = 0; i < 4 && p + i < P; ++i) row[i] = f(row[i]);
     }
 }
 
@@ -117,7 +161,27 @@ RPE_API int rpe_channel_layernorm(const float *x, const float *weight, const flo
     if (!x || !weight || !out || B < 0 || C < 1 || P < 0) return RPE_EINVAL;
     if (B == 0 || P == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
-    dim3 grid((unsigned)((P + 255) / 256), B), block(256);
-    hipLaunchKernelGGL(channel_norm_kernel, grid, block, 0, (hipStream_t)stream, x, weight, bias, C, P, eps, out);
+    if (C > 4 * 64) return RPE_EUNSUPPORTED;
+    dim3 grid((unsigned)((P + 63) / 64), B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int cpt = (C + 3) / 4;
+#define RPE_LN(N) hipLaunchKernelGGL(channel_norm_kernel<N>, grid, block, 0, st, x, weight, bias, C, P, eps, out)
+    if (cpt <= 8) RPE_LN(8);
+    else if (cpt <= 16) RPE_LN(16);
+    else if (cpt <= 24) RPE_LN(24);
+    else if (cpt <= 32) RPE_LN(32);
+    else if (cpt <= 48) RPE_LN(48);
+    else RPE_LN(64);
+#undef RPE_LN
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_channel_affine_act(float *y, const float *scale, const float *shift, int B, int C, int64_t P, int act,
+                                   float slope, rpe_stream_t stream) {
+    if (!y || B < 0 || C < 1 || P < 0 || act < 0 || act > 2) return RPE_EINVAL;
+    if (B == 0 || P == 0) return 0;
+    if (B > 65535 || C > 65535) return RPE_EUNSUPPORTED;
+    dim3 grid((unsigned)((P + 1023) / 1024), C, B), block(256);
+    hipLaunchKernelGGL(affine_act_kernel, grid, block, 0, (hipStream_t)stream, y, scale, shift, C, P, act, slope);
     return rpe_launch_status();
 }

@@ -50,3 +50,16 @@ def channel_layernorm(x, weight, bias=None, eps=1e-5):
         rc = _lib.lib().rpe_channel_layernorm(_ptr(x), _ptr(w), _ptr(b), B, C, P, float(eps), _ptr(out), _lib.stream_of(x))
     _lib.check(rc, "channel_layernorm")
     return out
+
+
+def channel_affine_act_(y, scale, shift, act, slope=0.1):
+    """In place on a contiguous [B,C,...] tensor: y = act(scale[c]*y + shift[c]); act in {None,'relu','leaky_relu'}."""
+    _lib.require_gpu(y, op="channel_affine_act")
+    assert y.is_contiguous() and y.dtype == torch.float32
+    B, C = y.shape[:2]
+    P = y.numel() // (B * C)
+    code = {None: 0, "relu": 1, "leaky_relu": 2}[act]
+    with torch.cuda.device(y.device):
+        rc = _lib.lib().rpe_channel_affine_act(_ptr(y), _ptr(scale), _ptr(shift), B, C, P, code, float(slope), _lib.stream_of(y))
+    _lib.check(rc, "channel_affine_act")
+    return y

@@ -66,8 +66,45 @@ class _ConvNormRelu(nn.Module):
         self.norm_fn = _norm(norm, out_channels, self.dims)
         self.relu_fn = _act(activation)
 
+    def _epilogue(self):
+        """(scale, shift, act) of the per-channel epilogue y = act(scale*conv + shift) that bias, eval-mode BatchNorm
+        and the activation amount to -- or None when that does not apply (training BN, InstanceNorm).  Cached until a
+        parameter or buffer changes."""
+        norm, act = self.norm_fn, self.relu_fn
+        if isinstance(norm, nn.modules.batchnorm._BatchNorm):
+            if norm.training or not norm.track_running_stats:
+                return None
+        elif not isinstance(norm, nn.Identity):
+            return None
+        kind = "leaky_relu" if isinstance(act, nn.LeakyReLU) else "relu" if isinstance(act, nn.ReLU) else None
+        tensors = [t for t in (self.conv_fn.bias, *norm.parameters(), *norm.buffers()) if t is not None]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        cache = getattr(self, "_epi_cache", None)
+        if cache is None or cache[0] != key:
+            bias = self.conv_fn.bias.detach().float() if self.conv_fn.bias is not None else None
+            scale = None
+            if isinstance(norm, nn.modules.batchnorm._BatchNorm):
+                scale = (norm.weight.detach() if norm.affine else 1.0) / torch.sqrt(norm.running_var + norm.eps)
+                shift = (norm.bias.detach() if norm.affine else 0.0) - norm.running_mean * scale
+                if bias is not None:
+                    shift = shift + bias * scale
+                scale, bias = scale.float().contiguous(), shift.float().contiguous()
+            self._epi_cache = cache = (key, (scale, bias.contiguous() if bias is not None else None, kind))
+        return cache[1]
+
     def forward(self, x):
-        return self.relu_fn(self.norm_fn(self.conv_fn(x)))
+        epi = self._epilogue() if x.is_cuda else None
+        if epi is None:
+            return self.relu_fn(self.norm_fn(self.conv_fn(x)))
+        # convolution without its bias (MIOpen / hipBLASLt), then bias + BatchNorm + activation in ONE in-place kernel
+        from .restormer_ops import channel_affine_act_
+        c = self.conv_fn
+        conv = torch.nn.functional.conv1d if self.dims == 1 else torch.nn.functional.conv2d
+        y = conv(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        scale, shift, kind = epi
+        if scale is None and shift is None and kind is None:
+            return y
+        return channel_affine_act_(y.contiguous(), scale, shift, kind, 0.1)
 
 
 class Conv1dNormRelu(_ConvNormRelu):

@@ -52,3 +52,20 @@ def test_channel_layernorm(shape):
     torch.testing.assert_close(channel_layernorm(x.to(DEV), w.to(DEV), b.to(DEV)).cpu(), ref, rtol=1e-5, atol=2e-5)
     ref = x / torch.sqrt(var + 1e-5) * w.view(view)  # BiasFree, :43-44 (C = 1: var = 0, outputs ~1e3)
     torch.testing.assert_close(channel_layernorm(x.to(DEV), w.to(DEV), None).cpu(), ref, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("dims,norm,act", [(2, "batch_norm", "leaky_relu"), (1, None, "relu"), (2, None, None), (1, "batch_norm", None)])
+def test_conv_norm_relu_fused_epilogue(dims, norm, act):
+    """Conv{1,2}dNormRelu on the GPU (bias + eval BatchNorm + activation fused) against the same module on the CPU."""
+    from rpeflow_amd.utils import Conv1dNormRelu, Conv2dNormRelu
+    torch.manual_seed(dims)
+    cls = Conv2dNormRelu if dims == 2 else Conv1dNormRelu
+    m = cls(13, 22, kernel_size=3 if dims == 2 else 1, padding=1 if dims == 2 else 0, norm=norm, activation=act).eval()
+    if norm:
+        m.norm_fn.running_mean.normal_(); m.norm_fn.running_var.uniform_(0.5, 2.0)
+        m.norm_fn.weight.data.uniform_(0.5, 1.5); m.norm_fn.bias.data.normal_()
+    x = torch.randn(2, 13, 9, 14) if dims == 2 else torch.randn(2, 13, 37)
+    with torch.no_grad():
+        ref = m(x)
+        got = m.to(DEV)(x.to(DEV)).cpu()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
