@@ -283,16 +283,18 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
         off[t] = o;
     }
 
-    auto issue_piece = [&](int chunk, int t) {  // t is a compile-time constant at every call site
-        float *slot = lds + (chunk % NSLOT) * G::SLOT;
+    auto issue_piece = [&](int chunk, int slot_index, int t) {  // t is a compile-time constant at every call site
+        float *slot = lds + slot_index * G::SLOT;
         const int64_t cbase = (int64_t)chunk * CK * HW;
         const int q = wave + NW * t;
-        const float *src = off[t] >= 0 ? (q >= G::PIECES1 ? g2 : g1) + cbase + off[t] : zero;
+        // both addresses are formed unconditionally and selected: no branch in the chunk body
+        const float *inside = (q >= G::PIECES1 ? g2 : g1) + cbase + max(off[t], 0);
+        const float *src = off[t] >= 0 ? inside : zero;
         __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(slot + q * 256), 16, 0, 0);
     };
-    auto issue = [&](int chunk) {
+    auto issue = [&](int chunk, int slot_index) {
 #pragma unroll
-        for (int t = 0; t < G::PPW; ++t) issue_piece(chunk, t);
+        for (int t = 0; t < G::PPW; ++t) issue_piece(chunk, slot_index, t);
     };
 
     f32x4 acc[RY][ND][3];
@@ -308,25 +310,22 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
     static_assert(AHEAD >= 1 && AHEAD <= 6, "ring depth supported by the wait table below");
     static_assert((AHEAD - 1) * G::PPW <= 63, "vmcnt is a 6-bit counter");
 #pragma unroll
-    for (int p = 0; p < AHEAD; ++p)
-        if (p < nchunks) issue(p);
+    for (int p = 0; p < AHEAD; ++p) issue(min(p, nchunks - 1), p);
     for (int ch = 0; ch < nchunks; ++ch) {
-        // chunk ch has landed once at most the DMAs of the younger chunks of THIS wave are pending
-        const int younger = min(nchunks - 1 - ch, AHEAD - 1);
-        switch (younger) {  // wave-uniform
-            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * G::PPW) : "memory"); break;
-            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::PPW) : "memory"); break;
-            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * G::PPW) : "memory"); break;
-            case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * G::PPW) : "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * G::PPW) : "memory"); break;
-        }
+        // Chunk ch has landed once at most the DMAs of the AHEAD-1 younger chunks of THIS wave are pending.  Every
+        // iteration issues exactly PPW DMAs -- past the end they re-fetch the last chunk into a slot nobody reads
+        // any more -- so the count is a constant and the chunk body has no branch (which lets hipcc count its
+        // lgkmcnt waits instead of draining the LDS queue at every basic-block boundary).
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * G::PPW) : "memory");
         __builtin_amdgcn_s_barrier();  // ... for every wave; and everyone is done reading chunk ch-1
-        const bool more = ch + AHEAD < nchunks;  // wave-uniform
-        if (!(PD > 0 && SPREAD) && more) issue(ch + AHEAD);  // SPREAD: issued piece by piece among the MFMA steps below
+        const int next = min(ch + AHEAD, nchunks - 1);
+        const int next_slot = (ch + AHEAD) % NSLOT;
+        constexpr bool more = true;
+        if (!(PD > 0 && SPREAD) && more) issue(next, next_slot);  // SPREAD: issued piece by piece among the MFMA steps below
 
-        const float *l1 = lds + (ch % NSLOT) * G::SLOT + (wave * RY) * TX + lane;
-        const float *l2 = lds + (ch % NSLOT) * G::SLOT + G::OFF2 + (wave * RY) * PX2 + lane;
+        const int slot_id = ch % NSLOT;
+        const float *l1 = lds + slot_id * G::SLOT + (wave * RY) * TX + lane;
+        const float *l2 = lds + slot_id * G::SLOT + G::OFF2 + (wave * RY) * PX2 + lane;
         if constexpr (PD == 0) {
 #pragma unroll 1
             for (int c = 0; c < CK; ++c) {
@@ -353,42 +352,45 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
             constexpr int DMA_EVERY = STEPS / G::PPW;
             static_assert(DMA_EVERY >= 1, "more DMA pieces than steps");
             float br[PD + 1][3], ar[2][RY];
-            auto load_step = [&](int t) {  // compile-time t after inlining
-                const int c = t / ROWS, r = t % ROWS;
-                if (r == 0) {
+            {
+                auto load_step = [&](int t) {  // compile-time t after inlining
+                    const int c = t / ROWS, r = t % ROWS;
+                    if (r == 0) {
 #pragma unroll
-                    for (int ry = 0; ry < RY; ++ry) ar[c & 1][ry] = l1[(c * G::TY + ry) * TX];
-                }
-#pragma unroll
-                for (int s = 0; s < 3; ++s) br[t % (PD + 1)][s] = l2[(c * G::TY2 + r) * PX2 + 4 * s];
-            };
-#pragma unroll
-            for (int t = 0; t < PD; ++t) load_step(t);
-            static_for<STEPS>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                constexpr int c = t / ROWS, r = t % ROWS;
-                if constexpr (SPREAD && t % DMA_EVERY == DMA_EVERY / 2 && t / DMA_EVERY < G::PPW) {
-                    if (more) issue_piece(ch + AHEAD, t / DMA_EVERY);
-                }
-                if constexpr (t + PD < STEPS) load_step(t + PD);
-#pragma unroll
-                for (int s = 0; s < 3; ++s)
-#pragma unroll
-                    for (int ry = 0; ry < RY; ++ry) {
-                        const int dy = r - ry;
-                        if (dy >= 0 && dy < ND)
-                            acc[ry][dy][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[c & 1][ry], br[t % (PD + 1)][s], acc[ry][dy][s], 0, 0, 0);
+                        for (int ry = 0; ry < RY; ++ry) ar[c & 1][ry] = l1[(c * G::TY + ry) * TX];
                     }
-                constexpr int n_valid = (r < RY ? r + 1 : (r >= ND ? ROWS - r : RY));  // in1 rows this in2 row pairs with
-                if constexpr (t + PD < STEPS)
-                    __builtin_amdgcn_sched_group_barrier(0x100, ((t + PD) % ROWS == 0) ? 3 + RY : 3, 0);  // DS reads
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * n_valid, 0);                             // MFMAs
-            });
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) br[t % (PD + 1)][s] = l2[(c * G::TY2 + r) * PX2 + 4 * s];
+                };
+#pragma unroll
+                for (int t = 0; t < PD; ++t) load_step(t);
+                static_for<STEPS>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    constexpr int c = t / ROWS, r = t % ROWS;
+                    if constexpr (SPREAD && t % DMA_EVERY == DMA_EVERY / 2 && t / DMA_EVERY < G::PPW) {
+                        if (more) issue_piece(next, next_slot, t / DMA_EVERY);
+                    }
+                    if constexpr (t + PD < STEPS) load_step(t + PD);
+#pragma unroll
+                    for (int s = 0; s < 3; ++s)
+#pragma unroll
+                        for (int ry = 0; ry < RY; ++ry) {
+                            const int dy = r - ry;
+                            if (dy >= 0 && dy < ND)
+                                acc[ry][dy][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[c & 1][ry], br[t % (PD + 1)][s], acc[ry][dy][s], 0, 0, 0);
+                        }
+                    constexpr int n_valid = (r < RY ? r + 1 : (r >= ND ? ROWS - r : RY));  // in1 rows this in2 row pairs with
+                    if constexpr (t + PD < STEPS)
+                        __builtin_amdgcn_sched_group_barrier(0x100, ((t + PD) % ROWS == 0) ? 3 + RY : 3, 0);  // DS reads
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * n_valid, 0);                             // MFMAs
+                });
+            }
         }
     }
 
     // ---- epilogue: per wave and (row, dy), a [9 dx][64 px] staging tile in LDS, then coalesced stores
-    __builtin_amdgcn_s_barrier();  // all waves left the ring (no DMA pending: vmcnt(0) above)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (unused) DMAs have landed
+    __builtin_amdgcn_s_barrier();                     // ... in every wave, and all waves left the ring
     float *stage = lds + wave * (2 * ND * TX);  // two tiles per wave, used alternately
     const int g = lane >> 2, j = lane & 3;
     const float fc = (float)C;
