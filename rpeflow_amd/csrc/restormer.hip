@@ -66,6 +66,74 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(Segments seg, const float 
     out[((int64_t)b * Cout + c) * HW + p] = v;
 }
 
+// Strip form for W % 4 == 0: one thread produces a 4-wide x R-high patch of one channel plane.  Every input row is
+// fetched once as a float4 plus its two halo scalars and feeds up to KH output rows from registers, so a patch costs
+// (R + KH - 1) * 3 load instructions for 4R outputs instead of 9 per output.
+template <int KH, int R>
+__device__ __forceinline__ void dw_strip(const float *__restrict__ in, const float *__restrict__ w, int y0, int x, int H, int W,
+                                         float (&acc)[R][4]) {
+    float wv[KH * 3];
+#pragma unroll
+    for (int i = 0; i < KH * 3; ++i) wv[i] = w[i];
+#pragma unroll
+    for (int o = 0; o < R; ++o)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[o][i] = 0.f;
+#pragma unroll
+    for (int r = -(KH / 2); r < R + KH / 2; ++r) {
+        const int yy = y0 + r;
+        if (yy < 0 || yy >= H) continue;
+        const float *row = in + (int64_t)yy * W + x;
+        const float4 m = *reinterpret_cast<const float4 *>(row);
+        const float v[6] = {x > 0 ? row[-1] : 0.f, m.x, m.y, m.z, m.w, x + 4 < W ? row[4] : 0.f};
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const int o = r - ky + KH / 2;  // output row fed by this input row through tap ky
+            if (o < 0 || o >= R) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[o][i] = __fmaf_rn(wv[ky * 3 + kx], v[i + kx], acc[o][i]);
+        }
+    }
+}
+
+template <int KH, bool GATE>
+__global__ __launch_bounds__(256) void dwconv3_strip_kernel(Segments seg, const float *__restrict__ weight,
+                                                            const float *__restrict__ bias, int C, int H, int W,
+                                                            float *__restrict__ out) {
+    constexpr int R = KH == 3 ? 4 : 1;
+    const int W4 = W >> 2, HR = (H + R - 1) / R;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W4 * HR) return;
+    const int yb = t / W4, x = (t - yb * W4) * 4, y0 = yb * R;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int64_t HW = (int64_t)H * W;
+    const int Cout = GATE ? C / 2 : C;
+    float acc[R][4];
+    dw_strip<KH, R>(plane(seg, b, c, HW), weight + (int64_t)c * KH * 3, y0, x, H, W, acc);
+    const float b0 = bias ? bias[c] : 0.f;
+    if (GATE) {
+        const int c2 = c + Cout;
+        float gat[R][4];
+        dw_strip<KH, R>(plane(seg, b, c2, HW), weight + (int64_t)c2 * KH * 3, y0, x, H, W, gat);
+        const float b1 = bias ? bias[c2] : 0.f;
+#pragma unroll
+        for (int o = 0; o < R; ++o)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[o][i] = gelu_erf(acc[o][i] + b0) * (gat[o][i] + b1);
+    } else {
+#pragma unroll
+        for (int o = 0; o < R; ++o)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[o][i] += b0;
+    }
+    float *op = out + ((int64_t)b * Cout + c) * HW + (int64_t)y0 * W + x;
+#pragma unroll
+    for (int o = 0; o < R; ++o)
+        if (y0 + o < H) *reinterpret_cast<float4 *>(op + (int64_t)o * W) = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+}
+
 // 64 positions x 4 channel groups per workgroup: thread (pl, cg) keeps channels cg, cg+4, ... of its position in
 // registers (x is read once), the two reductions over the four groups (mean, then sum of squared deviations:
 // the exact two-pass variance) go through LDS.
@@ -146,6 +214,19 @@ RPE_API int rpe_dwconv3(const float *in0, int C0, const float *in1, int C1, cons
     const int64_t HW = (int64_t)H * W;
     dim3 grid((unsigned)((HW + 255) / 256), gate ? C / 2 : C, B), block(256);
     hipStream_t st = (hipStream_t)stream;
+    auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (W % 4 == 0 && aligned(in0) && aligned(in1) && aligned(in2) && aligned(out)) {  // planes stay 16-byte aligned: HW % 4 == 0
+        const int64_t strips = (int64_t)(W / 4) * (kh == 3 ? (H + 3) / 4 : 1);
+        grid.x = (unsigned)((strips + 255) / 256);
+        if (kh == 3) {
+            if (gate) hipLaunchKernelGGL((dwconv3_strip_kernel<3, true>), grid, block, 0, st, seg, weight, bias, C, H, W, out);
+            else hipLaunchKernelGGL((dwconv3_strip_kernel<3, false>), grid, block, 0, st, seg, weight, bias, C, H, W, out);
+        } else {
+            if (gate) hipLaunchKernelGGL((dwconv3_strip_kernel<1, true>), grid, block, 0, st, seg, weight, bias, C, H, W, out);
+            else hipLaunchKernelGGL((dwconv3_strip_kernel<1, false>), grid, block, 0, st, seg, weight, bias, C, H, W, out);
+        }
+        return rpe_launch_status();
+    }
     if (kh == 3) {
         if (gate) hipLaunchKernelGGL((dwconv3_kernel<3, true>), grid, block, 0, st, seg, weight, bias, C, H, W, out);
         else hipLaunchKernelGGL((dwconv3_kernel<3, false>), grid, block, 0, st, seg, weight, bias, C, H, W, out);

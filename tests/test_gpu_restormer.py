@@ -11,7 +11,7 @@ from rpeflow_amd.restormer_ops import channel_layernorm, dwconv3  # noqa: E402
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 9, 7, 11), (1, 96, 36, 60), (3, 5, 1, 1), (2, 30, 2, 130)])
+@pytest.mark.parametrize("B,C,H,W", [(2, 9, 7, 11), (1, 96, 36, 60), (3, 5, 1, 1), (2, 30, 2, 130), (2, 6, 7, 12), (1, 3, 1, 4), (2, 4, 9, 8)])
 def test_dwconv_2d(B, C, H, W):
     torch.manual_seed(C)
     x, y = torch.randn(B, C, H, W), torch.randn(B, C, H, W)
@@ -28,7 +28,7 @@ def test_dwconv_2d(B, C, H, W):
     assert (got - F.gelu(a) * g).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("B,C,N", [(2, 7, 33), (1, 64, 4096), (2, 3, 1)])
+@pytest.mark.parametrize("B,C,N", [(2, 7, 33), (1, 64, 4096), (2, 3, 1), (2, 5, 4), (1, 3, 36)])
 def test_dwconv_1d(B, C, N):
     torch.manual_seed(N)
     x, y = torch.randn(B, C, N), torch.randn(B, C, N)

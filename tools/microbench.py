@@ -57,6 +57,25 @@ def main():
                 us = timeit(lambda: ops.furthest_point_sampling(p, S), warmup=1, iters=3)
                 print(f"fps variant={variant} B={B} N={N} S={S}: {us:9.1f} us  {us / S:6.3f} us/sample")
             _lib.lib().rpe_debug_set_fps_variant(1)
+    if "restormer" in which:
+        from rpeflow_amd.restormer_ops import channel_layernorm, dwconv3
+        for (B, C, H, Wd) in [(4, 96, 144, 240), (4, 81, 144, 240), (4, 32, 144, 240), (4, 96, 72, 120), (4, 64, 1, 4096)]:
+            shape = (B, C, H, Wd) if H > 1 else (B, C, Wd)
+            x, y = torch.randn(*shape, device=dev), torch.randn(*shape, device=dev)
+            k = (3, 3) if H > 1 else (3,)
+            wq = torch.randn(3 * C, 1, *k, device=dev)
+            hid = int(C * 2.66)
+            h = torch.randn(shape[0], 2 * hid, *shape[2:], device=dev)
+            wg = torch.randn(2 * hid, 1, *k, device=dev)
+            us = timeit(lambda: dwconv3([x, y, y], wq))
+            byt = x.numel() * 4 * 6
+            print(f"dwconv qkv  {shape}: {us:8.1f} us  {byt / us / 1e6:6.2f} TB/s")
+            us = timeit(lambda: dwconv3([h], wg, gate=True))
+            byt = h.numel() * 4 * 1.5
+            print(f"dwconv gate {tuple(h.shape)}: {us:8.1f} us  {byt / us / 1e6:6.2f} TB/s")
+            g, bb = torch.rand(C, device=dev), torch.rand(C, device=dev)
+            us = timeit(lambda: channel_layernorm(x, g, bb))
+            print(f"layernorm   {shape}: {us:8.1f} us  {x.numel() * 8 / us / 1e6:6.2f} TB/s")
 
 
 if __name__ == "__main__":

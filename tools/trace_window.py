@@ -21,3 +21,14 @@ span = int(rows[hi]["Start_Timestamp"]) - int(rows[lo]["End_Timestamp"])
 print(f"window: {len(win)} kernels, kernel time {tot / 1e6 / steps:.3f} ms/step, wall {span / 1e6 / steps:.3f} ms/step, {len(win) / steps:.0f} launches/step")
 for name, (d, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
     print(f"{d / 1e6 / steps:8.3f} ms/step {n / steps:7.1f}/step {d / n / 1e3:9.1f} us  {name[:120]}")
+
+if len(sys.argv) > 3:  # per-launch dump of the last step in the window: start offset, duration, queue, grid, name
+    per = len(win) // steps
+    last = win[-per:]
+    t0 = int(last[0]["Start_Timestamp"])
+    with open(sys.argv[3], "w") as f:
+        f.write("start_us,dur_us,queue,grid,wg,name\n")
+        for r in last:
+            f.write("%.1f,%.1f,%s,%s,%s,%s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3,
+                                              r.get("Queue_Id", ""), r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")),
+                                              r["Kernel_Name"][:100].replace(",", ";")))
