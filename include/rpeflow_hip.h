@@ -178,6 +178,17 @@ int rpe_dwconv3(const float *in0, int C0, const float *in1, int C1, const float 
                 float *out, rpe_stream_t stream);
 int rpe_channel_layernorm(const float *x, const float *weight, const float *bias, int B, int C, int64_t P,
                           float eps, float *out, rpe_stream_t stream);
+/* rpe_channel_attention_matrix: the attention core of Mutual_Attention{2D,3D}.forward (restormer_arch.py:184-203,
+ *   265-282) up to and including project_out, as a per-batch C x C matrix (C = heads * c):
+ *     attn_h = softmax_j( normalize(q_h) normalize(k_h)^T * temperature[h] ),  F.normalize over the P positions (eps),
+ *     m_out[b] = w_out blockdiag_h(attn_h)                                      w_out [C,C] = project_out.weight
+ *   so that project_out(attn v) = m_out[b] v[b] -- the caller finishes with one batched GEMM (+ residual).
+ *   q, k: [B][C][P] fp32 with row stride P and the given batch stride in floats (views into the qkv tensor).
+ *   c <= 96.  workspace: rpe_channel_attention_workspace_floats(B, heads, c, P) floats.                         */
+int64_t rpe_channel_attention_workspace_floats(int B, int heads, int c, int64_t P);
+int rpe_channel_attention_matrix(const float *q, const float *k, int64_t batch_stride, const float *temperature,
+                                 const float *w_out, int B, int heads, int c, int64_t P, float eps,
+                                 float *workspace, float *m_out, rpe_stream_t stream);
 /* rpe_channel_affine_act: y[b][c][p] = act(scale[c]*y[b][c][p] + shift[c]) IN PLACE over [B,C,P] -- the bias add,
  *   eval-mode BatchNorm and activation after a Conv{1,2}dNormRelu convolution (models/utils.py:7-62) in one pass.
  *   scale / shift may be NULL (1 / 0).  act: 0 none, 1 relu, 2 leaky_relu(slope).                              */

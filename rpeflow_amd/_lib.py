@@ -31,6 +31,9 @@ _PROTOTYPES = {
     "rpe_dwconv3": [_c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                     _c_ptr, _c_ptr],
     "rpe_channel_layernorm": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_float, _c_ptr, _c_ptr],
+    "rpe_channel_attention_matrix": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_i64, _c_float,
+                                     _c_ptr, _c_ptr, _c_ptr],
+    "rpe_channel_attention_workspace_floats": [_c_int, _c_int, _c_int, _c_i64],
     "rpe_channel_affine_act": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_int, _c_float, _c_ptr],
     "rpe_corr3d_hidden": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                           _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
@@ -69,6 +72,7 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = _c_int
+        handle.rpe_channel_attention_workspace_floats.restype = _c_i64
         handle.rpe_error_string.argtypes = [_c_int]
         handle.rpe_error_string.restype = ctypes.c_char_p
         if handle.rpe_abi_version() != 1:

@@ -1,0 +1,237 @@
+// Channel ("transposed") attention core of the Restormer cross blocks: Mutual_Attention{2D,3D}.forward,
+// models/restormer_arch.py:169-204 and 251-283.
+//
+// Reference chain per block:  q,k = F.normalize(q,k over the P positions);  attn = softmax(q k^T * temperature);
+// out = project_out(attn v);  ~12 PyTorch kernels over [B,C,P] tensors.  Here:
+//
+//   attn_gram_kernel     G[b][h] = q_h k_h^T (c x c, contraction over P) and the squared row norms of q and k, in one
+//                        pass over q and k on v_mfma_f32_16x16x4_f32.  Normalising afterwards,
+//                        G_ij / (max(|q_i|,eps) max(|k_j|,eps)), equals the reference's normalise-then-multiply up to
+//                        fp32 rounding.  Positions are split over workgroups; partial sums are written per workgroup
+//                        and added in a fixed order by the next kernel (deterministic, no atomics).
+//   attn_softmax_kernel  sums the partials, scales by the norms and the temperature, softmax over j (one wave per row).
+//   attn_project_kernel  folds the 1x1 project_out convolution in: M[b] = W_o blockdiag_h(attn_h)  (C x C), so that the
+//                        caller finishes the block with ONE batched GEMM  out = residual + M[b] v[b].
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kChunk = 2048;  // positions per workgroup (4 waves x 16-position groups, interleaved)
+
+__host__ __device__ inline int attn_chunks(int64_t P) { return (int)((P + kChunk - 1) / kChunk); }
+
+template <bool VEC>
+__device__ __forceinline__ float4 load_row4(const float *__restrict__ base, int row, int c, int64_t P, int64_t p, int64_t pend) {
+    // 4 consecutive positions p..p+3 of channel `row`; zero outside the head's channels / the chunk
+    if (row >= c || p >= pend) return make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *src = base + (int64_t)row * P + p;
+    if (VEC) return *reinterpret_cast<const float4 *>(src);  // P % 4 == 0, 16-byte aligned planes: p + 3 < pend
+    float4 v;
+    v.x = src[0];
+    v.y = p + 1 < pend ? src[1] : 0.f;
+    v.z = p + 2 < pend ? src[2] : 0.f;
+    v.w = p + 3 < pend ? src[3] : 0.f;
+    return v;
+}
+
+// grid (chunks * T, heads, B), 256 threads; T = ceil(c / 16).  Workgroup (s, ti) owns rows 16 ti .. 16 ti + 15 of the
+// gram for positions [s * kChunk, (s + 1) * kChunk): one q tile row against all T k tiles (k is re-read T times, from L2).
+template <int T, bool VEC>
+__global__ __launch_bounds__(256) void attn_gram_kernel(const float *__restrict__ q, const float *__restrict__ k, int64_t batch_stride,
+                                                        int heads, int c, int64_t P, float *__restrict__ gpart,
+                                                        float *__restrict__ npart) {
+    __shared__ float tiles[T * 256];  // [T][64][4] accumulator tiles
+    __shared__ float norms[(T + 1) * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int s = blockIdx.x / T, ti = blockIdx.x - s * T, h = blockIdx.y, b = blockIdx.z, S = gridDim.x / T;
+    const int row = lane & 15, grp = lane >> 4;
+    const float *qh = q + (int64_t)b * batch_stride + (int64_t)h * c * P;
+    const float *kh = k + (int64_t)b * batch_stride + (int64_t)h * c * P;
+    const int64_t p0 = (int64_t)s * kChunk;
+    const int64_t pend = p0 + kChunk < P ? p0 + kChunk : P;
+    const bool k_norms = ti == 0;  // the k norms are the same in every tile row: the first one writes them
+
+    f32x4 acc[T];
+    float sq = 0.f, sk[T];
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        sk[j] = 0.f;
+        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t gs = p0 + wave * 16; gs < pend; gs += 64) {  // wave-uniform trip count: every lane joins the MFMAs
+        const int64_t p = gs + grp * 4;
+        const float4 a = load_row4<VEC>(qh, ti * 16 + row, c, P, p, pend);
+        float4 bb[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) bb[t] = load_row4<VEC>(kh, t * 16 + row, c, P, p, pend);
+        sq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+        if (k_norms) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) sk[t] += (bb[t].x * bb[t].x + bb[t].y * bb[t].y) + (bb[t].z * bb[t].z + bb[t].w * bb[t].w);
+        }
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb[j].x, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb[j].y, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb[j].z, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb[j].w, acc[j], 0, 0, 0);
+        }
+    }
+    // norms: add the four position groups of the wave (lanes l, l^16, l^32, l^48 share a row)
+    sq += __shfl_xor(sq, 16);
+    sq += __shfl_xor(sq, 32);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        sk[t] += __shfl_xor(sk[t], 16);
+        sk[t] += __shfl_xor(sk[t], 32);
+    }
+    for (int w = 0; w < 4; ++w) {  // waves add into LDS one after the other (fixed order)
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                f32x4 *slot = reinterpret_cast<f32x4 *>(tiles + (j * 64 + lane) * 4);
+                *slot = w == 0 ? acc[j] : *slot + acc[j];
+            }
+            if (grp == 0) {
+                norms[row] = w == 0 ? sq : norms[row] + sq;
+#pragma unroll
+                for (int t = 0; t < T; ++t) norms[(1 + t) * 16 + row] = w == 0 ? sk[t] : norms[(1 + t) * 16 + row] + sk[t];
+            }
+        }
+        __syncthreads();
+    }
+    // partial gram [b][h][s][c][c]; tile element (j-tile, lane, reg): row 16 ti + 4 (lane >> 4) + reg, col 16 jt + (lane & 15)
+    float *gp = gpart + (((int64_t)b * heads + h) * S + s) * c * c;
+    const int rows = min(16, c - ti * 16);
+    for (int o = threadIdx.x; o < rows * c; o += 256) {
+        const int ir = o / c, j = o - ir * c, jt = j >> 4, jc = j & 15;
+        gp[(ti * 16 + ir) * c + j] = tiles[(jt * 64 + ((ir >> 2) << 4) + jc) * 4 + (ir & 3)];
+    }
+    // partial squared norms [b][s][2][heads*c]
+    float *np = npart + ((int64_t)b * S + s) * 2 * heads * c + h * c;
+    if (threadIdx.x < rows) np[ti * 16 + threadIdx.x] = norms[threadIdx.x];
+    if (k_norms)
+        for (int i = threadIdx.x; i < c; i += 256) np[heads * c + i] = norms[16 + i];
+}
+
+// One wave per attention row (b, h, i): sums the partials in a fixed order, scales by the norms and the temperature,
+// softmax over j.  grid (ceil(B*C / 4)), 256 threads; attn_out [B][C][c].
+__global__ __launch_bounds__(256) void attn_softmax_kernel(const float *__restrict__ gpart, const float *__restrict__ npart, int S,
+                                                           const float *__restrict__ temperature, int B, int heads, int c, float eps,
+                                                           float *__restrict__ attn_out) {
+    const int lane = threadIdx.x & 63, C = heads * c;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * C) return;
+    const int b = r / C, hi = r - b * C, h = hi / c, i = hi - h * c;
+    const float *gp = gpart + ((int64_t)b * heads + h) * S * c * c + i * c;
+    const float *np = npart + (int64_t)b * S * 2 * C;
+    float nq = 0.f;
+    for (int t = 0; t < S; ++t) nq += np[(int64_t)t * 2 * C + hi];
+    nq = fmaxf(sqrtf(nq), eps);
+    const float temp = temperature[h];
+    float v[2];  // c <= 96 < 128: columns lane and lane + 64
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = lane + 64 * u;
+        v[u] = -INFINITY;
+        if (j < c) {
+            float g = 0.f, nk = 0.f;
+            for (int t = 0; t < S; ++t) {
+                g += gp[(int64_t)t * c * c + j];
+                nk += np[(int64_t)t * 2 * C + C + h * c + j];
+            }
+            v[u] = g / (nq * fmaxf(sqrtf(nk), eps)) * temp;
+        }
+        mx = fmaxf(mx, v[u]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        v[u] = lane + 64 * u < c ? expf(v[u] - mx) : 0.f;
+        sum += v[u];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (lane + 64 * u < c) attn_out[(int64_t)r * c + lane + 64 * u] = v[u] * inv;
+}
+
+// M[b][o][h*c + j] = sum_i W_o[o][h*c + i] * attn[b][h][i][j].  grid (B, slices of M's elements), 256 threads;
+// dynamic LDS: attn[b] (C*c floats).
+__global__ __launch_bounds__(256) void attn_project_kernel(const float *__restrict__ attn_in, const float *__restrict__ w_out, int heads,
+                                                           int c, float *__restrict__ m_out) {
+    extern __shared__ float attn[];
+    const int C = heads * c, b = blockIdx.x;
+    for (int o = threadIdx.x; o < C * c; o += 256) attn[o] = attn_in[(int64_t)b * C * c + o];
+    __syncthreads();
+    float *mb = m_out + (int64_t)b * C * C;
+    const int per = (C * C + gridDim.y - 1) / gridDim.y;
+    const int e_end = min(C * C, (int)(blockIdx.y + 1) * per);
+    for (int e = blockIdx.y * per + threadIdx.x; e < e_end; e += 256) {
+        const int o = e / C, col = e - o * C, h = col / c, j = col - h * c;
+        const float *w = w_out + (int64_t)o * C + h * c;
+        const float *a = attn + (h * c) * c + j;
+        float s0 = 0.f, s1 = 0.f;
+        int i = 0;
+        for (; i + 1 < c; i += 2) {
+            s0 = __fmaf_rn(w[i], a[i * c], s0);
+            s1 = __fmaf_rn(w[i + 1], a[(i + 1) * c], s1);
+        }
+        if (i < c) s0 = __fmaf_rn(w[i], a[i * c], s0);
+        mb[e] = s0 + s1;
+    }
+}
+
+template <int T>
+int launch_gram(bool vec, dim3 grid, hipStream_t st, const float *q, const float *k, int64_t batch_stride, int heads, int c, int64_t P,
+                float *gpart, float *npart) {
+    grid.x *= T;
+    if (vec) hipLaunchKernelGGL((attn_gram_kernel<T, true>), grid, dim3(256), 0, st, q, k, batch_stride, heads, c, P, gpart, npart);
+    else hipLaunchKernelGGL((attn_gram_kernel<T, false>), grid, dim3(256), 0, st, q, k, batch_stride, heads, c, P, gpart, npart);
+    return rpe_launch_status();
+}
+
+}  // namespace
+
+RPE_API int64_t rpe_channel_attention_workspace_floats(int B, int heads, int c, int64_t P) {
+    if (B < 0 || heads < 1 || c < 1 || P < 0) return -1;
+    return (int64_t)B * attn_chunks(P > 0 ? P : 1) * ((int64_t)heads * c * c + 2 * (int64_t)heads * c) + (int64_t)B * heads * c * c;
+}
+
+RPE_API int rpe_channel_attention_matrix(const float *q, const float *k, int64_t batch_stride, const float *temperature,
+                                         const float *w_out, int B, int heads, int c, int64_t P, float eps, float *workspace,
+                                         float *m_out, rpe_stream_t stream) {
+    if (!q || !k || !temperature || !w_out || !workspace || !m_out || B < 0 || heads < 1 || c < 1 || P < 1) return RPE_EINVAL;
+    if (B == 0) return 0;
+    if (c > 96 || heads > 65535 || B > 65535) return RPE_EUNSUPPORTED;
+    const int C = heads * c, S = attn_chunks(P);
+    if ((size_t)C * c * sizeof(float) > 64 * 1024) return RPE_EUNSUPPORTED;  // attn[b] staged in LDS by attn_project_kernel
+    float *gpart = workspace, *npart = workspace + (int64_t)B * heads * S * c * c;
+    const bool vec = P % 4 == 0 && batch_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(S, heads, B);
+    const int T = (c + 15) / 16;
+    int rc;
+    switch (T) {
+        case 1: rc = launch_gram<1>(vec, grid, st, q, k, batch_stride, heads, c, P, gpart, npart); break;
+        case 2: rc = launch_gram<2>(vec, grid, st, q, k, batch_stride, heads, c, P, gpart, npart); break;
+        case 3: rc = launch_gram<3>(vec, grid, st, q, k, batch_stride, heads, c, P, gpart, npart); break;
+        case 4: rc = launch_gram<4>(vec, grid, st, q, k, batch_stride, heads, c, P, gpart, npart); break;
+        case 5: rc = launch_gram<5>(vec, grid, st, q, k, batch_stride, heads, c, P, gpart, npart); break;
+        default: rc = launch_gram<6>(vec, grid, st, q, k, batch_stride, heads, c, P, gpart, npart); break;
+    }
+    if (rc) return rc;
+    float *attn = npart + (int64_t)B * S * 2 * C;
+    hipLaunchKernelGGL(attn_softmax_kernel, dim3((B * C + 3) / 4), dim3(256), 0, st, gpart, npart, S, temperature, B, heads, c, eps, attn);
+    hipLaunchKernelGGL(attn_project_kernel, dim3(B, C >= 64 ? 16 : 4), dim3(256), (size_t)C * c * sizeof(float), st, attn, w_out, heads, c, m_out);
+    return rpe_launch_status();
+}

@@ -81,13 +81,28 @@ class _MutualAttention(nn.Module):
         self.qkv_dwconv = conv(dim * 3, dim * 3, kernel_size=3, stride=1, padding=1, groups=dim * 3, bias=bias)
         self.project_out = conv(dim, dim, kernel_size=1, bias=bias)
 
-    def forward(self, x, y):
+    def forward(self, x, y, residual=None):
+        """Returns project_out(attention) (+ residual when given)."""
         shape = x.shape
-        if x.is_cuda:  # depth-wise conv reading x | y | y in place of the concatenation
-            from .restormer_ops import dwconv3
+        if x.is_cuda and shape[1] // self.num_heads <= 96:
+            # depth-wise conv reading x | y | y in place of the concatenation; gram + softmax + project_out folded into
+            # one C x C matrix per sample (csrc/attention.hip); one batched GEMM applies it to v and adds the residual
+            from .restormer_ops import channel_attention_matrix, dwconv3
             qkv = dwconv3([x, y, y], self.qkv_dwconv.weight, self.qkv_dwconv.bias)
-        else:
-            qkv = self.qkv_dwconv(torch.cat((x, y, y), dim=1))
+            m = channel_attention_matrix(qkv, self.num_heads, self.temperature, self.project_out.weight)
+            v = qkv.reshape(shape[0], 3 * shape[1], -1)[:, 2 * shape[1]:]
+            if self.project_out.bias is not None:
+                bias = self.project_out.bias.view(1, -1, 1)
+                residual = bias if residual is None else residual.reshape(shape[0], shape[1], -1) + bias
+            if residual is None:
+                return torch.bmm(m, v).reshape(shape)
+            return torch.baddbmm(residual.reshape(shape[0], shape[1], -1), m, v).reshape(shape)
+        out = self._forward_plain(x, y)
+        return out if residual is None else residual + out
+
+    def _forward_plain(self, x, y):
+        shape = x.shape
+        qkv = self.qkv_dwconv(torch.cat((x, y, y), dim=1))
         q, k, v = qkv.chunk(3, dim=1)
         heads = lambda t: t.reshape(shape[0], self.num_heads, shape[1] // self.num_heads, -1)
         q, k, v = F.normalize(heads(q), dim=-1), F.normalize(heads(k), dim=-1), heads(v)
@@ -127,7 +142,7 @@ class _CrossTransformerBlock(nn.Module):
 
     def forward(self, x, y):
         assert x.shape == y.shape
-        x = x + self.attn(self.norm1x(x), self.norm1y(y))
+        x = self.attn(self.norm1x(x), self.norm1y(y), residual=x)
         return x + self.ffn(self.norm2(x))
 
 

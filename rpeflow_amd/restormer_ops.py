@@ -1,5 +1,6 @@
 """Host side of the Restormer-block kernels (csrc/restormer.hip): depth-wise 3x3 / 3-tap convolution with
-fused channel concatenation and GDFN gate, and channel LayerNorm.  GPU tensors only."""
+fused channel concatenation and GDFN gate, channel LayerNorm, and the channel-attention core (csrc/attention.hip).
+GPU tensors only."""
 import ctypes
 
 import torch
@@ -63,3 +64,25 @@ def channel_affine_act_(y, scale, shift, act, slope=0.1):
         rc = _lib.lib().rpe_channel_affine_act(_ptr(y), _ptr(scale), _ptr(shift), B, C, P, code, float(slope), _lib.stream_of(y))
     _lib.check(rc, "channel_affine_act")
     return y
+
+
+def channel_attention_matrix(qkv, heads, temperature, w_out, eps=1e-12):
+    """qkv [B,3C,...] contiguous (q | k | v along channels).  Returns M [B,C,C] with
+    project_out(softmax(normalize(q) normalize(k)^T * temperature) v) == M @ v  (restormer_arch.py:184-203)."""
+    _lib.require_gpu(qkv, temperature, w_out, op="channel_attention_matrix")
+    assert qkv.is_contiguous() and qkv.dtype == torch.float32 and qkv.shape[1] % (3 * heads) == 0
+    B, C = qkv.shape[0], qkv.shape[1] // 3
+    P = qkv.numel() // (B * 3 * C)
+    c = C // heads
+    t = temperature.detach().reshape(-1).contiguous().float()
+    w = w_out.detach().reshape(C, C).contiguous().float()
+    assert t.numel() == heads
+    L = _lib.lib()
+    ws = torch.empty(L.rpe_channel_attention_workspace_floats(B, heads, c, P), dtype=torch.float32, device=qkv.device)
+    m = torch.empty(B, C, C, dtype=torch.float32, device=qkv.device)
+    q_ptr = qkv.data_ptr()
+    with torch.cuda.device(qkv.device):
+        rc = L.rpe_channel_attention_matrix(ctypes.c_void_p(q_ptr), ctypes.c_void_p(q_ptr + 4 * C * P), 3 * C * P, _ptr(t), _ptr(w),
+                                            B, heads, c, P, float(eps), _ptr(ws), _ptr(m), _lib.stream_of(qkv))
+    _lib.check(rc, "channel_attention_matrix")
+    return m

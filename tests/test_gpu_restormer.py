@@ -69,3 +69,23 @@ def test_conv_norm_relu_fused_epilogue(dims, norm, act):
         ref = m(x)
         got = m.to(DEV)(x.to(DEV)).cpu()
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dims,C,heads,spatial", [(2, 81, 1, (36, 60)), (2, 81, 3, (9, 15)), (2, 96, 2, (18, 30)), (1, 32, 1, (256,)),
+                                                  (1, 192, 4, (301,)), (2, 32, 1, (144, 240)), (1, 64, 2, (4096,)), (1, 16, 1, (7,))])
+def test_mutual_attention_fused(dims, C, heads, spatial):
+    """Mutual_Attention{2D,3D} (restormer_arch.py:169-204, 251-283): gram + softmax + project_out folded into one
+    matrix per sample on the GPU, against the plain PyTorch chain on the CPU."""
+    from rpeflow_amd.model import _MutualAttention
+    torch.manual_seed(C + heads)
+    m = _MutualAttention(C, heads, False, dims).eval()
+    with torch.no_grad():
+        m.temperature.uniform_(0.5, 3.0)
+        x, y, r = (torch.randn(2, C, *spatial) for _ in range(3))
+        ref = m._forward_plain(x, y)
+        mg = m.to(DEV)
+        got = mg(x.to(DEV), y.to(DEV)).cpu()
+        got_r = mg(x.to(DEV), y.to(DEV), residual=r.to(DEV)).cpu()
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 2e-5 * max(scale, 1.0), (got - ref).abs().max().item()
+    assert (got_r - (r + ref)).abs().max().item() < 2e-5 * max(scale, 1.0)

@@ -76,6 +76,19 @@ def main():
             g, bb = torch.rand(C, device=dev), torch.rand(C, device=dev)
             us = timeit(lambda: channel_layernorm(x, g, bb))
             print(f"layernorm   {shape}: {us:8.1f} us  {x.numel() * 8 / us / 1e6:6.2f} TB/s")
+    if "attn" in which:
+        from rpeflow_amd.model import _MutualAttention
+        for (dims, C, heads, sp) in [(2, 96, 2, (144, 240)), (2, 81, 1, (144, 240)), (2, 32, 1, (144, 240)), (2, 81, 1, (72, 120)),
+                                     (1, 64, 2, (4096,)), (1, 192, 4, (256,))]:
+            m = _MutualAttention(C, heads, False, dims).to(dev).eval()
+            x, y = torch.randn(4, C, *sp, device=dev), torch.randn(4, C, *sp, device=dev)
+            with torch.no_grad():
+                us = timeit(lambda: m(x, y, residual=x))
+                us0 = timeit(lambda: x + m.project_out(m._forward_plain(x, y)) if False else x + m._forward_plain(x, y))
+                from rpeflow_amd.restormer_ops import channel_attention_matrix, dwconv3
+                qkv = dwconv3([x, y, y], m.qkv_dwconv.weight)
+                usm = timeit(lambda: channel_attention_matrix(qkv, heads, m.temperature, m.project_out.weight))
+            print(f"attention C={C} heads={heads} {sp}: fused {us:8.1f} us (matrix part {usm:7.1f})   plain torch {us0:8.1f} us")
 
 
 if __name__ == "__main__":
