@@ -236,6 +236,7 @@ def main():
         if not args.eager:
             try:  # the whole forward as ONE HIP graph: ~3000 launches and the Python between them replayed in one call
                 graph = torch.cuda.CUDAGraph()
+                eager_out = {k: v.clone() for k, v in out.items()}
                 with torch.cuda.graph(graph):
                     out = model(batch)
                 graph.replay()
@@ -244,6 +245,10 @@ def main():
             except Exception as e:  # noqa: BLE001 -- capture is an optimisation, not a requirement
                 torch.cuda.synchronize()
                 launch = "eager (graph capture failed: %s)" % type(e).__name__
+            if fwd_step == graph.replay:  # the replayed graph (two-stream branches included) must reproduce the eager forward
+                for key in ("flow_2d", "flow_3d"):
+                    err = (out[key] - eager_out[key]).abs().mean().item() / (eager_out[key].abs().mean().item() + 1e-6)
+                    assert err < 1e-3, "graph replay differs from the eager forward: relative mean |d %s| = %g" % (key, err)
         dt = timed(fwd_step)
 
     totals = timer.totals_ms()

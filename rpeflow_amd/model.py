@@ -391,6 +391,34 @@ def convex_upsample(flow, mask, scale_factor=8):
 
 
 # ------------------------------------------------------------------ the core (RPEFlow_core.py:165-432)
+class _Branches:
+    """Two-branch execution for decode(): at every pyramid level the 2-D chain (convolutions over H*W pixels) and the
+    3-D chain (small kernels over N points) only meet at the three Bi-CLFM fusers, so the 3-D chain runs on a side HIP
+    stream between those points.  Under graph capture the two chains become parallel branches of the one hipGraph.
+    Tensors crossing streams are registered with the caching allocator (record_stream)."""
+
+    def __init__(self, side_stream):
+        self.side = side_stream
+        self.main = torch.cuda.current_stream(side_stream.device) if side_stream is not None else None
+
+    def fork(self, fn, inputs=()):
+        """Run fn() on the side stream after everything queued on the main stream so far."""
+        if self.side is None:
+            return fn()
+        self.side.wait_stream(self.main)
+        for t in inputs:
+            t.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            return fn()
+
+    def join(self, outputs=()):
+        """Main stream waits for the side branch; ``outputs`` are side-allocated tensors the main stream will read."""
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+            for t in outputs:
+                t.record_stream(self.main)
+
+
 class RPEFlow_core(nn.Module):
     def __init__(self, cfgs2d, cfgs3d, cfgsattention=None, ops=None):
         super().__init__()
@@ -443,14 +471,16 @@ class RPEFlow_core(nn.Module):
     def encode_event(self, event_voxel):
         return self.efeature_pyramid_2d(event_voxel)
 
-    def decode(self, xyzs1, xyzs2, feats1_2d, feats2_2d, feats1_3d, feats2_3d, efeats_2d, camera_info):
-        """RPEFlow_core.py:302-432 without the MI loss bookkeeping."""
+    def decode(self, xyzs1, xyzs2, feats1_2d, feats2_2d, feats1_3d, feats2_3d, efeats_2d, camera_info, side_stream=None):
+        """RPEFlow_core.py:302-432 without the MI loss bookkeeping.  ``side_stream``: run the 3-D chain of every level
+        beside the 2-D chain (see _Branches); None = everything in order on the current stream."""
         flows_2d, flows_3d, flow_feats_2d, flow_feats_3d = [], [], [], []
         sensor_h, sensor_w = camera_info["sensor_h"], camera_info["sensor_w"]
         md, k = self.cfgs2d.max_displacement, self.cfgs3d.k
         o = self.ops
         correlation2d, k_nearest_neighbor = o.correlation2d, o.k_nearest_neighbor
         backwarp_2d, backwarp_3d, knn_interpolation = o.backwarp_2d, o.backwarp_3d, o.knn_interpolation
+        br = _Branches(side_stream)
         top = len(xyzs1) - 1
         for level in range(top, 0, -1):
             xyz1, feat1_2d, feat1_3d = xyzs1[level], feats1_2d[level], feats1_3d[level]
@@ -463,54 +493,76 @@ class RPEFlow_core(nn.Module):
             xy1, xy2 = project_pc2image(xyz1, camera_info), project_pc2image(xyz2, camera_info)
             xy1[:, 0] *= sx; xy1[:, 1] *= sy
             xy2[:, 0] *= sx; xy2[:, 1] *= sy
+            fuse2d, fuse3d = self.pyramid_feat_fusers_2d[level], self.pyramid_feat_fusers_3d[level]
+            zeros = lambda *s: torch.zeros(s, dtype=xy1.dtype, device=xy1.device)
+
+            # ---- stage 1: pyramid fusers, warps and cost volumes.  3-D chain on the side stream.
+            def chain_3d(feat1_2d=feat1_2d, feat2_2d=feat2_2d, feat1_3d=feat1_3d, feat2_3d=feat2_3d):
+                knn_1in1 = k_nearest_neighbor(xyz1, xyz1, k=k)
+                f1, f2 = fuse3d(xy1, feat1_2d, feat1_3d), fuse3d(xy2, feat2_2d, feat2_3d)
+                if level == top:
+                    last_flow_3d, last_flow_feat_3d, xyz2_warp = zeros(batch_size, 3, n_points), zeros(batch_size, 64, n_points), xyz2
+                else:
+                    up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], dim=1), xyz1)
+                    last_flow_3d, last_flow_feat_3d = up[:, :3, :], up[:, 3:, :]
+                    xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
+                feat_corr_3d = self.correlations_3d[level](xyz1, f1, xyz2_warp, f2, knn_1in1)
+                last_flow_3d_to_2d = torch.cat([last_flow_3d[:, 0:1] * sx, last_flow_3d[:, 1:2] * sy], dim=1)
+                return knn_1in1, f1, last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d
+
+            side_in = [xyz1, xyz2, xy1, xy2, feat1_2d, feat2_2d, feat1_3d, feat2_3d]
+            if level != top:
+                side_in += [xyzs1[level + 1], flows_3d[-1], flow_feats_3d[-1]]
+            out_3d = br.fork(chain_3d, side_in)
 
             grid = mesh_grid(batch_size, image_h, image_w, xy1.device).reshape(batch_size, 2, -1)
             nn_proj1 = k_nearest_neighbor(xy1, grid, k=1)
             nn_proj2 = k_nearest_neighbor(xy2, grid, k=1)
-            knn_1in1 = k_nearest_neighbor(xyz1, xyz1, k=k)
-
-            fuse2d, fuse3d = self.pyramid_feat_fusers_2d[level], self.pyramid_feat_fusers_3d[level]
-            feat1_2d, feat1_3d = fuse2d(xy1, feat1_2d, feat1_3d, nn_proj1), fuse3d(xy1, feat1_2d, feat1_3d)
-            feat2_2d, feat2_3d = fuse2d(xy2, feat2_2d, feat2_3d, nn_proj2), fuse3d(xy2, feat2_2d, feat2_3d)
-
+            feat1_2d_fused = fuse2d(xy1, feat1_2d, feat1_3d, nn_proj1)
+            feat2_2d_fused = fuse2d(xy2, feat2_2d, feat2_3d, nn_proj2)
             if level == top:
-                zeros = lambda *s: torch.zeros(s, dtype=xy1.dtype, device=xy1.device)
-                last_flow_2d, last_flow_3d = zeros(batch_size, 2, image_h, image_w), zeros(batch_size, 3, n_points)
-                last_flow_feat_2d, last_flow_feat_3d = zeros(batch_size, 32, image_h, image_w), zeros(batch_size, 64, n_points)
-                xyz2_warp, feat2_2d_warp = xyz2, feat2_2d
+                last_flow_2d, last_flow_feat_2d = zeros(batch_size, 2, image_h, image_w), zeros(batch_size, 32, image_h, image_w)
+                feat2_2d_warp = feat2_2d_fused
             else:
                 last_flow_2d = F.interpolate(flows_2d[-1] * 2, scale_factor=2, mode="bilinear", align_corners=True)
                 last_flow_feat_2d = F.interpolate(flow_feats_2d[-1], scale_factor=2, mode="bilinear", align_corners=True)
-                feat2_2d_warp = backwarp_2d(feat2_2d, last_flow_2d, padding_mode="border")
-                up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], dim=1), xyz1)
-                last_flow_3d, last_flow_feat_3d = up[:, :3, :], up[:, 3:, :]
-                xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
-
-            feat_corr_3d = self.correlations_3d[level](xyz1, feat1_3d, xyz2_warp, feat2_3d, knn_1in1)
-            feat_corr_2d = F.leaky_relu(correlation2d(feat1_2d, feat2_2d_warp, md), 0.1)
-
-            last_flow_3d_to_2d = torch.cat([last_flow_3d[:, 0:1] * sx, last_flow_3d[:, 1:2] * sy], dim=1)
+                feat2_2d_warp = backwarp_2d(feat2_2d_fused, last_flow_2d, padding_mode="border")
+            feat_corr_2d = F.leaky_relu(correlation2d(feat1_2d_fused, feat2_2d_warp, md), 0.1)
             last_flow_2d_to_3d = torch.cat([last_flow_2d[:, 0:1] * ((sensor_w - 1) / (image_w - 1)),
                                             last_flow_2d[:, 1:2] * ((sensor_h - 1) / (image_h - 1))], dim=1)
+            br.join(out_3d)
+            knn_1in1, feat1_3d, last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d = out_3d
+            feat1_2d = feat1_2d_fused
+
+            # ---- stage 2: correlation fusers and flow estimators
+            def chain_3d():
+                corr_3d_fused = self.corr_feat_fusers_3d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d,
+                                                                last_flow_2d_to_3d)
+                x_3d = torch.cat([self.correlation_aligners_3d[level](corr_3d_fused), self.feature_aligners_3d[level](feat1_3d),
+                                  last_flow_3d, last_flow_feat_3d], dim=1)
+                return (self.flow_estimator_3d(xyz1, x_3d, knn_1in1),)
+
+            out_3d = br.fork(chain_3d, [feat_corr_2d, efeat_2d, last_flow_2d_to_3d])
             corr_2d_fused = self.corr_feat_fusers_2d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_2d,
                                                             last_flow_3d_to_2d, nn_proj1)
-            corr_3d_fused = self.corr_feat_fusers_3d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d,
-                                                            last_flow_2d_to_3d)
-
             x_2d = torch.cat([corr_2d_fused, self.feature_aligners_2d[level](feat1_2d), self.efeature_aligners_2d[level](efeat_2d),
                               last_flow_2d, last_flow_feat_2d], dim=1)
-            x_3d = torch.cat([self.correlation_aligners_3d[level](corr_3d_fused), self.feature_aligners_3d[level](feat1_3d),
-                              last_flow_3d, last_flow_feat_3d], dim=1)
-            flow_feat_2d = self.flow_estimator_2d(x_2d)
-            flow_feat_3d = self.flow_estimator_3d(xyz1, x_3d, knn_1in1)
+            flow_feat_2d_raw = self.flow_estimator_2d(x_2d)
+            br.join(out_3d)
+            flow_feat_3d_raw, = out_3d
 
-            flow_feat_2d, flow_feat_3d = (self.estimator_feat_fuser_2d(xy1, flow_feat_2d, flow_feat_3d, nn_proj1),
-                                          self.estimator_feat_fuser_3d(xy1, flow_feat_2d, flow_feat_3d))
+            # ---- stage 3: decoder fusers and flow heads
+            def chain_3d():
+                flow_feat_3d = self.estimator_feat_fuser_3d(xy1, flow_feat_2d_raw, flow_feat_3d_raw)
+                return flow_feat_3d, last_flow_3d + self.conv_last_3d(flow_feat_3d)
 
+            out_3d = br.fork(chain_3d, [flow_feat_2d_raw])
+            flow_feat_2d = self.estimator_feat_fuser_2d(xy1, flow_feat_2d_raw, flow_feat_3d_raw, nn_proj1)
             flow_2d = last_flow_2d + self.conv_last_2d(flow_feat_2d)
-            flow_3d = last_flow_3d + self.conv_last_3d(flow_feat_3d)
             flow_feat_2d, flow_delta_2d = self.context_network_2d(torch.cat([flow_feat_2d, flow_2d], dim=1))
             flow_2d = flow_delta_2d + flow_2d
+            br.join(out_3d)
+            flow_feat_3d, flow_3d = out_3d
 
             flows_2d.append(flow_2d); flows_3d.append(flow_3d)
             flow_feats_2d.append(flow_feat_2d); flow_feats_3d.append(flow_feat_3d)
@@ -595,8 +647,9 @@ class RPEFlow(nn.Module):
             feats1_2d, feats1_3d = core.encode(image1, xyzs1)
             feats2_2d, feats2_3d = core.encode(image2, xyzs2)
             efeats_2d = core.encode_event(event_voxel)
+        side = self._side_stream(pc1.device) if (pc1.is_cuda and self.overlap_streams) else None
         flows_2d, flows_3d = core.decode(xyzs1, xyzs2, feats1_2d, feats2_2d, feats1_3d, feats2_3d, efeats_2d,
-                                         paral if self.cfgs.ids.enabled else persp)
+                                         paral if self.cfgs.ids.enabled else persp, side_stream=side)
         flow_3d = flows_3d[0]
         if self.cfgs.ids.enabled:
             xyz1 = xyzs1[0]
