@@ -471,9 +471,13 @@ class RPEFlow_core(nn.Module):
     def encode_event(self, event_voxel):
         return self.efeature_pyramid_2d(event_voxel)
 
-    def decode(self, xyzs1, xyzs2, feats1_2d, feats2_2d, feats1_3d, feats2_3d, efeats_2d, camera_info, side_stream=None):
-        """RPEFlow_core.py:302-432 without the MI loss bookkeeping.  ``side_stream``: run the 3-D chain of every level
-        beside the 2-D chain (see _Branches); None = everything in order on the current stream."""
+    def decode(self, xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d, camera_info, side_stream=None):
+        """RPEFlow_core.py:302-432 without the MI loss bookkeeping.
+
+        ``feats_2d_both`` / ``feats_3d_both``: pyramids of frame 1 and frame 2 stacked on the batch axis ([2B,...], frame 1
+        first).  The reference runs the shared-weight pyramid fusers once per frame (:329-338); all their layers are
+        per-sample in eval mode, so one pass over the 2B stack computes the same thing with half the launches.
+        ``side_stream``: run the 3-D chain of every level beside the 2-D chain (see _Branches); None = in order."""
         flows_2d, flows_3d, flow_feats_2d, flow_feats_3d = [], [], [], []
         sensor_h, sensor_w = camera_info["sensor_h"], camera_info["sensor_w"]
         md, k = self.cfgs2d.max_displacement, self.cfgs3d.k
@@ -481,25 +485,27 @@ class RPEFlow_core(nn.Module):
         correlation2d, k_nearest_neighbor = o.correlation2d, o.k_nearest_neighbor
         backwarp_2d, backwarp_3d, knn_interpolation = o.backwarp_2d, o.backwarp_3d, o.knn_interpolation
         br = _Branches(side_stream)
+        camera_both = {key: (torch.cat([v, v]) if torch.is_tensor(v) else v) for key, v in camera_info.items()}
         top = len(xyzs1) - 1
         for level in range(top, 0, -1):
-            xyz1, feat1_2d, feat1_3d = xyzs1[level], feats1_2d[level], feats1_3d[level]
-            xyz2, feat2_2d, feat2_3d = xyzs2[level], feats2_2d[level], feats2_3d[level]
+            xyz1, xyz2 = xyzs1[level], xyzs2[level]
+            feat_2d_both, feat_3d_both = feats_2d_both[level], feats_3d_both[level]
             efeat_2d = efeats_2d[level]
-            batch_size, image_h, image_w = feat1_2d.shape[0], feat1_2d.shape[2], feat1_2d.shape[3]
+            batch_size, image_h, image_w = feat_2d_both.shape[0] // 2, feat_2d_both.shape[2], feat_2d_both.shape[3]
             n_points = xyz1.shape[-1]
             sx, sy = (image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1)
 
-            xy1, xy2 = project_pc2image(xyz1, camera_info), project_pc2image(xyz2, camera_info)
-            xy1[:, 0] *= sx; xy1[:, 1] *= sy
-            xy2[:, 0] *= sx; xy2[:, 1] *= sy
+            xy_both = project_pc2image(torch.cat([xyz1, xyz2], dim=0), camera_both)
+            xy_both[:, 0] *= sx; xy_both[:, 1] *= sy
+            xy1 = xy_both[:batch_size]
             fuse2d, fuse3d = self.pyramid_feat_fusers_2d[level], self.pyramid_feat_fusers_3d[level]
             zeros = lambda *s: torch.zeros(s, dtype=xy1.dtype, device=xy1.device)
 
             # ---- stage 1: pyramid fusers, warps and cost volumes.  3-D chain on the side stream.
-            def chain_3d(feat1_2d=feat1_2d, feat2_2d=feat2_2d, feat1_3d=feat1_3d, feat2_3d=feat2_3d):
+            def chain_3d():
                 knn_1in1 = k_nearest_neighbor(xyz1, xyz1, k=k)
-                f1, f2 = fuse3d(xy1, feat1_2d, feat1_3d), fuse3d(xy2, feat2_2d, feat2_3d)
+                f_both = fuse3d(xy_both, feat_2d_both, feat_3d_both)
+                f1, f2 = f_both[:batch_size], f_both[batch_size:]
                 if level == top:
                     last_flow_3d, last_flow_feat_3d, xyz2_warp = zeros(batch_size, 3, n_points), zeros(batch_size, 64, n_points), xyz2
                 else:
@@ -510,16 +516,16 @@ class RPEFlow_core(nn.Module):
                 last_flow_3d_to_2d = torch.cat([last_flow_3d[:, 0:1] * sx, last_flow_3d[:, 1:2] * sy], dim=1)
                 return knn_1in1, f1, last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d
 
-            side_in = [xyz1, xyz2, xy1, xy2, feat1_2d, feat2_2d, feat1_3d, feat2_3d]
+            side_in = [xyz1, xyz2, xy_both, feat_2d_both, feat_3d_both]
             if level != top:
                 side_in += [xyzs1[level + 1], flows_3d[-1], flow_feats_3d[-1]]
             out_3d = br.fork(chain_3d, side_in)
 
-            grid = mesh_grid(batch_size, image_h, image_w, xy1.device).reshape(batch_size, 2, -1)
-            nn_proj1 = k_nearest_neighbor(xy1, grid, k=1)
-            nn_proj2 = k_nearest_neighbor(xy2, grid, k=1)
-            feat1_2d_fused = fuse2d(xy1, feat1_2d, feat1_3d, nn_proj1)
-            feat2_2d_fused = fuse2d(xy2, feat2_2d, feat2_3d, nn_proj2)
+            grid = mesh_grid(2 * batch_size, image_h, image_w, xy1.device).reshape(2 * batch_size, 2, -1)
+            nn_proj_both = k_nearest_neighbor(xy_both, grid, k=1)
+            nn_proj1 = nn_proj_both[:batch_size]
+            fused_both = fuse2d(xy_both, feat_2d_both, feat_3d_both, nn_proj_both)
+            feat1_2d_fused, feat2_2d_fused = fused_both[:batch_size], fused_both[batch_size:]
             if level == top:
                 last_flow_2d, last_flow_feat_2d = zeros(batch_size, 2, image_h, image_w), zeros(batch_size, 32, image_h, image_w)
                 feat2_2d_warp = feat2_2d_fused
@@ -625,30 +631,34 @@ class RPEFlow(nn.Module):
 
         core = self.pwc_fusion_core
         n_samples = [4096, 2048, 1024, 512, 256]
+        # frames 1 and 2 go through the shared-weight pyramids as one 2B batch (the reference calls encode() twice,
+        # RPEFlow.py:78-79; eval-mode BatchNorm makes the two forms equal sample by sample)
+        image_both = torch.cat([image1, image2], dim=0)
+
+        def encode_3d():
+            xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, n_samples)
+            return xyzs1, xyzs2, core.feature_pyramid_3d([torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)])
+
         if pc1.is_cuda and self.overlap_streams:
             # The 3-D encoder (FPS: 4096 dependent samples on 2B workgroups, then small PointConv kernels) and
-            # the three 2-D pyramids (large convolutions) share no data until decode(): run them on two HIP
+            # the 2-D pyramids (large convolutions) share no data until decode(): run them on two HIP
             # streams.  FPS alone keeps 2B of 256 CUs busy for ~4.8 ms; here it hides behind the convolutions.
             main = torch.cuda.current_stream(pc1.device)
             side = self._side_stream(pc1.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, n_samples)
-                feats1_3d = core.feature_pyramid_3d(xyzs1)
-                feats2_3d = core.feature_pyramid_3d(xyzs2)
-            feats1_2d = core.feature_pyramid_2d(image1)
-            feats2_2d = core.feature_pyramid_2d(image2)
+                xyzs1, xyzs2, feats_3d_both = encode_3d()
+            feats_2d_both = core.feature_pyramid_2d(image_both)
             efeats_2d = core.encode_event(event_voxel)
             main.wait_stream(side)
-            for t in list(xyzs1) + list(xyzs2) + list(feats1_3d) + list(feats2_3d):
+            for t in list(xyzs1) + list(xyzs2) + list(feats_3d_both):
                 t.record_stream(main)  # allocated on the side stream, consumed on the main one
         else:
-            xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, n_samples)
-            feats1_2d, feats1_3d = core.encode(image1, xyzs1)
-            feats2_2d, feats2_3d = core.encode(image2, xyzs2)
+            xyzs1, xyzs2, feats_3d_both = encode_3d()
+            feats_2d_both = core.feature_pyramid_2d(image_both)
             efeats_2d = core.encode_event(event_voxel)
         side = self._side_stream(pc1.device) if (pc1.is_cuda and self.overlap_streams) else None
-        flows_2d, flows_3d = core.decode(xyzs1, xyzs2, feats1_2d, feats2_2d, feats1_3d, feats2_3d, efeats_2d,
+        flows_2d, flows_3d = core.decode(xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d,
                                          paral if self.cfgs.ids.enabled else persp, side_stream=side)
         flow_3d = flows_3d[0]
         if self.cfgs.ids.enabled:

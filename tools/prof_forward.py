@@ -1,5 +1,5 @@
 """Full forward only, for rocprofv3 --kernel-trace: warm-up (MIOpen find), a marker kernel, N steady-state steps,
-a marker.  tools/trace_window.py sums kernels between the markers.  Usage: python tools/prof_forward.py [steps]"""
+a marker.  tools/trace_window.py sums kernels between the markers.  Usage: python tools/prof_forward.py [steps] [graph]"""
 import os
 import sys
 
@@ -21,9 +21,17 @@ torch.cuda.synchronize()
 from rpeflow_amd import _lib
 probe = torch.zeros(256, device=dev)
 mark = lambda: _lib.lib().rpe_probe_mfma4x4(probe.data_ptr(), torch.cuda.current_stream().cuda_stream)  # marker kernel
+step = lambda: model(batch)
+if "graph" in sys.argv:  # replay the forward as one HIP graph, as bench.py does
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        model(batch)
+    graph.replay()
+    torch.cuda.synchronize()
+    step = graph.replay
 mark()
 for _ in range(steps):
-    model(batch)
+    step()
 mark()
 torch.cuda.synchronize()
 print("done", steps)
