@@ -224,6 +224,120 @@ __global__ __launch_bounds__(kThreads) void fps_kernel_dpp(const float *__restri
 }
 
 
+// ---- variant 3: the same algorithm on the integer pipe, reductions as fused DPP instructions ----------------
+// Running distances are non-negative floats (sums of squares, 1e10 at the start), so their bit patterns order like
+// the values: min / max / == run as v_min_i32 / v_max3_i32 / v_cmp_eq_u32 with no NaN canonicalisation, invalid slots
+// hold -1.  The compiler expands every __builtin_amdgcn_update_dpp + max step into mov, nop, mov_dpp, 2 x max; here a
+// step is ONE v_max_i32_dpp (plus the two wait states a DPP read of a fresh VALU result needs).  The argmax keeps no
+// per-point index: a wave reduces values only, then eight v_cmp ballots find the lowest index holding the wave's
+// maximum on the scalar unit.  Per sample and wave ~85 VALU instructions instead of ~160; tie rule unchanged.
+#define RPE_DPP_STEP(op, v, ctrl) asm volatile("s_nop 1\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
+__device__ __forceinline__ int row_max16_i32(int v) {
+    RPE_DPP_STEP("v_max_i32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    RPE_DPP_STEP("v_max_i32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    RPE_DPP_STEP("v_max_i32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+    RPE_DPP_STEP("v_max_i32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    return v;  // lane 15 of every row: the row's maximum
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+    v = row_max16_i32(v);
+    RPE_DPP_STEP("v_max_i32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    RPE_DPP_STEP("v_max_i32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    int r;
+    asm volatile("s_nop 1\n\tv_readlane_b32 %0, %1, 63" : "=s"(r) : "v"(v));
+    return r;
+}
+
+template <int PPT, bool LDS_XYZ>
+__global__ __launch_bounds__(kThreads) void fps_kernel_int(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
+                                                           int N, int S, int64_t *__restrict__ idx) {
+    static_assert(PPT % 2 == 0, "packed path needs an even number of points per thread");
+    constexpr int H = PPT / 2;
+    extern __shared__ float lds[];
+    int *part_v = reinterpret_cast<int *>(lds);
+    int *part_i = reinterpret_cast<int *>(lds + 2 * kWaves);
+    float *lx = lds + 4 * kWaves, *ly = lx + N, *lz = ly + N;
+
+    const int tid = threadIdx.x, lane = rpe_lane();
+    const int wave = rpe_uniform(tid >> 6);
+    const int b = blockIdx.x;
+    xyz += (int64_t)b * sb;
+    idx += (int64_t)b * S;
+
+    f32x2 px[H], py[H], pz[H];
+    int md[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int i = tid + j * kThreads;
+        const bool valid = i < N;
+        const float *a = xyz + (int64_t)(valid ? i : 0) * sn;
+        const float x = a[0], y = a[sd], z = a[2 * sd];
+        px[j >> 1][j & 1] = x;
+        py[j >> 1][j & 1] = y;
+        pz[j >> 1][j & 1] = z;
+        md[j] = valid ? __float_as_int(1e10f) : -1;
+        if (LDS_XYZ && valid) {
+            lx[i] = x;
+            ly[i] = y;
+            lz[i] = z;
+        }
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int s = 0; s < S; ++s) {
+        if (tid == 0) idx[s] = (int64_t)cur;
+        if (s == S - 1) break;
+        float cx, cy, cz;
+        if (LDS_XYZ) {
+            cx = lx[cur]; cy = ly[cur]; cz = lz[cur];
+        } else {
+            const float *a = xyz + (int64_t)cur * sn;
+            cx = a[0]; cy = a[sd]; cz = a[2 * sd];
+        }
+        const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+        int tmax = -1;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
+            const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            f32x2 nd = xx + yy;
+            nd = nd + zz;
+            md[2 * h] = min(md[2 * h], __float_as_int(nd[0]));
+            md[2 * h + 1] = min(md[2 * h + 1], __float_as_int(nd[1]));
+            tmax = max(tmax, max(md[2 * h], md[2 * h + 1]));
+        }
+        const int wmax = wave_max_i32(tmax);
+        // lowest index in the wave holding wmax: index = tid + j * kThreads, so the lowest j wins, then the lowest lane
+        int widx = 0x7fffffff;
+#pragma unroll
+        for (int j = PPT - 1; j >= 0; --j) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(md[j] == wmax);
+            widx = m ? j * kThreads + wave * RPE_WAVE + (int)__builtin_ctzll(m) : widx;
+        }
+        const int par = (s & 1) * kWaves;
+        if (lane == 0) {
+            part_v[par + wave] = wmax;
+            part_i[par + wave] = widx;
+        }
+        __syncthreads();
+        const int pv = part_v[par + (lane & (kWaves - 1))];
+        const int pi = part_i[par + (lane & (kWaves - 1))];
+        int bmax;
+        {
+            int r = row_max16_i32(pv);
+            asm volatile("s_nop 1\n\tv_readlane_b32 %0, %1, 15" : "=s"(bmax) : "v"(r));
+        }
+        unsigned long long tied = __builtin_amdgcn_ballot_w64(pv == bmax) & 0xffffull;  // row 0 holds one copy of the 16 partials
+        cur = 0x7fffffff;
+        do {  // one pass unless two waves tie on the maximum
+            cur = min(cur, __builtin_amdgcn_readlane(pi, (int)__builtin_ctzll(tied)));
+            tied &= tied - 1;
+        } while (tied);
+    }
+}
+
+
 // ---- spatially sorted FPS with exact skipping ---------------------------------------------
 // The two kernels above touch every point in every iteration.  But a new sample only lowers the
 // running distance of points closer to it than their current distance, and late in the run that is
@@ -424,7 +538,7 @@ __global__ __launch_bounds__(kThreads) void fps_sorted_kernel(const float *__res
 // Measured on MI355X (8192 -> 4096): 1.68 / 1.19 / 1.32 us per sample.  Variant 2 removes ~95 % of the
 // distance arithmetic but not the per-sample latency chain (candidate update -> wave reduce -> LDS ->
 // barrier -> block reduce) that bounds all three, so 1 stays the default.
-int g_fps_variant = 1;
+int g_fps_variant = 3;  // 0 shuffle, 1 DPP + packed math, 2 Morton-sorted with skipping, 3 integer pipe + fused DPP (fastest)
 
 template <int PPT>
 int launch_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, hipStream_t st) {
@@ -435,6 +549,7 @@ int launch_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int 
     auto kern = use_lds ? fps_kernel<PPT, true> : fps_kernel<PPT, false>;
     if constexpr (PPT % 2 == 0) {
         if (g_fps_variant >= 1) kern = use_lds ? fps_kernel_dpp<PPT, true> : fps_kernel_dpp<PPT, false>;
+        if (g_fps_variant == 3) kern = use_lds ? fps_kernel_int<PPT, true> : fps_kernel_int<PPT, false>;
     }
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -459,7 +574,7 @@ int launch_fps_sorted(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int 
 }
 
 RPE_API int rpe_debug_set_fps_variant(int variant) {
-    if (variant < 0 || variant > 2) return RPE_EINVAL;
+    if (variant < 0 || variant > 3) return RPE_EINVAL;
     g_fps_variant = variant;
     return 0;
 }
