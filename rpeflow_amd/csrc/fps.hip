@@ -538,6 +538,246 @@ __global__ __launch_bounds__(kThreads) void fps_sorted_kernel(const float *__res
 // Measured on MI355X (8192 -> 4096): 1.68 / 1.19 / 1.32 us per sample.  Variant 2 removes ~95 % of the
 // distance arithmetic but not the per-sample latency chain (candidate update -> wave reduce -> LDS ->
 // barrier -> block reduce) that bounds all three, so 1 stays the default.
+// ---- variant 4: Morton-sorted clusters, skipped per wave, on the machinery of variant 3 ------------------
+// A new sample c lowers the running distance of point i only if d(i,c) < md[i].  Points are sorted along a Morton
+// curve so that a wave owns NCL spatially compact clusters (PPT / NCL rows of 64 points each) with known bounding
+// boxes.  Per sample a wave evaluates, for each of its clusters, a lower bound LB of the squared distance from c to
+// the box; if 0.99999 * LB exceeds the cluster's largest running distance no point of the cluster can change (the
+// margin is far larger than the rounding of either side) and the cluster is skipped: no distance arithmetic, no
+// reduction.  Late in the run one or two of the 16 waves do any work per sample.  Whatever is recomputed uses exactly
+// the reference arithmetic, ties resolve to the lowest ORIGINAL index, so the output is index-for-index the reference fallback's.
+__device__ __forceinline__ int wave_min_i32(int v) {
+    RPE_DPP_STEP("v_min_i32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
+    RPE_DPP_STEP("v_min_i32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
+    RPE_DPP_STEP("v_min_i32_dpp", v, "row_shr:4 row_mask:0xf bank_mask:0xf");
+    RPE_DPP_STEP("v_min_i32_dpp", v, "row_shr:8 row_mask:0xf bank_mask:0xf");
+    RPE_DPP_STEP("v_min_i32_dpp", v, "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    RPE_DPP_STEP("v_min_i32_dpp", v, "row_bcast:31 row_mask:0xc bank_mask:0xf");
+    int r;
+    asm volatile("s_nop 1\n\tv_readlane_b32 %0, %1, 63" : "=s"(r) : "v"(v));
+    return r;
+}
+
+#ifdef RPE_FPS_STATS
+__device__ unsigned long long g_fps_stats[4];
+#endif
+template <int PPT, int NCL>
+__global__ __launch_bounds__(kThreads) void fps_pruned_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
+                                                              int N, int S, int64_t *__restrict__ idx) {
+    static_assert(PPT % NCL == 0 && (PPT / NCL) % 2 == 0, "a cluster is a whole number of packed row pairs");
+    constexpr int NP = PPT * kThreads;  // padded (power of two) element count
+    constexpr int RPC = PPT / NCL;      // rows per cluster
+    constexpr int H = PPT / 2;
+    // LDS: the sort buffer [NP] u64 first; afterwards the same bytes hold x[N] y[N] z[N] by original index
+    extern __shared__ unsigned long long sortbuf[];
+    __shared__ float red[6][kWaves];
+    __shared__ int part_v[2 * kWaves], part_i[2 * kWaves];
+    const int tid = threadIdx.x, lane = rpe_lane();
+    const int wave = rpe_uniform(tid >> 6);
+    const int b = blockIdx.x;
+    xyz += (int64_t)b * sb;
+    idx += (int64_t)b * S;
+
+    // ---- 1. bounding box of the cloud
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < N; i += kThreads) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = xyz[(int64_t)i * sn + d * sd];
+            lo[d] = fminf(lo[d], v);
+            hi[d] = fmaxf(hi[d], v);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float l = wave_minf(lo[d]), h = wave_max(hi[d]);
+        if (lane == 0) { red[d][wave] = l; red[3 + d][wave] = h; }
+    }
+    __syncthreads();
+    float clo[3], scale[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float l = red[d][0], h = red[3 + d][0];
+        for (int w = 1; w < kWaves; ++w) { l = fminf(l, red[d][w]); h = fmaxf(h, red[3 + d][w]); }
+        clo[d] = l;
+        scale[d] = h > l ? 1023.0f / (h - l) : 0.f;  // per-axis: clusters come out as boxes of similar proportions as the cloud
+    }
+
+    // ---- 2. Morton keys + bitonic sort (ascending; padding sorts last)
+    for (int i = tid; i < NP; i += kThreads) {
+        unsigned long long e = ~0ull;
+        if (i < N) {
+            unsigned key = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float v = xyz[(int64_t)i * sn + d * sd];
+                int q = (int)((v - clo[d]) * scale[d]);
+                q = q < 0 ? 0 : (q > 1023 ? 1023 : q);  // NaN -> 0
+                key |= spread10((unsigned)q) << d;
+            }
+            e = ((unsigned long long)key << 32) | (unsigned)i;
+        }
+        sortbuf[i] = e;
+    }
+    __syncthreads();
+    for (int k = 2; k <= NP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < NP / 2; p += kThreads) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
+                const unsigned long long a = sortbuf[i], c = sortbuf[l];
+                const bool up = (i & k) == 0;
+                if ((a > c) == up) { sortbuf[i] = c; sortbuf[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- 3. this thread's points: row j of wave w = sorted positions w*64*PPT + j*64 + lane
+    f32x2 px[H], py[H], pz[H];
+    int md[PPT], oi[PPT];
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};  // lane c < NCL: box of cluster c
+#pragma unroll
+    for (int c = 0; c < NCL; ++c) {
+        float l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int r = 0; r < RPC; ++r) {
+            const int j = c * RPC + r;
+            const unsigned o = (unsigned)(sortbuf[wave * (RPE_WAVE * PPT) + j * RPE_WAVE + lane] & 0xffffffffu);
+            const bool valid = o != 0xffffffffu;
+            oi[j] = valid ? (int)o : 0x7fffffff;
+            const float *a = xyz + (int64_t)(valid ? o : 0) * sn;
+            const float x = a[0], y = a[sd], z = a[2 * sd];
+            px[j >> 1][j & 1] = x;
+            py[j >> 1][j & 1] = y;
+            pz[j >> 1][j & 1] = z;
+            md[j] = valid ? __float_as_int(1e10f) : -1;
+            if (valid) {
+                l3[0] = fminf(l3[0], x); h3[0] = fmaxf(h3[0], x);
+                l3[1] = fminf(l3[1], y); h3[1] = fmaxf(h3[1], y);
+                l3[2] = fminf(l3[2], z); h3[2] = fmaxf(h3[2], z);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float l = wave_minf(l3[d]), h = wave_max(h3[d]);
+            if (lane == c) { blo[d] = l; bhi[d] = h; }
+        }
+    }
+    __syncthreads();  // everyone has read its sorted entries: the buffer becomes the coordinate table
+    float *lx = reinterpret_cast<float *>(sortbuf), *ly = lx + N, *lz = ly + N;
+    for (int i = tid; i < N; i += kThreads) {
+        lx[i] = xyz[(int64_t)i * sn];
+        ly[i] = xyz[(int64_t)i * sn + sd];
+        lz[i] = xyz[(int64_t)i * sn + 2 * sd];
+    }
+    __syncthreads();
+
+    int cmax[NCL];      // wave-uniform: largest running distance (bits) per cluster; -1 for an empty cluster
+    int cmaxv = -1;     // lane c < NCL: cmax[c] (for the lane-parallel skip test)
+#pragma unroll
+    for (int c = 0; c < NCL; ++c) {
+        int t = -1;
+#pragma unroll
+        for (int r = 0; r < RPC; ++r) t = max(t, md[c * RPC + r]);
+        cmax[c] = wave_max_i32(t);
+        cmaxv = lane == c ? cmax[c] : cmaxv;
+    }
+    int wmax = -1, widx = 0x7fffffff;  // the wave's candidate: value bits, lowest original index holding it
+    bool fresh = true;                 // candidate must be (re)derived
+
+    int cur = 0;
+    for (int s = 0; s < S; ++s) {
+        if (tid == 0) idx[s] = (int64_t)cur;
+        if (s == S - 1) break;
+        const float cx = lx[cur], cy = ly[cur], cz = lz[cur];
+        // lane c: lower bound of the squared distance from the sample to box c, shrunk by 1e-5
+        const float ex = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.f), ey = fmaxf(fmaxf(blo[1] - cy, cy - bhi[1]), 0.f),
+                    ez = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.f);
+        const float lb = ((ex * ex + ey * ey) + ez * ez) * 0.99999f;
+        const unsigned need = (unsigned)__builtin_amdgcn_ballot_w64(__float_as_int(lb) <= cmaxv) & ((1u << NCL) - 1u);
+        if (need) {
+            const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+#pragma unroll
+            for (int c = 0; c < NCL; ++c) {
+                if (!((need >> c) & 1u)) continue;  // wave-uniform
+#ifdef RPE_FPS_STATS
+                if (lane == 0) atomicAdd(&g_fps_stats[0], 1ull);
+#endif
+                int t = -1;
+#pragma unroll
+                for (int h = c * RPC / 2; h < (c + 1) * RPC / 2; ++h) {
+                    const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
+                    const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                    f32x2 nd = xx + yy;
+                    nd = nd + zz;
+                    md[2 * h] = min(md[2 * h], __float_as_int(nd[0]));
+                    md[2 * h + 1] = min(md[2 * h + 1], __float_as_int(nd[1]));
+                    t = max(t, max(md[2 * h], md[2 * h + 1]));
+                }
+                cmax[c] = wave_max_i32(t);
+                cmaxv = lane == c ? cmax[c] : cmaxv;
+            }
+            fresh = true;
+        }
+        if (fresh) {  // wave-uniform: derive (wmax, widx) from the clusters' maxima
+            fresh = false;
+            wmax = cmax[0];
+#pragma unroll
+            for (int c = 1; c < NCL; ++c) wmax = max(wmax, cmax[c]);
+            unsigned long long m[PPT];
+            int holders = 0;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                m[j] = __builtin_amdgcn_ballot_w64(md[j] == wmax);
+                holders += (int)__builtin_popcountll(m[j]);
+            }
+            if (holders == 1) {
+                widx = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < PPT; ++j)
+                    if (m[j]) widx = __builtin_amdgcn_readlane(oi[j], (int)__builtin_ctzll(m[j]));
+            } else {  // several points share the maximum (the start, duplicates): lowest original index
+                int v = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) v = md[j] == wmax ? min(v, oi[j]) : v;
+                widx = wave_min_i32(v);
+            }
+        }
+        const int par = (s & 1) * kWaves;
+        if (lane == 0) {
+            part_v[par + wave] = wmax;
+            part_i[par + wave] = widx;
+        }
+        __syncthreads();
+        const int pv = part_v[par + (lane & (kWaves - 1))];
+        const int pi = part_i[par + (lane & (kWaves - 1))];
+        int bmax;
+        {
+            int r = row_max16_i32(pv);
+            asm volatile("s_nop 1\n\tv_readlane_b32 %0, %1, 15" : "=s"(bmax) : "v"(r));
+        }
+        unsigned long long tied = __builtin_amdgcn_ballot_w64(pv == bmax) & 0xffffull;
+        cur = 0x7fffffff;
+        do {
+            cur = min(cur, __builtin_amdgcn_readlane(pi, (int)__builtin_ctzll(tied)));
+            tied &= tied - 1;
+        } while (tied);
+    }
+}
+
+template <int PPT, int NCL>
+int launch_fps_pruned(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, hipStream_t st) {
+    const size_t sort_bytes = sizeof(unsigned long long) * (size_t)PPT * kThreads, table_bytes = sizeof(float) * 3 * (size_t)N;
+    const size_t shmem = sort_bytes > table_bytes ? sort_bytes : table_bytes;
+    auto kern = fps_pruned_kernel<PPT, NCL>;
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), shmem, st, xyz, sb, sn, sd, N, S, idx);
+    return rpe_launch_status();
+}
+
 int g_fps_variant = 3;  // 0 shuffle, 1 DPP + packed math, 2 Morton-sorted with skipping, 3 integer pipe + fused DPP (fastest)
 
 template <int PPT>
@@ -549,7 +789,7 @@ int launch_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int 
     auto kern = use_lds ? fps_kernel<PPT, true> : fps_kernel<PPT, false>;
     if constexpr (PPT % 2 == 0) {
         if (g_fps_variant >= 1) kern = use_lds ? fps_kernel_dpp<PPT, true> : fps_kernel_dpp<PPT, false>;
-        if (g_fps_variant == 3) kern = use_lds ? fps_kernel_int<PPT, true> : fps_kernel_int<PPT, false>;
+        if (g_fps_variant >= 3) kern = use_lds ? fps_kernel_int<PPT, true> : fps_kernel_int<PPT, false>;
     }
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -573,8 +813,17 @@ int launch_fps_sorted(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int 
     return rpe_launch_status();
 }
 
+#ifdef RPE_FPS_STATS
+extern "C" __attribute__((visibility("default"))) unsigned long long rpe_debug_fps_stats(int reset) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fps_stats), sizeof(h));
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_fps_stats), z, sizeof(z)); }
+    return h[0];
+}
+#endif
 RPE_API int rpe_debug_set_fps_variant(int variant) {
-    if (variant < 0 || variant > 3) return RPE_EINVAL;
+    if (variant < 0 || variant > 6) return RPE_EINVAL;
     g_fps_variant = variant;
     return 0;
 }
@@ -590,6 +839,17 @@ RPE_API int rpe_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B,
         if (ppt <= 4) return launch_fps_sorted<4>(xyz, sb, sn, sd, B, N, S, idx, st);
         if (ppt <= 8) return launch_fps_sorted<8>(xyz, sb, sn, sd, B, N, S, idx, st);
         return launch_fps_sorted<16>(xyz, sb, sn, sd, B, N, S, idx, st);
+    }
+    if (g_fps_variant >= 4 && N > kThreads && N <= 16 * kThreads) {  // 4/5/6: pruned, 1/2/4 clusters per wave
+#define RPE_PRUNED(P)                                                                                          \
+    return g_fps_variant == 4   ? launch_fps_pruned<P, 1>(xyz, sb, sn, sd, B, N, S, idx, st)                   \
+           : g_fps_variant == 5 ? launch_fps_pruned<P, (P >= 4 ? 2 : 1)>(xyz, sb, sn, sd, B, N, S, idx, st)    \
+                                : launch_fps_pruned<P, (P >= 8 ? 4 : P >= 4 ? 2 : 1)>(xyz, sb, sn, sd, B, N, S, idx, st)
+        if (ppt <= 2) RPE_PRUNED(2);
+        if (ppt <= 4) RPE_PRUNED(4);
+        if (ppt <= 8) RPE_PRUNED(8);
+        RPE_PRUNED(16);
+#undef RPE_PRUNED
     }
     if (ppt <= 1) return launch_fps<1>(xyz, sb, sn, sd, B, N, S, idx, st);
     if (ppt <= 2) return launch_fps<2>(xyz, sb, sn, sd, B, N, S, idx, st);

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from . import _lib
 from .csrc import k_nearest_neighbor
-from .utils import MLP2d, _act, _norm
+from .utils import MLP2d, _act, _norm, affine_epilogue
 
 
 def _ptr(t):
@@ -59,8 +59,16 @@ class _PointConv(nn.Module):
         self.activation_fn = _act(activation)
 
     def _finish(self, grouped):
-        out = self.linear(grouped).float()  # [B,Q,Cout]
-        return self.activation_fn(self.norm_fn(out.transpose(1, 2)))
+        epi = affine_epilogue(self, self.linear.bias, self.norm_fn, self.activation_fn) if grouped.is_cuda else None
+        if epi is None:
+            out = self.linear(grouped).float()  # [B,Q,Cout]
+            return self.activation_fn(self.norm_fn(out.transpose(1, 2)))
+        # W [Cout,K] x grouped^T [B,K,Q] lands channel-first with no transpose pass; bias + eval BatchNorm + activation
+        # follow as one in-place kernel
+        from .restormer_ops import channel_affine_act_
+        scale, shift, kind = epi
+        out = torch.matmul(self.linear.weight, grouped.transpose(1, 2))  # [B,Cout,Q]
+        return channel_affine_act_(out, scale, shift, kind, 0.1)
 
 
 class PointConvDownSampling(_PointConv):

@@ -54,6 +54,34 @@ def _act(kind):
     raise NotImplementedError("Unknown activation function: %s" % kind)
 
 
+def affine_epilogue(owner, bias, norm, act):
+    """(scale, shift, act) of the per-channel epilogue y = act(scale*x + shift) that a bias add, eval-mode BatchNorm
+    and the activation amount to -- or None when that does not apply (training BN, InstanceNorm).  Cached on ``owner``
+    until a parameter or buffer changes."""
+    if isinstance(norm, nn.modules.batchnorm._BatchNorm):
+        if norm.training or not norm.track_running_stats:
+            return None
+    elif not isinstance(norm, nn.Identity):
+        return None
+    kind = "leaky_relu" if isinstance(act, nn.LeakyReLU) else "relu" if isinstance(act, nn.ReLU) else None
+    if kind is None and not isinstance(act, nn.Identity):
+        return None
+    tensors = [t for t in (bias, *norm.parameters(), *norm.buffers()) if t is not None]
+    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    cache = getattr(owner, "_epi_cache", None)
+    if cache is None or cache[0] != key:
+        bias = bias.detach().float() if bias is not None else None
+        scale = None
+        if isinstance(norm, nn.modules.batchnorm._BatchNorm):
+            scale = (norm.weight.detach() if norm.affine else 1.0) / torch.sqrt(norm.running_var + norm.eps)
+            shift = (norm.bias.detach() if norm.affine else 0.0) - norm.running_mean * scale
+            if bias is not None:
+                shift = shift + bias * scale
+            scale, bias = scale.float().contiguous(), shift.float().contiguous()
+        owner._epi_cache = cache = (key, (scale, bias.contiguous() if bias is not None else None, kind))
+    return cache[1]
+
+
 class _ConvNormRelu(nn.Module):
     """utils.py:7-62: conv_fn / norm_fn / relu_fn, in that order and under those names."""
     dims = 1
@@ -67,30 +95,7 @@ class _ConvNormRelu(nn.Module):
         self.relu_fn = _act(activation)
 
     def _epilogue(self):
-        """(scale, shift, act) of the per-channel epilogue y = act(scale*conv + shift) that bias, eval-mode BatchNorm
-        and the activation amount to -- or None when that does not apply (training BN, InstanceNorm).  Cached until a
-        parameter or buffer changes."""
-        norm, act = self.norm_fn, self.relu_fn
-        if isinstance(norm, nn.modules.batchnorm._BatchNorm):
-            if norm.training or not norm.track_running_stats:
-                return None
-        elif not isinstance(norm, nn.Identity):
-            return None
-        kind = "leaky_relu" if isinstance(act, nn.LeakyReLU) else "relu" if isinstance(act, nn.ReLU) else None
-        tensors = [t for t in (self.conv_fn.bias, *norm.parameters(), *norm.buffers()) if t is not None]
-        key = tuple((t.data_ptr(), t._version) for t in tensors)
-        cache = getattr(self, "_epi_cache", None)
-        if cache is None or cache[0] != key:
-            bias = self.conv_fn.bias.detach().float() if self.conv_fn.bias is not None else None
-            scale = None
-            if isinstance(norm, nn.modules.batchnorm._BatchNorm):
-                scale = (norm.weight.detach() if norm.affine else 1.0) / torch.sqrt(norm.running_var + norm.eps)
-                shift = (norm.bias.detach() if norm.affine else 0.0) - norm.running_mean * scale
-                if bias is not None:
-                    shift = shift + bias * scale
-                scale, bias = scale.float().contiguous(), shift.float().contiguous()
-            self._epi_cache = cache = (key, (scale, bias.contiguous() if bias is not None else None, kind))
-        return cache[1]
+        return affine_epilogue(self, self.conv_fn.bias, self.norm_fn, self.relu_fn)
 
     def forward(self, x):
         epi = self._epilogue() if x.is_cuda else None

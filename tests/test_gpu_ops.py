@@ -136,7 +136,7 @@ def test_fps_golden_cases(golden_dir, name):
     assert np.array_equal(got, G(golden_dir, name)["idx"]), name + " vs reference golden"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 def test_fps_both_kernel_variants_agree(golden_dir, variant):
     """The first (shuffle) kernel and the DPP/packed-math kernel give identical samples."""
     try:

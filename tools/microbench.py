@@ -52,7 +52,7 @@ def main():
         for (B, N, S) in [(8, 8192, 4096), (2, 8192, 4096), (8, 4096, 1024)]:
             p = (torch.rand(B, 3, N, device=dev) * 30).transpose(1, 2)
             from rpeflow_amd import _lib
-            for variant in (1, 3):
+            for variant in (3, 4, 5, 6):
                 _lib.lib().rpe_debug_set_fps_variant(variant)
                 us = timeit(lambda: ops.furthest_point_sampling(p, S), warmup=1, iters=3)
                 print(f"fps variant={variant} B={B} N={N} S={S}: {us:9.1f} us  {us / S:6.3f} us/sample")
