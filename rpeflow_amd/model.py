@@ -391,6 +391,35 @@ def convex_upsample(flow, mask, scale_factor=8):
 
 
 # ------------------------------------------------------------------ the core (RPEFlow_core.py:165-432)
+class StampTrace:
+    """Timeline of a multi-stream forward: stamp(name) drops a one-thread kernel on the current stream that stores the
+    GPU wall clock (rpe_debug_stamp).  Works inside a captured HIP graph: every replay refreshes the values.  Set
+    rpeflow_amd.model.TRACE = StampTrace(device) before the (captured) forward, read() after a replay."""
+
+    def __init__(self, device, slots=1024):
+        self.buf = torch.zeros(slots, dtype=torch.int64, device=device)
+        self.names = []
+
+    def __call__(self, name):
+        from . import _lib
+        i = len(self.names)
+        self.names.append(name)
+        _lib.check(_lib.lib().rpe_debug_stamp(self.buf.data_ptr() + 8 * i, _lib.stream_of(self.buf)), "stamp")
+
+    def read(self):
+        """[(name, microseconds since the first stamp)] in issue order."""
+        v = self.buf[:len(self.names)].cpu().tolist()
+        return [(n, (t - v[0]) / 100.0) for n, t in zip(self.names, v)]
+
+
+TRACE = None
+
+
+def _stamp(name):
+    if TRACE is not None:
+        TRACE(name)
+
+
 class _Branches:
     """Two-branch execution for decode(): at every pyramid level the 2-D chain (convolutions over H*W pixels) and the
     3-D chain (small kernels over N points) only meet at the three Bi-CLFM fusers, so the 3-D chain runs on a side HIP
@@ -471,13 +500,17 @@ class RPEFlow_core(nn.Module):
     def encode_event(self, event_voxel):
         return self.efeature_pyramid_2d(event_voxel)
 
-    def decode(self, xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d, camera_info, side_stream=None):
+    def decode(self, xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d, camera_info, side_stream=None, pre_stream=None,
+               all_levels=False):
         """RPEFlow_core.py:302-432 without the MI loss bookkeeping.
 
         ``feats_2d_both`` / ``feats_3d_both``: pyramids of frame 1 and frame 2 stacked on the batch axis ([2B,...], frame 1
         first).  The reference runs the shared-weight pyramid fusers once per frame (:329-338); all their layers are
         per-sample in eval mode, so one pass over the 2B stack computes the same thing with half the launches.
-        ``side_stream``: run the 3-D chain of every level beside the 2-D chain (see _Branches); None = in order."""
+        ``side_stream``: run the 3-D chain of every level beside the 2-D chain (see _Branches); None = in order.
+        ``pre_stream``: the pyramid fusers and neighbour searches of ALL levels depend on the encoders only, not on the
+        coarse-to-fine flow recurrence; they are issued up front, on this third stream when given, and each level of the
+        recurrence waits for its own set."""
         flows_2d, flows_3d, flow_feats_2d, flow_feats_3d = [], [], [], []
         sensor_h, sensor_w = camera_info["sensor_h"], camera_info["sensor_w"]
         md, k = self.cfgs2d.max_displacement, self.cfgs3d.k
@@ -487,45 +520,72 @@ class RPEFlow_core(nn.Module):
         br = _Branches(side_stream)
         camera_both = {key: (torch.cat([v, v]) if torch.is_tensor(v) else v) for key, v in camera_info.items()}
         top = len(xyzs1) - 1
+        batch_size = feats_2d_both[1].shape[0] // 2
+
+        # ---- stage 1, hoisted out of the recurrence: projections, neighbour searches, pyramid fusers of every level
+        def fuse_level(level):
+            image_h, image_w = feats_2d_both[level].shape[2:]
+            xy_both = project_pc2image(torch.cat([xyzs1[level], xyzs2[level]], dim=0), camera_both)
+            xy_both[:, 0] *= (image_w - 1) / (sensor_w - 1)
+            xy_both[:, 1] *= (image_h - 1) / (sensor_h - 1)
+            grid = mesh_grid(2 * batch_size, image_h, image_w, xy_both.device).reshape(2 * batch_size, 2, -1)
+            nn_proj_both = k_nearest_neighbor(xy_both, grid, k=1)
+            knn_1in1 = k_nearest_neighbor(xyzs1[level], xyzs1[level], k=k)
+            fused_2d = self.pyramid_feat_fusers_2d[level](xy_both, feats_2d_both[level], feats_3d_both[level], nn_proj_both)
+            fused_3d = self.pyramid_feat_fusers_3d[level](xy_both, feats_2d_both[level], feats_3d_both[level])
+            return xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d
+
+        fused, ready = {}, {}
+        if pre_stream is not None:
+            main = torch.cuda.current_stream(pre_stream.device)
+            pre_stream.wait_stream(main)
+            for t in list(xyzs1) + list(xyzs2) + list(feats_2d_both) + list(feats_3d_both):
+                t.record_stream(pre_stream)
+            with torch.cuda.stream(pre_stream):
+                for level in range(top, 0, -1):
+                    fused[level] = fuse_level(level)
+                    _stamp("pre L%d done" % level)
+                    ready[level] = torch.cuda.Event()
+                    ready[level].record(pre_stream)
+        else:
+            for level in range(top, 0, -1):
+                fused[level] = fuse_level(level)
+
         for level in range(top, 0, -1):
             xyz1, xyz2 = xyzs1[level], xyzs2[level]
-            feat_2d_both, feat_3d_both = feats_2d_both[level], feats_3d_both[level]
             efeat_2d = efeats_2d[level]
-            batch_size, image_h, image_w = feat_2d_both.shape[0] // 2, feat_2d_both.shape[2], feat_2d_both.shape[3]
+            image_h, image_w = feats_2d_both[level].shape[2:]
             n_points = xyz1.shape[-1]
             sx, sy = (image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1)
-
-            xy_both = project_pc2image(torch.cat([xyz1, xyz2], dim=0), camera_both)
-            xy_both[:, 0] *= sx; xy_both[:, 1] *= sy
-            xy1 = xy_both[:batch_size]
-            fuse2d, fuse3d = self.pyramid_feat_fusers_2d[level], self.pyramid_feat_fusers_3d[level]
+            if pre_stream is not None:
+                torch.cuda.current_stream(pre_stream.device).wait_event(ready[level])
+                for t in fused[level]:
+                    t.record_stream(torch.cuda.current_stream(pre_stream.device))
+            _stamp("main L%d start" % level)
+            xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d = fused.pop(level)
+            xy1, nn_proj1 = xy_both[:batch_size], nn_proj_both[:batch_size]
+            feat1_2d, feat2_2d_fused = fused_2d[:batch_size], fused_2d[batch_size:]
+            feat1_3d, feat2_3d = fused_3d[:batch_size], fused_3d[batch_size:]
             zeros = lambda *s: torch.zeros(s, dtype=xy1.dtype, device=xy1.device)
 
-            # ---- stage 1: pyramid fusers, warps and cost volumes.  3-D chain on the side stream.
+            # ---- stage 1b: warps and cost volumes.  3-D chain on the side stream.
             def chain_3d():
-                knn_1in1 = k_nearest_neighbor(xyz1, xyz1, k=k)
-                f_both = fuse3d(xy_both, feat_2d_both, feat_3d_both)
-                f1, f2 = f_both[:batch_size], f_both[batch_size:]
                 if level == top:
                     last_flow_3d, last_flow_feat_3d, xyz2_warp = zeros(batch_size, 3, n_points), zeros(batch_size, 64, n_points), xyz2
                 else:
                     up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], dim=1), xyz1)
                     last_flow_3d, last_flow_feat_3d = up[:, :3, :], up[:, 3:, :]
                     xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
-                feat_corr_3d = self.correlations_3d[level](xyz1, f1, xyz2_warp, f2, knn_1in1)
+                feat_corr_3d = self.correlations_3d[level](xyz1, feat1_3d, xyz2_warp, feat2_3d, knn_1in1)
                 last_flow_3d_to_2d = torch.cat([last_flow_3d[:, 0:1] * sx, last_flow_3d[:, 1:2] * sy], dim=1)
-                return knn_1in1, f1, last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d
+                _stamp("side L%d stage1 done" % level)
+                return last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d
 
-            side_in = [xyz1, xyz2, xy_both, feat_2d_both, feat_3d_both]
+            side_in = [xyz1, xyz2, xy_both, knn_1in1, fused_3d]
             if level != top:
                 side_in += [xyzs1[level + 1], flows_3d[-1], flow_feats_3d[-1]]
             out_3d = br.fork(chain_3d, side_in)
 
-            grid = mesh_grid(2 * batch_size, image_h, image_w, xy1.device).reshape(2 * batch_size, 2, -1)
-            nn_proj_both = k_nearest_neighbor(xy_both, grid, k=1)
-            nn_proj1 = nn_proj_both[:batch_size]
-            fused_both = fuse2d(xy_both, feat_2d_both, feat_3d_both, nn_proj_both)
-            feat1_2d_fused, feat2_2d_fused = fused_both[:batch_size], fused_both[batch_size:]
             if level == top:
                 last_flow_2d, last_flow_feat_2d = zeros(batch_size, 2, image_h, image_w), zeros(batch_size, 32, image_h, image_w)
                 feat2_2d_warp = feat2_2d_fused
@@ -533,12 +593,12 @@ class RPEFlow_core(nn.Module):
                 last_flow_2d = F.interpolate(flows_2d[-1] * 2, scale_factor=2, mode="bilinear", align_corners=True)
                 last_flow_feat_2d = F.interpolate(flow_feats_2d[-1], scale_factor=2, mode="bilinear", align_corners=True)
                 feat2_2d_warp = backwarp_2d(feat2_2d_fused, last_flow_2d, padding_mode="border")
-            feat_corr_2d = F.leaky_relu(correlation2d(feat1_2d_fused, feat2_2d_warp, md), 0.1)
+            feat_corr_2d = F.leaky_relu(correlation2d(feat1_2d, feat2_2d_warp, md), 0.1)
             last_flow_2d_to_3d = torch.cat([last_flow_2d[:, 0:1] * ((sensor_w - 1) / (image_w - 1)),
                                             last_flow_2d[:, 1:2] * ((sensor_h - 1) / (image_h - 1))], dim=1)
+            _stamp("main L%d stage1 done" % level)
             br.join(out_3d)
-            knn_1in1, feat1_3d, last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d = out_3d
-            feat1_2d = feat1_2d_fused
+            last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d = out_3d
 
             # ---- stage 2: correlation fusers and flow estimators
             def chain_3d():
@@ -546,7 +606,9 @@ class RPEFlow_core(nn.Module):
                                                                 last_flow_2d_to_3d)
                 x_3d = torch.cat([self.correlation_aligners_3d[level](corr_3d_fused), self.feature_aligners_3d[level](feat1_3d),
                                   last_flow_3d, last_flow_feat_3d], dim=1)
-                return (self.flow_estimator_3d(xyz1, x_3d, knn_1in1),)
+                est = self.flow_estimator_3d(xyz1, x_3d, knn_1in1)
+                _stamp("side L%d stage2 done" % level)
+                return (est,)
 
             out_3d = br.fork(chain_3d, [feat_corr_2d, efeat_2d, last_flow_2d_to_3d])
             corr_2d_fused = self.corr_feat_fusers_2d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_2d,
@@ -554,19 +616,23 @@ class RPEFlow_core(nn.Module):
             x_2d = torch.cat([corr_2d_fused, self.feature_aligners_2d[level](feat1_2d), self.efeature_aligners_2d[level](efeat_2d),
                               last_flow_2d, last_flow_feat_2d], dim=1)
             flow_feat_2d_raw = self.flow_estimator_2d(x_2d)
+            _stamp("main L%d stage2 done" % level)
             br.join(out_3d)
             flow_feat_3d_raw, = out_3d
 
             # ---- stage 3: decoder fusers and flow heads
             def chain_3d():
                 flow_feat_3d = self.estimator_feat_fuser_3d(xy1, flow_feat_2d_raw, flow_feat_3d_raw)
-                return flow_feat_3d, last_flow_3d + self.conv_last_3d(flow_feat_3d)
+                flow_3d = last_flow_3d + self.conv_last_3d(flow_feat_3d)
+                _stamp("side L%d stage3 done" % level)
+                return flow_feat_3d, flow_3d
 
             out_3d = br.fork(chain_3d, [flow_feat_2d_raw])
             flow_feat_2d = self.estimator_feat_fuser_2d(xy1, flow_feat_2d_raw, flow_feat_3d_raw, nn_proj1)
             flow_2d = last_flow_2d + self.conv_last_2d(flow_feat_2d)
             flow_feat_2d, flow_delta_2d = self.context_network_2d(torch.cat([flow_feat_2d, flow_2d], dim=1))
             flow_2d = flow_delta_2d + flow_2d
+            _stamp("main L%d stage3 done" % level)
             br.join(out_3d)
             flow_feat_3d, flow_3d = out_3d
 
@@ -576,9 +642,10 @@ class RPEFlow_core(nn.Module):
         flows_2d = [f.float() for f in flows_2d][::-1]
         flows_3d = [f.float() for f in flows_3d][::-1]
         flows_2d[0] = convex_upsample(flows_2d[0], self.up_mask_head_2d(flow_feats_2d[-1]), scale_factor=4)
-        for i in range(1, len(flows_2d)):
+        # the coarser levels' up-sampled flows (RPEFlow_core.py:426-430) feed the training losses only; inference reads [0]
+        for i in range(1, len(flows_2d) if all_levels else 1):
             flows_2d[i] = F.interpolate(flows_2d[i] * 4, scale_factor=4, mode="bilinear", align_corners=True)
-        for i in range(len(flows_3d)):
+        for i in range(len(flows_3d) if all_levels else 1):
             flows_3d[i] = knn_interpolation(xyzs1[i + 1], flows_3d[i], xyzs1[i])
         return flows_2d, flows_3d
 
@@ -599,8 +666,8 @@ class RPEFlow(nn.Module):
         self._streams = {}
         self.pwc_fusion_core = RPEFlow_core(self.cfgs.pwc2d, self.cfgs.pwc3d, self.cfgs.get("attention"), ops=ops)
 
-    def _side_stream(self, device):
-        key = torch.device(device).index
+    def _side_stream(self, device, name="side"):
+        key = (torch.device(device).index, name)
         if key not in self._streams:
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
@@ -634,10 +701,14 @@ class RPEFlow(nn.Module):
         # frames 1 and 2 go through the shared-weight pyramids as one 2B batch (the reference calls encode() twice,
         # RPEFlow.py:78-79; eval-mode BatchNorm makes the two forms equal sample by sample)
         image_both = torch.cat([image1, image2], dim=0)
+        _stamp("main start")
 
         def encode_3d():
             xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, n_samples)
-            return xyzs1, xyzs2, core.feature_pyramid_3d([torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)])
+            _stamp("side fps done")
+            feats = core.feature_pyramid_3d([torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)])
+            _stamp("side encode3d done")
+            return xyzs1, xyzs2, feats
 
         if pc1.is_cuda and self.overlap_streams:
             # The 3-D encoder (FPS: 4096 dependent samples on 2B workgroups, then small PointConv kernels) and
@@ -649,7 +720,9 @@ class RPEFlow(nn.Module):
             with torch.cuda.stream(side):
                 xyzs1, xyzs2, feats_3d_both = encode_3d()
             feats_2d_both = core.feature_pyramid_2d(image_both)
+            _stamp("main image pyramid done")
             efeats_2d = core.encode_event(event_voxel)
+            _stamp("main event pyramid done")
             main.wait_stream(side)
             for t in list(xyzs1) + list(xyzs2) + list(feats_3d_both):
                 t.record_stream(main)  # allocated on the side stream, consumed on the main one
@@ -658,8 +731,10 @@ class RPEFlow(nn.Module):
             feats_2d_both = core.feature_pyramid_2d(image_both)
             efeats_2d = core.encode_event(event_voxel)
         side = self._side_stream(pc1.device) if (pc1.is_cuda and self.overlap_streams) else None
+        pre = self._side_stream(pc1.device, "pre") if side is not None else None
         flows_2d, flows_3d = core.decode(xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d,
-                                         paral if self.cfgs.ids.enabled else persp, side_stream=side)
+                                         paral if self.cfgs.ids.enabled else persp, side_stream=side, pre_stream=pre)
+        _stamp("main decode done")
         flow_3d = flows_3d[0]
         if self.cfgs.ids.enabled:
             xyz1 = xyzs1[0]
