@@ -533,13 +533,16 @@ class RPEFlow_core(nn.Module):
             knn_1in1 = k_nearest_neighbor(xyzs1[level], xyzs1[level], k=k)
             fused_2d = self.pyramid_feat_fusers_2d[level](xy_both, feats_2d_both[level], feats_3d_both[level], nn_proj_both)
             fused_3d = self.pyramid_feat_fusers_3d[level](xy_both, feats_2d_both[level], feats_3d_both[level])
-            return xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d
+            # the aligners of the estimator inputs (:385-390) read the fused frame-1 features and the event features only
+            aligned = (self.feature_aligners_2d[level](fused_2d[:batch_size]), self.efeature_aligners_2d[level](efeats_2d[level]),
+                       self.feature_aligners_3d[level](fused_3d[:batch_size]))
+            return xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d, *aligned
 
         fused, ready = {}, {}
         if pre_stream is not None:
             main = torch.cuda.current_stream(pre_stream.device)
             pre_stream.wait_stream(main)
-            for t in list(xyzs1) + list(xyzs2) + list(feats_2d_both) + list(feats_3d_both):
+            for t in list(xyzs1) + list(xyzs2) + list(feats_2d_both) + list(feats_3d_both) + list(efeats_2d):
                 t.record_stream(pre_stream)
             with torch.cuda.stream(pre_stream):
                 for level in range(top, 0, -1):
@@ -562,7 +565,7 @@ class RPEFlow_core(nn.Module):
                 for t in fused[level]:
                     t.record_stream(torch.cuda.current_stream(pre_stream.device))
             _stamp("main L%d start" % level)
-            xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d = fused.pop(level)
+            xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d, aligned_2d, aligned_e2d, aligned_3d = fused.pop(level)
             xy1, nn_proj1 = xy_both[:batch_size], nn_proj_both[:batch_size]
             feat1_2d, feat2_2d_fused = fused_2d[:batch_size], fused_2d[batch_size:]
             feat1_3d, feat2_3d = fused_3d[:batch_size], fused_3d[batch_size:]
@@ -581,7 +584,7 @@ class RPEFlow_core(nn.Module):
                 _stamp("side L%d stage1 done" % level)
                 return last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d
 
-            side_in = [xyz1, xyz2, xy_both, knn_1in1, fused_3d]
+            side_in = [xyz1, xyz2, xy_both, knn_1in1, fused_3d, aligned_3d]
             if level != top:
                 side_in += [xyzs1[level + 1], flows_3d[-1], flow_feats_3d[-1]]
             out_3d = br.fork(chain_3d, side_in)
@@ -604,8 +607,7 @@ class RPEFlow_core(nn.Module):
             def chain_3d():
                 corr_3d_fused = self.corr_feat_fusers_3d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d,
                                                                 last_flow_2d_to_3d)
-                x_3d = torch.cat([self.correlation_aligners_3d[level](corr_3d_fused), self.feature_aligners_3d[level](feat1_3d),
-                                  last_flow_3d, last_flow_feat_3d], dim=1)
+                x_3d = torch.cat([self.correlation_aligners_3d[level](corr_3d_fused), aligned_3d, last_flow_3d, last_flow_feat_3d], dim=1)
                 est = self.flow_estimator_3d(xyz1, x_3d, knn_1in1)
                 _stamp("side L%d stage2 done" % level)
                 return (est,)
@@ -613,8 +615,7 @@ class RPEFlow_core(nn.Module):
             out_3d = br.fork(chain_3d, [feat_corr_2d, efeat_2d, last_flow_2d_to_3d])
             corr_2d_fused = self.corr_feat_fusers_2d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_2d,
                                                             last_flow_3d_to_2d, nn_proj1)
-            x_2d = torch.cat([corr_2d_fused, self.feature_aligners_2d[level](feat1_2d), self.efeature_aligners_2d[level](efeat_2d),
-                              last_flow_2d, last_flow_feat_2d], dim=1)
+            x_2d = torch.cat([corr_2d_fused, aligned_2d, aligned_e2d, last_flow_2d, last_flow_feat_2d], dim=1)
             flow_feat_2d_raw = self.flow_estimator_2d(x_2d)
             _stamp("main L%d stage2 done" % level)
             br.join(out_3d)
@@ -703,31 +704,30 @@ class RPEFlow(nn.Module):
         image_both = torch.cat([image1, image2], dim=0)
         _stamp("main start")
 
-        def encode_3d():
-            xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, n_samples)
-            _stamp("side fps done")
-            feats = core.feature_pyramid_3d([torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)])
-            _stamp("side encode3d done")
-            return xyzs1, xyzs2, feats
-
         if pc1.is_cuda and self.overlap_streams:
             # The 3-D encoder (FPS: 4096 dependent samples on 2B workgroups, then small PointConv kernels) and
             # the 2-D pyramids (large convolutions) share no data until decode(): run them on two HIP
-            # streams.  FPS alone keeps 2B of 256 CUs busy for ~4.8 ms; here it hides behind the convolutions.
+            # streams.  FPS alone keeps 2B of 256 CUs busy for ~3.5 ms; here it hides behind the convolutions.
             main = torch.cuda.current_stream(pc1.device)
             side = self._side_stream(pc1.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                xyzs1, xyzs2, feats_3d_both = encode_3d()
+                xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, n_samples)
+                both = [torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)]
+                _stamp("side fps done")
             feats_2d_both = core.feature_pyramid_2d(image_both)
             _stamp("main image pyramid done")
             efeats_2d = core.encode_event(event_voxel)
             _stamp("main event pyramid done")
+            with torch.cuda.stream(side):
+                feats_3d_both = core.feature_pyramid_3d(both)
+                _stamp("side encode3d done")
             main.wait_stream(side)
             for t in list(xyzs1) + list(xyzs2) + list(feats_3d_both):
                 t.record_stream(main)  # allocated on the side stream, consumed on the main one
         else:
-            xyzs1, xyzs2, feats_3d_both = encode_3d()
+            xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, n_samples)
+            feats_3d_both = core.feature_pyramid_3d([torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)])
             feats_2d_both = core.feature_pyramid_2d(image_both)
             efeats_2d = core.encode_event(event_voxel)
         side = self._side_stream(pc1.device) if (pc1.is_cuda and self.overlap_streams) else None

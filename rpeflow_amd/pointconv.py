@@ -74,8 +74,11 @@ class _PointConv(nn.Module):
 class PointConvDownSampling(_PointConv):
     """pointconv.py:7-61."""
 
-    def forward(self, xyz, features, sampled_xyz):
-        knn_indices = k_nearest_neighbor(xyz, sampled_xyz, self.k)  # [B,Q,k]
+    def forward(self, xyz, features, sampled_xyz, knn_indices=None):
+        """``knn_indices`` [B,Q,k]: neighbours of sampled_xyz in xyz if the caller already has them (the reference
+        always searches here, pointconv.py:46)."""
+        if knn_indices is None:
+            knn_indices = k_nearest_neighbor(xyz, sampled_xyz, self.k)  # [B,Q,k]
         return self._finish(pointconv_group(xyz, features, sampled_xyz, knn_indices, self.weight_net))
 
 
