@@ -84,6 +84,15 @@ int rpe_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
 int rpe_correlation2d_forward(const float *in1, const float *in2, int B, int C, int H, int W, int md,
                               float leaky_slope, int algo, float *out, rpe_stream_t stream);
 
+/* ---- correlation2d backward (training path of the operator) -------------------
+ * Replaces correlation_backward_kernel_wrapper (correlation.cpp; kernels correlation_backward_kernel.cu:4-88)
+ * behind CorrelationFunction.backward (wrapper.py:27-37), NCHW throughout:
+ *   grad_in1[b][c][p] = 1/C sum_k grad_out[b][k][p]       in2[b][c][p + d_k]
+ *   grad_in2[b][c][q] = 1/C sum_k grad_out[b][k][q - d_k] in1[b][c][q - d_k]      d_k = (k/(2md+1) - md, k%(2md+1) - md)
+ * grad_out [B,(2md+1)^2,H,W]; either gradient pointer may be NULL to skip it.  md <= 4.                     */
+int rpe_correlation2d_backward(const float *grad_out, const float *in1, const float *in2, int B, int C, int H, int W,
+                               int md, float *grad_in1, float *grad_in2, rpe_stream_t stream);
+
 /* ---- batch_indexing_channel_first / _last (models/utils.py:119-137, 101-116) ---
  * out[b][c][i] = data[b][c][idx[b][i]]   (data[b][c][n] = data[b*sb + c*sc + n*sn], out [B,C,I] contiguous)
  * out[b][i][c] = data[b][idx[b][i]][c]   (data[b][n][c] = data[b*sb + n*sn + c*sc], out [B,I,C] contiguous)

@@ -112,6 +112,23 @@ def correlation2d(input1, input2, max_displacement):
     return out
 
 
+def correlation2d_backward(grad_output, input1, input2, max_displacement):
+    """Gradients of _correlation_py (wrapper.py:56-65) w.r.t. both inputs, as autograd derives them: every cost plane
+    k = mean_c(in1 * shift_k(in2)) sends grad/C * shift_k(in2) to in1 and the un-shifted grad/C * in1 to in2.
+    float64 accumulation, rounded once.  NCHW."""
+    go, a, b = np.asarray(grad_output, np.float64), np.asarray(input1, np.float64), np.asarray(input2, np.float64)
+    B, C, H, W = a.shape
+    md, n = max_displacement, 2 * max_displacement + 1
+    bp = np.pad(b, ((0, 0), (0, 0), (md, md), (md, md)))
+    g1, g2p = np.zeros_like(a), np.zeros_like(bp)
+    for i in range(n):
+        for j in range(n):
+            g = go[:, i * n + j][:, None] / C
+            g1 += g * bp[:, :, i:i + H, j:j + W]
+            g2p[:, :, i:i + H, j:j + W] += g * a
+    return g1.astype(np.float32), g2p[:, :, md:md + H, md:md + W].astype(np.float32)
+
+
 # --------------------------------------------------------------------------
 # glue ops of models/utils.py
 # --------------------------------------------------------------------------

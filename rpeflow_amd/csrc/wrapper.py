@@ -57,14 +57,45 @@ def squared_distance(xyz1: torch.Tensor, xyz2: torch.Tensor):
     return out
 
 
+class CorrelationFunction(torch.autograd.Function):
+    """models/csrc/wrapper.py:18-37: the operator with its gradients (NCHW on both sides here)."""
+
+    @staticmethod
+    def forward(ctx, input1, input2, max_displacement):
+        ctx.save_for_backward(input1, input2)
+        ctx.max_displacement = int(max_displacement)
+        return _correlation2d_forward(input1, input2, max_displacement)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input1, input2 = ctx.saved_tensors
+        B, C, H, W = input1.shape
+        grad_output = grad_output.contiguous().float()
+        need1, need2 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g1 = torch.empty_like(input1) if need1 else None
+        g2 = torch.empty_like(input2) if need2 else None
+        with torch.cuda.device(input1.device):
+            rc = _lib.lib().rpe_correlation2d_backward(_ptr(grad_output), _ptr(input1), _ptr(input2), B, C, H, W, ctx.max_displacement,
+                                                       _ptr(g1) if need1 else None, _ptr(g2) if need2 else None,
+                                                       _lib.stream_of(input1))
+        _lib.check(rc, "correlation2d backward")
+        return g1, g2, None
+
+
 def correlation2d(input1: torch.Tensor, input2: torch.Tensor, max_displacement: int, cpp_impl=True):
-    """models/csrc/wrapper.py:55-72.  NCHW in, [B,(2md+1)^2,H,W] out; forward only."""
+    """models/csrc/wrapper.py:55-72.  NCHW in, [B,(2md+1)^2,H,W] out; differentiable in both inputs."""
     if not cpp_impl:
         _no_torch_path("correlation2d")
     _lib.require_gpu(input1, input2, op="correlation2d")
     assert input1.shape == input2.shape and input1.dim() == 4
     input1 = input1.contiguous().float()
     input2 = input2.contiguous().float()
+    if torch.is_grad_enabled() and (input1.requires_grad or input2.requires_grad):
+        return CorrelationFunction.apply(input1, input2, max_displacement)
+    return _correlation2d_forward(input1, input2, max_displacement)
+
+
+def _correlation2d_forward(input1, input2, max_displacement):
     B, C, H, W = input1.shape
     n = 2 * int(max_displacement) + 1
     out = torch.empty((B, n * n, H, W), dtype=torch.float32, device=input1.device)

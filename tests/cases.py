@@ -86,6 +86,13 @@ def corr_inputs(name):
     return I.feature_map(r, B, C, H, W), I.feature_map(r, B, C, H, W), md
 
 
+def corr_grad_output(name):
+    """Seeded upstream gradient for the correlation backward cases."""
+    B, C, H, W, md, seed = CORR_CASES[name]
+    n = 2 * md + 1
+    return I.rng(seed + 5000).standard_normal((B, n * n, H, W), dtype=np.float32)
+
+
 # glue ops: one small case each (B, C2, C3, H, W, N, seed)
 GLUE = dict(B=2, C2=12, C3=10, H=18, W=30, N=200, M=97, seed=501)
 

@@ -71,6 +71,10 @@ def gen_corr():
     for name in K.CORR_CASES:
         a, b, md = K.corr_inputs(name)
         save(name, out=ref_ops.correlation2d(T(a), T(b), md).numpy())
+        # gradients of the reference's differentiable fallback (_correlation_py through autograd)
+        ta, tb = T(a).clone().requires_grad_(True), T(b).clone().requires_grad_(True)
+        ref_ops.correlation2d(ta, tb, md).backward(T(K.corr_grad_output(name)))
+        save(name + "_grad", grad1=ta.grad.numpy(), grad2=tb.grad.numpy())
 
 
 def gen_glue():

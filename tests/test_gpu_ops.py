@@ -210,6 +210,36 @@ def test_correlation_ragged_shapes(B, C, H, Wd):
         assert np.abs(got - ref).max() < 5e-6, algo
 
 
+@pytest.mark.parametrize("name", list(K.CORR_CASES))
+def test_correlation_backward_matches_reference_autograd(golden_dir, name):
+    """CorrelationFunction.backward (wrapper.py:27-37) against the gradients autograd derives from the reference's
+    differentiable fallback."""
+    a, b, md = K.corr_inputs(name)
+    ta, tb = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+    out = ops.correlation2d(ta, tb, md)
+    assert out.requires_grad
+    assert np.abs(out.detach().cpu().numpy() - G(golden_dir, name)["out"]).max() < 5e-6
+    out.backward(dev(K.corr_grad_output(name)))
+    ref = G(golden_dir, name + "_grad")
+    assert np.abs(ta.grad.cpu().numpy() - ref["grad1"]).max() < 5e-6
+    assert np.abs(tb.grad.cpu().numpy() - ref["grad2"]).max() < 5e-6
+
+
+@pytest.mark.parametrize("B,C,H,Wd,md", [(1, 3, 5, 7, 4), (2, 33, 17, 65, 4), (1, 9, 40, 18, 2), (2, 8, 16, 16, 1), (1, 20, 33, 47, 3), (1, 1, 1, 1, 4)])
+def test_correlation_backward_ragged_shapes(B, C, H, Wd, md):
+    r = I.rng(9200 + C + H + Wd)
+    a, b = I.feature_map(r, B, C, H, Wd), I.feature_map(r, B, C, H, Wd)
+    n = 2 * md + 1
+    go = r.standard_normal((B, n * n, H, Wd), dtype=np.float32)
+    ta, tb = dev(a).requires_grad_(True), dev(b)  # only one input needs a gradient here
+    ops.correlation2d(ta, tb, md).backward(dev(go))
+    g1, g2 = O.correlation2d_backward(go, a, b, md)
+    assert np.abs(ta.grad.cpu().numpy() - g1).max() < 5e-6 and tb.grad is None
+    ta, tb = dev(a), dev(b).requires_grad_(True)
+    ops.correlation2d(ta, tb, md).backward(dev(go))
+    assert np.abs(tb.grad.cpu().numpy() - g2).max() < 5e-6
+
+
 def test_correlation_fused_leaky_relu():
     r = I.rng(9100)
     a, b = I.feature_map(r, 2, 32, 18, 32), I.feature_map(r, 2, 32, 18, 32)

@@ -56,6 +56,14 @@ def test_correlation2d(golden_dir, name):
     assert np.abs(out - ref).max() < 2e-6
 
 
+@pytest.mark.parametrize("name", list(K.CORR_CASES))
+def test_correlation2d_backward(golden_dir, name):
+    a, b, md = K.corr_inputs(name)
+    g1, g2 = O.correlation2d_backward(K.corr_grad_output(name), a, b, md)
+    ref = G(golden_dir, name + "_grad")
+    assert np.abs(g1 - ref["grad1"]).max() < 2e-6 and np.abs(g2 - ref["grad2"]).max() < 2e-6
+
+
 def test_glue_ops(golden_dir):
     d, g = K.glue_inputs(), G(golden_dir, "glue_ops")
     assert np.array_equal(O.batch_indexing_channel_first(d["feat_3d"], d["idx"]), g["gather_cf"])
