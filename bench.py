@@ -278,7 +278,7 @@ def main():
                          **({"note": "FPS is bound by the latency of 4095 DEPENDENT sampling iterations per cloud (SURVEY.md 8d), "
                                      "one workgroup per cloud on 2B of 256 CUs, not by HBM or MFMA: the HBM fraction is reported for "
                                      "form only; see us_per_iteration against the measured floor of the per-iteration "
-                                     "reduce-barrier-broadcast chain (DESIGN.md section 4.2); roofline_corr is the bandwidth-bound kernel",
+                                     "reduce-barrier-broadcast chain (DESIGN.md section 4.3); roofline_corr is the bandwidth-bound kernel",
                              "us_per_iteration": round(dom_us / 4095, 4), "iteration_sync_floor_us": 0.41}
                             if dom == "fps+pyramid" else {})},
             "hotpath": {"frame_pairs_per_s": round(pairs / dt_hot, 3), "ms_per_step": round(dt_hot / args.steps * 1e3, 3),
