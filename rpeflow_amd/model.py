@@ -554,41 +554,48 @@ class RPEFlow_core(nn.Module):
             for level in range(top, 0, -1):
                 fused[level] = fuse_level(level)
 
+        zeros = lambda *s: torch.zeros(s, dtype=feats_2d_both[1].dtype, device=feats_2d_both[1].device)
+        main_stream = torch.cuda.current_stream(pre_stream.device) if pre_stream is not None else None
+
+        def take(level):
+            """This level's hoisted tensors, after the main stream has waited for them."""
+            if pre_stream is not None:
+                main_stream.wait_event(ready[level])
+                for t in fused[level]:
+                    t.record_stream(main_stream)
+            return fused.pop(level)
+
+        def stage1_3d(level, hoisted):
+            """3-D side of stage 1: up-sample the coarser 3-D flow, warp, cost volume (RPEFlow_core.py:345-361).  Reads the
+            hoisted tensors and the side stream's own previous outputs only, so it follows the previous level's stage 3 on
+            the side stream without waiting for the main stream's context network."""
+            xy_both, _, knn_1in1, _, fused_3d = hoisted[:5]
+            xyz1, xyz2, n_points = xyzs1[level], xyzs2[level], xyzs1[level].shape[-1]
+            image_h, image_w = feats_2d_both[level].shape[2:]
+            sx, sy = (image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1)
+            if level == top:
+                last_flow_3d, last_flow_feat_3d, xyz2_warp = zeros(batch_size, 3, n_points), zeros(batch_size, 64, n_points), xyz2
+            else:
+                up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], dim=1), xyz1)
+                last_flow_3d, last_flow_feat_3d = up[:, :3, :], up[:, 3:, :]
+                xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
+            feat_corr_3d = self.correlations_3d[level](xyz1, fused_3d[:batch_size], xyz2_warp, fused_3d[batch_size:], knn_1in1)
+            last_flow_3d_to_2d = torch.cat([last_flow_3d[:, 0:1] * sx, last_flow_3d[:, 1:2] * sy], dim=1)
+            _stamp("side L%d stage1 done" % level)
+            return last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d
+
+        hoisted = take(top)
+        out_s1 = br.fork(lambda: stage1_3d(top, hoisted), list(hoisted) + [xyzs1[top], xyzs2[top]])
         for level in range(top, 0, -1):
-            xyz1, xyz2 = xyzs1[level], xyzs2[level]
+            xyz1 = xyzs1[level]
             efeat_2d = efeats_2d[level]
             image_h, image_w = feats_2d_both[level].shape[2:]
-            n_points = xyz1.shape[-1]
-            sx, sy = (image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1)
-            if pre_stream is not None:
-                torch.cuda.current_stream(pre_stream.device).wait_event(ready[level])
-                for t in fused[level]:
-                    t.record_stream(torch.cuda.current_stream(pre_stream.device))
             _stamp("main L%d start" % level)
-            xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d, aligned_2d, aligned_e2d, aligned_3d = fused.pop(level)
+            xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d, aligned_2d, aligned_e2d, aligned_3d = hoisted
             xy1, nn_proj1 = xy_both[:batch_size], nn_proj_both[:batch_size]
             feat1_2d, feat2_2d_fused = fused_2d[:batch_size], fused_2d[batch_size:]
-            feat1_3d, feat2_3d = fused_3d[:batch_size], fused_3d[batch_size:]
-            zeros = lambda *s: torch.zeros(s, dtype=xy1.dtype, device=xy1.device)
 
-            # ---- stage 1b: warps and cost volumes.  3-D chain on the side stream.
-            def chain_3d():
-                if level == top:
-                    last_flow_3d, last_flow_feat_3d, xyz2_warp = zeros(batch_size, 3, n_points), zeros(batch_size, 64, n_points), xyz2
-                else:
-                    up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], dim=1), xyz1)
-                    last_flow_3d, last_flow_feat_3d = up[:, :3, :], up[:, 3:, :]
-                    xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
-                feat_corr_3d = self.correlations_3d[level](xyz1, feat1_3d, xyz2_warp, feat2_3d, knn_1in1)
-                last_flow_3d_to_2d = torch.cat([last_flow_3d[:, 0:1] * sx, last_flow_3d[:, 1:2] * sy], dim=1)
-                _stamp("side L%d stage1 done" % level)
-                return last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d
-
-            side_in = [xyz1, xyz2, xy_both, knn_1in1, fused_3d, aligned_3d]
-            if level != top:
-                side_in += [xyzs1[level + 1], flows_3d[-1], flow_feats_3d[-1]]
-            out_3d = br.fork(chain_3d, side_in)
-
+            # ---- stage 1, 2-D side: warp and cost volume
             if level == top:
                 last_flow_2d, last_flow_feat_2d = zeros(batch_size, 2, image_h, image_w), zeros(batch_size, 32, image_h, image_w)
                 feat2_2d_warp = feat2_2d_fused
@@ -600,8 +607,8 @@ class RPEFlow_core(nn.Module):
             last_flow_2d_to_3d = torch.cat([last_flow_2d[:, 0:1] * ((sensor_w - 1) / (image_w - 1)),
                                             last_flow_2d[:, 1:2] * ((sensor_h - 1) / (image_h - 1))], dim=1)
             _stamp("main L%d stage1 done" % level)
-            br.join(out_3d)
-            last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d = out_3d
+            br.join(out_s1)
+            last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d = out_s1
 
             # ---- stage 2: correlation fusers and flow estimators
             def chain_3d():
@@ -621,34 +628,43 @@ class RPEFlow_core(nn.Module):
             br.join(out_3d)
             flow_feat_3d_raw, = out_3d
 
-            # ---- stage 3: decoder fusers and flow heads
+            # ---- stage 3: decoder fusers and flow heads.  The side stream goes straight on to stage 1 of the next level
+            # (its inputs are hoisted or its own); the main stream meets it again at that level's cost volumes.
+            nxt = take(level - 1) if level > 1 else None
+
             def chain_3d():
                 flow_feat_3d = self.estimator_feat_fuser_3d(xy1, flow_feat_2d_raw, flow_feat_3d_raw)
                 flow_3d = last_flow_3d + self.conv_last_3d(flow_feat_3d)
                 _stamp("side L%d stage3 done" % level)
-                return flow_feat_3d, flow_3d
+                flows_3d.append(flow_3d)
+                flow_feats_3d.append(flow_feat_3d)
+                if nxt is not None:
+                    return stage1_3d(level - 1, nxt)
+                # last level: the up-sampling of the 3-D flow to the full cloud belongs to this chain too (:430)
+                return (knn_interpolation(xyzs1[1], flow_3d.float(), xyzs1[0]),)
 
-            out_3d = br.fork(chain_3d, [flow_feat_2d_raw])
+            side_in = [flow_feat_2d_raw] + (list(nxt) + [xyzs1[level - 1], xyzs2[level - 1]] if nxt is not None else [xyzs1[0]])
+            out_s1 = br.fork(chain_3d, side_in)
             flow_feat_2d = self.estimator_feat_fuser_2d(xy1, flow_feat_2d_raw, flow_feat_3d_raw, nn_proj1)
             flow_2d = last_flow_2d + self.conv_last_2d(flow_feat_2d)
             flow_feat_2d, flow_delta_2d = self.context_network_2d(torch.cat([flow_feat_2d, flow_2d], dim=1))
             flow_2d = flow_delta_2d + flow_2d
             _stamp("main L%d stage3 done" % level)
-            br.join(out_3d)
-            flow_feat_3d, flow_3d = out_3d
-
-            flows_2d.append(flow_2d); flows_3d.append(flow_3d)
-            flow_feats_2d.append(flow_feat_2d); flow_feats_3d.append(flow_feat_3d)
+            flows_2d.append(flow_2d)
+            flow_feats_2d.append(flow_feat_2d)
+            hoisted = nxt
 
         flows_2d = [f.float() for f in flows_2d][::-1]
-        flows_3d = [f.float() for f in flows_3d][::-1]
         flows_2d[0] = convex_upsample(flows_2d[0], self.up_mask_head_2d(flow_feats_2d[-1]), scale_factor=4)
+        br.join(list(out_s1) + flows_3d + flow_feats_3d)
+        flows_3d = [f.float() for f in flows_3d][::-1]
+        flows_3d_up = [out_s1[0]]
         # the coarser levels' up-sampled flows (RPEFlow_core.py:426-430) feed the training losses only; inference reads [0]
         for i in range(1, len(flows_2d) if all_levels else 1):
             flows_2d[i] = F.interpolate(flows_2d[i] * 4, scale_factor=4, mode="bilinear", align_corners=True)
-        for i in range(len(flows_3d) if all_levels else 1):
-            flows_3d[i] = knn_interpolation(xyzs1[i + 1], flows_3d[i], xyzs1[i])
-        return flows_2d, flows_3d
+        for i in range(1, len(flows_3d) if all_levels else 1):
+            flows_3d_up.append(knn_interpolation(xyzs1[i + 1], flows_3d[i], xyzs1[i]))
+        return flows_2d, flows_3d_up + flows_3d[len(flows_3d_up):]
 
 
 class RPEFlow(nn.Module):
