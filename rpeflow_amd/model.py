@@ -576,9 +576,12 @@ class RPEFlow_core(nn.Module):
             if level == top:
                 last_flow_3d, last_flow_feat_3d, xyz2_warp = zeros(batch_size, 3, n_points), zeros(batch_size, 64, n_points), xyz2
             else:
+                _stamp("side L%d stage1 begin" % level)
                 up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], dim=1), xyz1)
+                _stamp("side L%d stage1 knn_interp done" % level)
                 last_flow_3d, last_flow_feat_3d = up[:, :3, :], up[:, 3:, :]
                 xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
+                _stamp("side L%d stage1 backwarp done" % level)
             feat_corr_3d = self.correlations_3d[level](xyz1, fused_3d[:batch_size], xyz2_warp, fused_3d[batch_size:], knn_1in1)
             last_flow_3d_to_2d = torch.cat([last_flow_3d[:, 0:1] * sx, last_flow_3d[:, 1:2] * sy], dim=1)
             _stamp("side L%d stage1 done" % level)
