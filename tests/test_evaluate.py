@@ -121,3 +121,17 @@ def test_two_process_gloo_all_reduce_equals_single_process(tmp_path):
     _, single = E.evaluate(fake_model, data, batch_size=2, device="cpu")
     np.testing.assert_allclose(np.array(accs[0]), single.numpy(), rtol=1e-12)
     assert accs[0][0] == single[0].item() and accs[0][4] == single[4].item()
+
+
+@pytest.mark.gpu
+def test_graph_replayed_evaluation_matches_eager():
+    """The harness's HIP-graph path (static input buffers, one graph per batch shape, short last batch included) gives
+    the metrics of the eager loop."""
+    from rpeflow_amd.model import RPEFlow
+    torch.manual_seed(0)
+    model = RPEFlow().to("cuda:0").eval()
+    data = SyntheticPairs(5, H=128, W=192, N=8192)
+    eager, acc_e = E.evaluate(model, data, batch_size=2, device="cuda:0", graph=False)
+    graphed, acc_g = E.evaluate(model, data, batch_size=2, device="cuda:0", graph=True)
+    assert eager["counts"] == graphed["counts"]
+    np.testing.assert_allclose(acc_g.cpu().numpy(), acc_e.cpu().numpy(), rtol=1e-4)
