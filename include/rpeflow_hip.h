@@ -208,10 +208,12 @@ int rpe_channel_affine_act(float *y, const float *scale, const float *shift, int
  * Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation
  * kernel relies on: out[64*4] = D for A[lane]=lane, B[lane]=100*lane (one K).   */
 int rpe_probe_mfma4x4(float *out256, rpe_stream_t stream);
-/* Selects the FPS kernel: 3 (default) = integer-pipe running distances + fused DPP reductions; 1 = DPP reductions +
- * packed fp32; 0 = shuffle-based first version; 2 = Morton-sorted points with per-thread box skipping; 4/5/6 =
- * Morton-sorted clusters skipped per wave, 1/2/4 clusters a wave (2, 4-6: 1024 < N <= 16384, else 3).  All give
- * identical indices; kept for A/B timing and cross-checks. */
+/* Selects the FPS kernel: -1 (default) = automatic: 7 for >= 2048 samples of >= 8192 points, else 3;
+ * 3 = integer-pipe running distances + fused DPP reductions; 7 = Morton-sorted clusters skipped per wave, the skip test
+ * folded into the post-barrier reduction, candidate coordinates published with the partials; 1 = DPP reductions +
+ * packed fp32; 0 = shuffle-based first version; 2 = per-thread box skipping; 4/5/6 = wave-level skipping with the test
+ * in front of the barrier, 1/2/4 clusters a wave (2, 4-7: 1024 < N <= 16384, else 3).  All give identical indices;
+ * kept for A/B timing and cross-checks. */
 int rpe_debug_set_fps_variant(int variant);
 /* Writes the GPU's constant-rate clock (100 MHz wall_clock64) to *slot when the stream reaches this point: a
  * one-thread kernel, usable inside a captured HIP graph, for timelines of multi-stream replays that rocprofv3

@@ -136,7 +136,7 @@ def test_fps_golden_cases(golden_dir, name):
     assert np.array_equal(got, G(golden_dir, name)["idx"]), name + " vs reference golden"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_fps_both_kernel_variants_agree(golden_dir, variant):
     """The first (shuffle) kernel and the DPP/packed-math kernel give identical samples."""
     try:
@@ -149,7 +149,7 @@ def test_fps_both_kernel_variants_agree(golden_dir, variant):
         got = ops.furthest_point_sampling(dev(xyz), 4999).cpu().numpy()
         assert np.array_equal(got, O.furthest_point_sampling(xyz, 4999))
     finally:
-        _lib.lib().rpe_debug_set_fps_variant(3)
+        _lib.lib().rpe_debug_set_fps_variant(-1)
 
 
 @pytest.mark.parametrize("B,N,S", [(1, 2, 1), (2, 65, 64), (3, 1023, 100), (1, 1025, 1024), (2, 3000, 700), (1, 9000, 50), (1, 20000, 40)])
