@@ -15,6 +15,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .csrc import correlation2d as native_correlation2d
+from .csrc.wrapper import _correlation2d_algo as correlation2d_fused_leaky
 from .hotpath import native_ops
 from .utils import Conv1dNormRelu, Conv2dNormRelu, mesh_grid
 
@@ -606,7 +608,10 @@ class RPEFlow_core(nn.Module):
                 last_flow_2d = F.interpolate(flows_2d[-1] * 2, scale_factor=2, mode="bilinear", align_corners=True)
                 last_flow_feat_2d = F.interpolate(flow_feats_2d[-1], scale_factor=2, mode="bilinear", align_corners=True)
                 feat2_2d_warp = backwarp_2d(feat2_2d_fused, last_flow_2d, padding_mode="border")
-            feat_corr_2d = F.leaky_relu(correlation2d(feat1_2d, feat2_2d_warp, md), 0.1)
+            if feat1_2d.is_cuda and correlation2d is native_correlation2d:  # leaky_relu of :362 fused into the kernel's epilogue
+                feat_corr_2d = correlation2d_fused_leaky(feat1_2d, feat2_2d_warp, md, 0, leaky_slope=0.1)
+            else:
+                feat_corr_2d = F.leaky_relu(correlation2d(feat1_2d, feat2_2d_warp, md), 0.1)
             last_flow_2d_to_3d = torch.cat([last_flow_2d[:, 0:1] * ((sensor_w - 1) / (image_w - 1)),
                                             last_flow_2d[:, 1:2] * ((sensor_h - 1) / (image_h - 1))], dim=1)
             _stamp("main L%d stage1 done" % level)
