@@ -198,6 +198,10 @@ int64_t rpe_channel_attention_workspace_floats(int B, int heads, int c, int64_t 
 int rpe_channel_attention_matrix(const float *q, const float *k, int64_t batch_stride, const float *temperature,
                                  const float *w_out, int B, int heads, int c, int64_t P, float eps,
                                  float *workspace, float *m_out, rpe_stream_t stream);
+/* rpe_convex_upsample: RAFT-style convex up-sampling of a 2-D flow (models/utils.py:201-214):
+ *   out[b][c][h*s+i][w*s+j] = sum_k softmax_k(mask[b][k*s*s + i*s + j][h][w]) * s * flow[b][c][h + k/3 - 1][w + k%3 - 1]
+ *   (zero outside).  flow [B,2,H,W], mask [B,9*s*s,H,W], out [B,2,H*s,W*s]; s in {2,4,8}.                        */
+int rpe_convex_upsample(const float *flow, const float *mask, int B, int H, int W, int scale, float *out, rpe_stream_t stream);
 /* rpe_channel_affine_act: y[b][c][p] = act(scale[c]*y[b][c][p] + shift[c]) IN PLACE over [B,C,P] -- the bias add,
  *   eval-mode BatchNorm and activation after a Conv{1,2}dNormRelu convolution (models/utils.py:7-62) in one pass.
  *   scale / shift may be NULL (1 / 0).  act: 0 none, 1 relu, 2 leaky_relu(slope).                              */

@@ -34,6 +34,7 @@ _PROTOTYPES = {
     "rpe_channel_attention_matrix": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_i64, _c_float,
                                      _c_ptr, _c_ptr, _c_ptr],
     "rpe_channel_attention_workspace_floats": [_c_int, _c_int, _c_int, _c_i64],
+    "rpe_convex_upsample": [_c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_channel_affine_act": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_int, _c_float, _c_ptr],
     "rpe_corr3d_hidden": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                           _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],

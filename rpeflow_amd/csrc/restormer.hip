@@ -201,7 +201,72 @@ __global__ __launch_bounds__(256) void affine_act_kernel(float *__restrict__ y, 
     }
 }
 
+// RAFT-style convex up-sampling (models/utils.py:201-214, the last step of RPEFlow_core.forward :424): every fine pixel
+// (h*s+i, w*s+j) is a softmax-weighted combination (9 weights from mask channels k*s*s + i*s + j) of the 3x3
+// coarse neighbourhood of s*flow.  One thread per coarse pixel walks its s*s fine pixels: the mask planes are read
+// fully coalesced, once; the reference's softmax / unfold / product / sum / permute chain and its [B,2,9,s,s,H,W]
+// intermediates are gone.
+template <int S>
+__global__ __launch_bounds__(256) void convex_upsample_kernel(const float *__restrict__ flow, const float *__restrict__ mask, int H, int W,
+                                                              float *__restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    const int HW = H * W;
+    if (p >= HW) return;
+    const int h = p / W, w = p - h * W;
+    float f[2][9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int y = h + k / 3 - 1, x = w + k % 3 - 1;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) f[c][k] = in ? flow[((int64_t)b * 2 + c) * HW + (int64_t)y * W + x] * (float)S : 0.f;
+    }
+    const float *m = mask + (int64_t)b * 9 * S * S * HW + p;
+    const int64_t OW = (int64_t)W * S;
+#pragma unroll 1
+    for (int i = 0; i < S; ++i)
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            float e[9], mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                e[k] = m[(int64_t)(k * S * S + i * S + j) * HW];
+                mx = fmaxf(mx, e[k]);
+            }
+            float sum = 0.f, a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                e[k] = expf(e[k] - mx);
+                sum += e[k];
+            }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const float wk = e[k] * inv;
+                a0 += wk * f[0][k];
+                a1 += wk * f[1][k];
+            }
+            const int64_t o = ((int64_t)h * S + i) * OW + (int64_t)w * S + j;
+            out[((int64_t)b * 2 + 0) * HW * S * S + o] = a0;
+            out[((int64_t)b * 2 + 1) * HW * S * S + o] = a1;
+        }
+}
+
 }  // namespace
+
+RPE_API int rpe_convex_upsample(const float *flow, const float *mask, int B, int H, int W, int scale, float *out, rpe_stream_t stream) {
+    if (!flow || !mask || !out || B < 0 || H < 1 || W < 1) return RPE_EINVAL;
+    if (scale != 2 && scale != 4 && scale != 8) return RPE_EUNSUPPORTED;
+    if (B == 0) return 0;
+    if (B > 65535) return RPE_EUNSUPPORTED;
+    dim3 grid((unsigned)(((int64_t)H * W + 255) / 256), B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (scale == 2) hipLaunchKernelGGL(convex_upsample_kernel<2>, grid, block, 0, st, flow, mask, H, W, out);
+    else if (scale == 4) hipLaunchKernelGGL(convex_upsample_kernel<4>, grid, block, 0, st, flow, mask, H, W, out);
+    else hipLaunchKernelGGL(convex_upsample_kernel<8>, grid, block, 0, st, flow, mask, H, W, out);
+    return rpe_launch_status();
+}
 
 RPE_API int rpe_dwconv3(const float *in0, int C0, const float *in1, int C1, const float *in2, int C2, const float *weight,
                         const float *bias, int B, int H, int W, int kh, int gate, float *out, rpe_stream_t stream) {

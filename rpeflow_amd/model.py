@@ -385,6 +385,9 @@ def resize_flow2d(flow, target_h, target_w):
 
 def convex_upsample(flow, mask, scale_factor=8):
     """utils.py:201-214 (RAFT convex upsampling)."""
+    if flow.is_cuda and scale_factor in (2, 4, 8):
+        from .restormer_ops import convex_upsample as fused
+        return fused(flow, mask, scale_factor)
     b, _, h, w = flow.shape
     mask = torch.softmax(mask.view(b, 1, 9, scale_factor, scale_factor, h, w), dim=2)
     up = F.unfold(flow * scale_factor, [3, 3], padding=1).view(b, 2, 9, 1, 1, h, w)

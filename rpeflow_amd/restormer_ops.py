@@ -86,3 +86,16 @@ def channel_attention_matrix(qkv, heads, temperature, w_out, eps=1e-12):
                                             B, heads, c, P, float(eps), _ptr(ws), _ptr(m), _lib.stream_of(qkv))
     _lib.check(rc, "channel_attention_matrix")
     return m
+
+
+def convex_upsample(flow, mask, scale_factor):
+    """flow [B,2,H,W], mask [B,9*s*s,H,W] -> [B,2,H*s,W*s] (models/utils.py:201-214) in one kernel."""
+    _lib.require_gpu(flow, mask, op="convex_upsample")
+    flow, mask = flow.contiguous().float(), mask.contiguous().float()
+    B, _, H, W = flow.shape
+    assert flow.shape[1] == 2 and mask.shape == (B, 9 * scale_factor * scale_factor, H, W)
+    out = torch.empty((B, 2, H * scale_factor, W * scale_factor), dtype=torch.float32, device=flow.device)
+    with torch.cuda.device(flow.device):
+        rc = _lib.lib().rpe_convex_upsample(_ptr(flow), _ptr(mask), B, H, W, int(scale_factor), _ptr(out), _lib.stream_of(flow))
+    _lib.check(rc, "convex_upsample")
+    return out

@@ -89,3 +89,15 @@ def test_mutual_attention_fused(dims, C, heads, spatial):
     scale = ref.abs().max().item()
     assert (got - ref).abs().max().item() < 2e-5 * max(scale, 1.0), (got - ref).abs().max().item()
     assert (got_r - (r + ref)).abs().max().item() < 2e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("B,H,W,scale", [(2, 9, 15, 4), (1, 36, 60, 4), (2, 5, 7, 8), (1, 1, 1, 2), (3, 4, 33, 2)])
+def test_convex_upsample(B, H, W, scale):
+    """RAFT convex up-sampling (models/utils.py:201-214) in one kernel against the PyTorch chain on the CPU."""
+    from rpeflow_amd.model import convex_upsample
+    torch.manual_seed(H + W)
+    flow, mask = torch.randn(B, 2, H, W) * 3, torch.randn(B, 9 * scale * scale, H, W) * 2
+    ref = convex_upsample(flow, mask, scale)                      # CPU tensors: the reference chain
+    got = convex_upsample(flow.to(DEV), mask.to(DEV), scale).cpu()  # GPU tensors: the fused kernel
+    assert got.shape == ref.shape
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5)
