@@ -137,7 +137,16 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__
     bl.setup(gx, gy, H, W, border != 0);
     const int64_t HW = (int64_t)H * W;
     const int c0 = blockIdx.y * c_per_block, c1 = min(C, c0 + c_per_block);
-    for (int c = c0; c < c1; ++c) out[((int64_t)b * C + c) * P + p] = bl.sample(feat + ((int64_t)b * C + c) * HW);
+    // four channels per trip: 16 independent gathered loads in flight instead of 4
+    int c = c0;
+    for (; c + 4 <= c1; c += 4) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = bl.sample(feat + ((int64_t)b * C + c + u) * HW);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) out[((int64_t)b * C + c + u) * P + p] = v[u];
+    }
+    for (; c < c1; ++c) out[((int64_t)b * C + c) * P + p] = bl.sample(feat + ((int64_t)b * C + c) * HW);
 }
 
 // project_feat_with_nn_corr (utils.py:297-317) in two launches.
@@ -185,9 +194,28 @@ __global__ __launch_bounds__(256) void project_rows_kernel(const float *__restri
     const float *row = rows + ((int64_t)b * N + i) * (C2 + C3);
     const float *f2 = feat2d + (int64_t)b * C2 * HW + p;
     float s = 0.f;
-    for (int c = 0; c < C2; ++c) s += row[c] * f2[(int64_t)c * HW];
+    int c = 0;
+    for (; c + 4 <= C2; c += 4) {  // loads of four channels in flight; the sum keeps the reference's channel order
+        float r[4], f[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            r[u] = row[c + u];
+            f[u] = f2[(int64_t)(c + u) * HW];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += r[u] * f[u];
+    }
+    for (; c < C2; ++c) s += row[c] * f2[(int64_t)c * HW];
     o[2 * (int64_t)HW] = s / (float)C2;
-    for (int c = 0; c < C3; ++c) o[(int64_t)(3 + c) * HW] = row[C2 + c];
+    c = 0;
+    for (; c + 4 <= C3; c += 4) {
+        float r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) r[u] = row[C2 + c + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[(int64_t)(3 + c + u) * HW] = r[u];
+    }
+    for (; c < C3; ++c) o[(int64_t)(3 + c) * HW] = row[C2 + c];
 }
 
 int channel_split(int C, long items, int B);
