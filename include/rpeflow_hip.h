@@ -187,6 +187,11 @@ int rpe_dwconv3(const float *in0, int C0, const float *in1, int C1, const float 
                 float *out, rpe_stream_t stream);
 int rpe_channel_layernorm(const float *x, const float *weight, const float *bias, int B, int C, int64_t P,
                           float eps, float *out, rpe_stream_t stream);
+/* two tensors of one shape [B,C,P], each with its own affine parameters, in one launch: norm1x(x), norm1y(y) of the
+ * cross blocks (restormer_arch.py:218, 298) */
+int rpe_channel_layernorm_pair(const float *x0, const float *weight0, const float *bias0, float *out0,
+                               const float *x1, const float *weight1, const float *bias1, float *out1,
+                               int B, int C, int64_t P, float eps, rpe_stream_t stream);
 /* rpe_channel_attention_matrix: the attention core of Mutual_Attention{2D,3D}.forward (restormer_arch.py:184-203,
  *   265-282) up to and including project_out, as a per-batch C x C matrix (C = heads * c):
  *     attn_h = softmax_j( normalize(q_h) normalize(k_h)^T * temperature[h] ),  F.normalize over the P positions (eps),

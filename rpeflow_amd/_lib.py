@@ -31,6 +31,8 @@ _PROTOTYPES = {
     "rpe_dwconv3": [_c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                     _c_ptr, _c_ptr],
     "rpe_channel_layernorm": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_float, _c_ptr, _c_ptr],
+    "rpe_channel_layernorm_pair": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_float,
+                                   _c_ptr],
     "rpe_channel_attention_matrix": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_i64, _c_float,
                                      _c_ptr, _c_ptr, _c_ptr],
     "rpe_channel_attention_workspace_floats": [_c_int, _c_int, _c_int, _c_i64],

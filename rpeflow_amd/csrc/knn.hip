@@ -79,11 +79,10 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(
         const bool valid = pi < M;
         float p[3] = {0.f, 0.f, 0.f};
         if (valid) load_point<D>(inp, in_sn, in_sd, pi, p);
-        const float pp = rpe_sqnorm<D>(p);
+        const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;  // a lane past the end: p = 0, |p|^2 = +inf -> d = +inf for every query
 #pragma unroll
         for (int j = 0; j < QW; ++j) {
-            float d = rpe_pair_dist<D>(qs.qm2[j], qs.qq[j], p, pp);
-            d = valid ? d : INFINITY;
+            const float d = rpe_pair_dist<D>(qs.qm2[j], qs.qq[j], p, pp);
             unsigned long long m = __ballot(d < tau[j]);
             while (m) {  // wave-uniform: candidates in index order
                 const int l = __builtin_ctzll(m);
@@ -148,11 +147,11 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_nearest_kernel(
         const bool valid = pi < M;
         float p[3] = {0.f, 0.f, 0.f};
         if (valid) load_point<D>(inp, in_sn, in_sd, pi, p);
-        const float pp = rpe_sqnorm<D>(p);
+        const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;  // past the end: d = +inf, never taken
 #pragma unroll
         for (int j = 0; j < QW; ++j) {
             const float d = rpe_pair_dist<D>(qs.qm2[j], qs.qq[j], p, pp);
-            const bool take = valid && (d < bd[j]);  // strict: first index wins inside a lane
+            const bool take = d < bd[j];  // strict: first index wins inside a lane
             bd[j] = take ? d : bd[j];
             bi[j] = take ? pi : bi[j];
         }

@@ -137,10 +137,18 @@ __global__ __launch_bounds__(256) void dwconv3_strip_kernel(Segments seg, const 
 // 64 positions x 4 channel groups per workgroup: thread (pl, cg) keeps channels cg, cg+4, ... of its position in
 // registers (x is read once), the two reductions over the four groups (mean, then sum of squared deviations:
 // the exact two-pass variance) go through LDS.
+// Up to two independent tensors of one shape per launch (blockIdx.z): the cross blocks normalise x and y side by side.
+struct NormJobs {
+    const float *x[2], *weight[2], *bias[2];
+    float *out[2];
+};
+
 template <int CPT>  // channels per thread: C <= 4 * CPT
-__global__ __launch_bounds__(256) void channel_norm_kernel(const float *__restrict__ x, const float *__restrict__ weight,
-                                                           const float *__restrict__ bias, int C, int64_t P, float eps,
-                                                           float *__restrict__ out) {
+__global__ __launch_bounds__(256) void channel_norm_kernel(NormJobs jobs, int C, int64_t P, float eps) {
+    const float *__restrict__ x = jobs.x[blockIdx.z];
+    const float *__restrict__ weight = jobs.weight[blockIdx.z];
+    const float *__restrict__ bias = jobs.bias[blockIdx.z];
+    float *__restrict__ out = jobs.out[blockIdx.z];
     __shared__ float part[2][4][64];
     const int pl = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int64_t p = (int64_t)blockIdx.x * 64 + pl;
@@ -302,16 +310,13 @@ RPE_API int rpe_dwconv3(const float *in0, int C0, const float *in1, int C1, cons
     return rpe_launch_status();
 }
 
-RPE_API int rpe_channel_layernorm(const float *x, const float *weight, const float *bias, int B, int C, int64_t P, float eps,
-                                  float *out, rpe_stream_t stream) {
-    if (!x || !weight || !out || B < 0 || C < 1 || P < 0) return RPE_EINVAL;
+static int launch_layernorm(const NormJobs &jobs, int njobs, int B, int C, int64_t P, float eps, hipStream_t st) {
     if (B == 0 || P == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
     if (C > 4 * 64) return RPE_EUNSUPPORTED;
-    dim3 grid((unsigned)((P + 63) / 64), B), block(256);
-    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)((P + 63) / 64), B, njobs), block(256);
     const int cpt = (C + 3) / 4;
-#define RPE_LN(N) hipLaunchKernelGGL(channel_norm_kernel<N>, grid, block, 0, st, x, weight, bias, C, P, eps, out)
+#define RPE_LN(N) hipLaunchKernelGGL(channel_norm_kernel<N>, grid, block, 0, st, jobs, C, P, eps)
     if (cpt <= 8) RPE_LN(8);
     else if (cpt <= 16) RPE_LN(16);
     else if (cpt <= 24) RPE_LN(24);
@@ -320,6 +325,21 @@ RPE_API int rpe_channel_layernorm(const float *x, const float *weight, const flo
     else RPE_LN(64);
 #undef RPE_LN
     return rpe_launch_status();
+}
+
+RPE_API int rpe_channel_layernorm(const float *x, const float *weight, const float *bias, int B, int C, int64_t P, float eps,
+                                  float *out, rpe_stream_t stream) {
+    if (!x || !weight || !out || B < 0 || C < 1 || P < 0) return RPE_EINVAL;
+    NormJobs jobs{{x, x}, {weight, weight}, {bias, bias}, {out, out}};
+    return launch_layernorm(jobs, 1, B, C, P, eps, (hipStream_t)stream);
+}
+
+RPE_API int rpe_channel_layernorm_pair(const float *x0, const float *weight0, const float *bias0, float *out0, const float *x1,
+                                       const float *weight1, const float *bias1, float *out1, int B, int C, int64_t P, float eps,
+                                       rpe_stream_t stream) {
+    if (!x0 || !weight0 || !out0 || !x1 || !weight1 || !out1 || B < 0 || C < 1 || P < 0) return RPE_EINVAL;
+    NormJobs jobs{{x0, x1}, {weight0, weight1}, {bias0, bias1}, {out0, out1}};
+    return launch_layernorm(jobs, 2, B, C, P, eps, (hipStream_t)stream);
 }
 
 RPE_API int rpe_channel_affine_act(float *y, const float *scale, const float *shift, int B, int C, int64_t P, int act,

@@ -144,7 +144,14 @@ class _CrossTransformerBlock(nn.Module):
 
     def forward(self, x, y):
         assert x.shape == y.shape
-        x = self.attn(self.norm1x(x), self.norm1y(y), residual=x)
+        if x.is_cuda:  # both LayerNorms in one launch
+            from .restormer_ops import channel_layernorm_pair
+            nx, ny = self.norm1x.body, self.norm1y.body
+            nxo, nyo = channel_layernorm_pair(x, nx.weight, nx.bias if self.norm1x.with_bias else None,
+                                              y, ny.weight, ny.bias if self.norm1y.with_bias else None)
+        else:
+            nxo, nyo = self.norm1x(x), self.norm1y(y)
+        x = self.attn(nxo, nyo, residual=x)
         return x + self.ffn(self.norm2(x))
 
 

@@ -53,6 +53,23 @@ def channel_layernorm(x, weight, bias=None, eps=1e-5):
     return out
 
 
+def channel_layernorm_pair(x, wx, bx, y, wy, by, eps=1e-5):
+    """channel_layernorm of two same-shaped tensors with their own parameters in one launch."""
+    _lib.require_gpu(x, y, wx, wy, op="channel_layernorm_pair")
+    x, y = x.contiguous().float(), y.contiguous().float()
+    assert x.shape == y.shape and (bx is None) == (by is None)
+    B, C = x.shape[:2]
+    P = x.numel() // (B * C)
+    ox, oy = torch.empty_like(x), torch.empty_like(y)
+    f = lambda t: t.detach().contiguous().float() if t is not None else None
+    wx, bx, wy, by = f(wx), f(bx), f(wy), f(by)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().rpe_channel_layernorm_pair(_ptr(x), _ptr(wx), _ptr(bx), _ptr(ox), _ptr(y), _ptr(wy), _ptr(by), _ptr(oy),
+                                                   B, C, P, float(eps), _lib.stream_of(x))
+    _lib.check(rc, "channel_layernorm_pair")
+    return ox, oy
+
+
 def channel_affine_act_(y, scale, shift, act, slope=0.1):
     """In place on a contiguous [B,C,...] tensor: y = act(scale[c]*y + shift[c]); act in {None,'relu','leaky_relu'}."""
     _lib.require_gpu(y, op="channel_affine_act")

@@ -54,6 +54,17 @@ def test_channel_layernorm(shape):
     torch.testing.assert_close(channel_layernorm(x.to(DEV), w.to(DEV), None).cpu(), ref, rtol=1e-5, atol=2e-5)
 
 
+def test_channel_layernorm_pair():
+    from rpeflow_amd.restormer_ops import channel_layernorm_pair
+    torch.manual_seed(3)
+    x, y = torch.randn(2, 81, 9, 15).to(DEV), (torch.randn(2, 81, 9, 15) * 2 + 1).to(DEV)
+    wx, bx, wy, by = (torch.randn(81).to(DEV) for _ in range(4))
+    ox, oy = channel_layernorm_pair(x, wx, bx, y, wy, by)
+    assert torch.equal(ox, channel_layernorm(x, wx, bx)) and torch.equal(oy, channel_layernorm(y, wy, by))
+    ox, oy = channel_layernorm_pair(x, wx, None, y, wy, None)
+    assert torch.equal(ox, channel_layernorm(x, wx, None)) and torch.equal(oy, channel_layernorm(y, wy, None))
+
+
 @pytest.mark.parametrize("dims,norm,act", [(2, "batch_norm", "leaky_relu"), (1, None, "relu"), (2, None, None), (1, "batch_norm", None)])
 def test_conv_norm_relu_fused_epilogue(dims, norm, act):
     """Conv{1,2}dNormRelu on the GPU (bias + eval BatchNorm + activation fused) against the same module on the CPU."""
