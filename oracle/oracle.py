@@ -277,3 +277,24 @@ def correlation3d(params, xyz1, feat1, xyz2, feat2, knn_indices_1in1=None, k=16)
     w1 = _mlp_1x1(rel1, params, "weight_net1", 3, "relu")
     n2n = batch_indexing_channel_first(p2n, knn_indices_1in1)
     return np.sum(w1 * n2n, axis=3, dtype=np.float32)
+
+
+# --------------------------------------------------------------------------
+# event voxelisation (event_utils.py:109-128, 211-303; temporal_bilinear=True)
+# --------------------------------------------------------------------------
+def events_to_voxel(events, num_bins, height, width, event_polarity):
+    """events [N,4] float64 (x, y, t, polarity).  Restates eventsToXYTP(post_process=True) -> events_to_voxel_torch /
+    events_to_neg_pos_voxel_torch: float64 time normalisation, weights rounded to float32, accumulated per bin in event
+    order (np.add.at is sequential, like index_put_(accumulate=True) on the CPU)."""
+    ev = np.asarray(events, np.float64)
+    xs, ys, ps = ev[:, 0].astype(np.int32), ev[:, 1].astype(np.int32), ev[:, 3].astype(np.int32)
+    ts = (ev[:, 2] - ev[0, 2]) / ((ev[-1, 2] - ev[0, 2]) + 1e-6)
+    t_norm = (ts - ts[0]) / (ts[-1] - ts[0]) * (num_bins - 1)
+    grids = [np.where(ps > 0, 1.0, 0.0), np.where(ps <= 0, 1.0, 0.0)] if event_polarity else [ps.astype(np.float64)]
+    out = []
+    for wgt in grids:
+        for b in range(num_bins):
+            img = np.zeros((height, width), np.float32)
+            np.add.at(img, (ys, xs), (wgt * np.maximum(0.0, 1.0 - np.abs(t_norm - b))).astype(np.float32))
+            out.append(img)
+    return np.stack(out)

@@ -1,0 +1,58 @@
+// Event voxelisation on the device (event_utils.py:109-128 eventsToVoxel -> :211-262 events_to_voxel_torch with
+// temporal_bilinear=True, :264-303 the positive / negative split).  The reference does this
+// in the dataloader on the CPU, once per bin with index_put_(accumulate=True); here one launch handles all bins.
+//
+// To reproduce the reference's fp32 sums bit for bit the events arrive STABLY SORTED BY PIXEL (the host wrapper sorts
+// with torch): one thread owns one pixel and adds its events in their original order, exactly the order in which the
+// CPU's index_put_ accumulates them, so no atomics and no run-to-run variation.  The time normalisation is the
+// reference's two-step float64 arithmetic (eventsToXYTP :31-35, then :243-244); a weight max(0, 1 - |t - bin|) * p is
+// rounded to fp32 before it is added, as `.float()` does at :207.
+#include "common.h"
+
+namespace {
+
+// out [C][HW] zero-initialised, C = bins (signed polarity weights) or 2 * bins (positive grids, then negative grids)
+__global__ __launch_bounds__(256) void events_to_voxel_kernel(const int *__restrict__ pixel, const double *__restrict__ t,
+                                                              const int *__restrict__ pol, const int *__restrict__ run_start, int runs,
+                                                              int n_events, double t_first, double t_last, int bins, int split, int64_t HW,
+                                                              float *__restrict__ out) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= runs) return;
+    const int begin = run_start[u], end = u + 1 < runs ? run_start[u + 1] : n_events;
+    const int p = pixel[begin];
+    const double span = (t_last - t_first) + 1e-6;                // eventsToXYTP: (t - t0) / (deltaT + 1e-6)
+    const double te_last = (t_last - t_first) / span, te_first = (t_first - t_first) / span;
+    const double dt = te_last - te_first;                           // events_to_voxel_torch: dt = ts[-1] - ts[0]
+    for (int i = begin; i < end; ++i) {
+        const double te = (t[i] - t_first) / span;
+        const double tn = (te - te_first) / dt * (double)(bins - 1);  // t_norm, left to right as written at :244
+        const int b0 = (int)floor(tn);
+        const int sign = pol[i];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int b = b0 + k;
+            if (b < 0 || b >= bins) continue;
+            const double w = fmax(0.0, 1.0 - fabs(tn - (double)b));
+            if (split) {  // :296-297: positive grid takes p > 0, negative grid p <= 0, each with weight 1
+                float *o = out + (int64_t)(sign > 0 ? b : bins + b) * HW + p;
+                *o = *o + (float)(1.0 * w);
+            } else {
+                float *o = out + (int64_t)b * HW + p;
+                *o = *o + (float)((double)sign * w);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+RPE_API int rpe_events_to_voxel(const int *pixel_sorted, const double *t_sorted, const int *polarity_sorted, const int *run_start,
+                                int runs, int n_events, double t_first, double t_last, int bins, int split_polarity, int64_t HW,
+                                float *out, rpe_stream_t stream) {
+    if (!pixel_sorted || !t_sorted || !polarity_sorted || !run_start || !out || runs < 0 || n_events < 0 || bins < 1 || HW < 1)
+        return RPE_EINVAL;
+    if (runs == 0 || n_events == 0) return 0;
+    hipLaunchKernelGGL(events_to_voxel_kernel, dim3((runs + 255) / 256), dim3(256), 0, (hipStream_t)stream, pixel_sorted, t_sorted,
+                       polarity_sorted, run_start, runs, n_events, t_first, t_last, bins, split_polarity, HW, out);
+    return rpe_launch_status();
+}

@@ -134,3 +134,21 @@ def block_inputs(name):
     feat1 = r.standard_normal((c["B"], c["C"], c["N"]), dtype=np.float32)
     feat2 = r.standard_normal((c["B"], c["C"], c["N"]), dtype=np.float32)
     return dict(xyz1=xyz1, xyz2=xyz2, feat1=feat1, feat2=feat2)
+
+
+# event voxelisation (event_utils.eventsToVoxel): (N events, H, W, bins, polarity split, seed)
+EVENT_CASES = {
+    "events_5000_24x40_b5": (5000, 24, 40, 5, False, 601),
+    "events_20000_36x60_b10_pol": (20000, 36, 60, 10, True, 602),
+    "events_300_9x15_b1_pol": (300, 9, 15, 1, True, 603),
+}
+
+
+def event_inputs(name):
+    """[N,4] float64 (x, y, t, polarity) in time order: microsecond-like timestamps with repeats, polarity in {0, 1}."""
+    n, H, W, bins, pol, seed = EVENT_CASES[name]
+    r = I.rng(seed)
+    t = np.sort(r.integers(1_000_000, 1_050_000, n)).astype(np.float64)
+    ev = np.stack([r.integers(0, W, n).astype(np.float64), r.integers(0, H, n).astype(np.float64), t,
+                   r.integers(0, 2, n).astype(np.float64)], axis=1)
+    return ev, H, W, bins, pol

@@ -91,6 +91,26 @@ def gen_glue():
     save("glue_ops", **{k: v.numpy() for k, v in out.items()})
 
 
+def gen_events():
+    # event_utils.py imports h5py and cv2 at module level (HDF5 loading, visualisation: :11-20, :306-440); neither is
+    # installed here and neither is touched by eventsToVoxel, which is numpy + torch only.  Empty placeholder modules
+    # satisfy the import statements; the function under test runs unmodified.
+    import types
+    if "h5py" not in sys.modules:
+        sys.modules["h5py"] = types.ModuleType("h5py")
+    if "cv2" not in sys.modules:
+        cv2 = types.ModuleType("cv2")
+        cv2.setNumThreads = lambda n: None
+        cv2.ocl = types.SimpleNamespace(setUseOpenCL=lambda flag: None)
+        sys.modules["cv2"] = cv2
+    with contextlib.redirect_stdout(io.StringIO()):
+        import event_utils as ref_events
+    for name in K.EVENT_CASES:
+        ev, H, W, bins, pol = K.event_inputs(name)
+        vox = ref_events.eventsToVoxel(ev.copy(), num_bins=bins, height=H, width=W, event_polarity=pol, temporal_bilinear=True)
+        save(name, voxel=np.asarray(vox, np.float32))
+
+
 def load_params(module, seed):
     shapes = [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
     params = I.fill_params(shapes, seed)
@@ -175,6 +195,6 @@ def gen_model_dsec():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec"]
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "events"]
     for w in which:
         globals()["gen_" + w]()

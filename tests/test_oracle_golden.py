@@ -109,3 +109,9 @@ def test_correlation3d(golden_dir):
     p = I.fill_params(_shapes_corr3d(c["C"]), c["seed"] + 1000)
     out = O.correlation3d(p, x["xyz1"], x["feat1"], x["xyz2"], x["feat2"], k=c["k"])
     np.testing.assert_allclose(out, G(golden_dir, "correlation3d")["out"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", list(K.EVENT_CASES))
+def test_events_to_voxel(golden_dir, name):
+    ev, H, W, bins, pol = K.event_inputs(name)
+    assert_bits_equal(O.events_to_voxel(ev, bins, H, W, pol), G(golden_dir, name)["voxel"], name)
