@@ -239,7 +239,8 @@ def main():
                 eager_out = {k: v.clone() for k, v in out.items()}
                 with torch.cuda.graph(graph):
                     out = model(batch)
-                graph.replay()
+                for _ in range(max(args.warmup, 1)):  # untimed replays: graph upload, clocks back up after the capture
+                    graph.replay()
                 torch.cuda.synchronize()
                 fwd_step, launch = graph.replay, "one HIP graph per forward"
             except Exception as e:  # noqa: BLE001 -- capture is an optimisation, not a requirement

@@ -385,8 +385,7 @@ def resize_flow2d(flow, target_h, target_w):
     if (h, w) == (target_h, target_w):
         return flow
     flow = F.interpolate(flow, size=(target_h, target_w), mode="bilinear", align_corners=True)
-    flow[:, 0] *= target_w / w
-    flow[:, 1] *= target_h / h
+    flow *= _pair_scale(target_w / w, target_h / h, flow)
     return flow
 
 
@@ -403,6 +402,19 @@ def convex_upsample(flow, mask, scale_factor=8):
 
 
 # ------------------------------------------------------------------ the core (RPEFlow_core.py:165-432)
+_pair_scale_cache = {}
+
+
+def _pair_scale(a, b, like):
+    """[1,2,1(,1)] tensor (a, b) on like's device, cached: x[:, :2] * _pair_scale(...) scales the two flow channels by
+    different factors in one launch.  (Created on the first, eager forward; graph capture then finds it resident.)"""
+    key = (float(a), float(b), like.dim(), like.device)
+    t = _pair_scale_cache.get(key)
+    if t is None:
+        t = _pair_scale_cache[key] = torch.tensor([a, b], dtype=torch.float32, device=like.device).view([1, 2] + [1] * (like.dim() - 2))
+    return t
+
+
 class StampTrace:
     """Timeline of a multi-stream forward: stamp(name) drops a one-thread kernel on the current stream that stores the
     GPU wall clock (rpe_debug_stamp).  Works inside a captured HIP graph: every replay refreshes the values.  Set
@@ -538,8 +550,7 @@ class RPEFlow_core(nn.Module):
         def fuse_level(level):
             image_h, image_w = feats_2d_both[level].shape[2:]
             xy_both = project_pc2image(torch.cat([xyzs1[level], xyzs2[level]], dim=0), camera_both)
-            xy_both[:, 0] *= (image_w - 1) / (sensor_w - 1)
-            xy_both[:, 1] *= (image_h - 1) / (sensor_h - 1)
+            xy_both *= _pair_scale((image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1), xy_both)
             grid = mesh_grid(2 * batch_size, image_h, image_w, xy_both.device).reshape(2 * batch_size, 2, -1)
             nn_proj_both = k_nearest_neighbor(xy_both, grid, k=1)
             knn_1in1 = k_nearest_neighbor(xyzs1[level], xyzs1[level], k=k)
@@ -595,7 +606,7 @@ class RPEFlow_core(nn.Module):
                 xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
                 _stamp("side L%d stage1 backwarp done" % level)
             feat_corr_3d = self.correlations_3d[level](xyz1, fused_3d[:batch_size], xyz2_warp, fused_3d[batch_size:], knn_1in1)
-            last_flow_3d_to_2d = torch.cat([last_flow_3d[:, 0:1] * sx, last_flow_3d[:, 1:2] * sy], dim=1)
+            last_flow_3d_to_2d = last_flow_3d[:, :2] * _pair_scale(sx, sy, last_flow_3d)  # (:371-372) one launch, not mul, mul, cat
             _stamp("side L%d stage1 done" % level)
             return last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d
 
@@ -622,8 +633,7 @@ class RPEFlow_core(nn.Module):
                 feat_corr_2d = correlation2d_fused_leaky(feat1_2d, feat2_2d_warp, md, 0, leaky_slope=0.1)
             else:
                 feat_corr_2d = F.leaky_relu(correlation2d(feat1_2d, feat2_2d_warp, md), 0.1)
-            last_flow_2d_to_3d = torch.cat([last_flow_2d[:, 0:1] * ((sensor_w - 1) / (image_w - 1)),
-                                            last_flow_2d[:, 1:2] * ((sensor_h - 1) / (image_h - 1))], dim=1)
+            last_flow_2d_to_3d = last_flow_2d * _pair_scale((sensor_w - 1) / (image_w - 1), (sensor_h - 1) / (image_h - 1), last_flow_2d)
             _stamp("main L%d stage1 done" % level)
             br.join(out_s1)
             last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d = out_s1
