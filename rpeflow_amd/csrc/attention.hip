@@ -62,24 +62,55 @@ __global__ __launch_bounds__(256) void attn_gram_kernel(const float *__restrict_
         sk[j] = 0.f;
         acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    for (int64_t gs = p0 + wave * 16; gs < pend; gs += 64) {  // wave-uniform trip count: every lane joins the MFMAs
-        const int64_t p = gs + grp * 4;
-        const float4 a = load_row4<VEC>(qh, ti * 16 + row, c, P, p, pend);
-        float4 bb[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) bb[t] = load_row4<VEC>(kh, t * 16 + row, c, P, p, pend);
+    auto accumulate = [&](const float4 &a, const float4 (&bb)[T]) {
         sq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
         if (k_norms) {
 #pragma unroll
             for (int t = 0; t < T; ++t) sk[t] += (bb[t].x * bb[t].x + bb[t].y * bb[t].y) + (bb[t].z * bb[t].z + bb[t].w * bb[t].w);
         }
+        // position phase outermost: consecutive MFMAs write different accumulators (40-cycle dependent latency)
 #pragma unroll
-        for (int j = 0; j < T; ++j) {
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb[j].x, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb[j].y, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb[j].z, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb[j].w, acc[j], 0, 0, 0);
+        for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb[j].w, acc[j], 0, 0, 0);
+    };
+    int64_t gs = p0 + wave * 16;  // wave-uniform trip counts below: every lane joins the MFMAs
+    if (VEC) {
+        // Full 16-position groups, no guards: a row beyond the head's channels reads the last valid row instead (its gram
+        // rows / columns and norms are never stored); the next group's loads are issued before this group's MFMAs.
+        const float *qrow = qh + (int64_t)min(ti * 16 + row, c - 1) * P + grp * 4;
+        const float *krow[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) krow[t] = kh + (int64_t)min(t * 16 + row, c - 1) * P + grp * 4;
+        if (gs + 16 <= pend) {
+            float4 a = *reinterpret_cast<const float4 *>(qrow + gs), bb[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) bb[t] = *reinterpret_cast<const float4 *>(krow[t] + gs);
+            for (; gs + 64 + 16 <= pend; gs += 64) {
+                const float4 na = *reinterpret_cast<const float4 *>(qrow + gs + 64);
+                float4 nb[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) nb[t] = *reinterpret_cast<const float4 *>(krow[t] + gs + 64);
+                accumulate(a, bb);
+                a = na;
+#pragma unroll
+                for (int t = 0; t < T; ++t) bb[t] = nb[t];
+            }
+            accumulate(a, bb);
+            gs += 64;
         }
+    }
+    for (; gs < pend; gs += 64) {  // the chunk's ragged end (and everything when rows are not 16-byte aligned)
+        const int64_t p = gs + grp * 4;
+        const float4 a = load_row4<VEC>(qh, ti * 16 + row, c, P, p, pend);
+        float4 bb[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) bb[t] = load_row4<VEC>(kh, t * 16 + row, c, P, p, pend);
+        accumulate(a, bb);
     }
     // norms: add the four position groups of the wave (lanes l, l^16, l^32, l^48 share a row)
     sq += __shfl_xor(sq, 16);
