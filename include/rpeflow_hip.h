@@ -57,6 +57,20 @@ int rpe_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd,
             int B, int M, int Q, int D, int k,
             int64_t *idx, float *dist, rpe_stream_t stream);
 
+/* Several searches with the same (B, D, k) in ONE launch: job i is rpe_knn(jobs[i]...) exactly.  The PointConv pyramid's
+ * per-level searches (pointconv.py:46) depend on the sampled coordinates only and are issued together.            */
+#define RPE_KNN_MAX_JOBS 8
+typedef struct rpe_knn_job {
+    const float *input;
+    int64_t in_sb, in_sn, in_sd;   /* element strides: batch, point, dimension */
+    const float *query;
+    int64_t q_sb, q_sn, q_sd;
+    int M, Q;
+    int64_t *idx;                   /* [B,Q,k] */
+    float *dist;                    /* [B,Q,k] or NULL */
+} rpe_knn_job;
+int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, rpe_stream_t stream);
+
 /* ---- squared_distance (wrapper.py:40-52) ------------------------------------
  * out[b][i][j] = distance above between xyz1[b][i] and xyz2[b][j]; out contiguous. */
 int rpe_squared_distance(const float *xyz1, int64_t a_sb, int64_t a_sn, int64_t a_sd,

@@ -46,6 +46,7 @@ _PROTOTYPES = {
                                 _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                                 _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_correlation2d_backward": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
+    "rpe_knn_multi": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr],
     "rpe_debug_set_fps_variant": [_c_int],
     "rpe_debug_stamp": [_c_ptr, _c_ptr],
     "rpe_gather_channel_first": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
@@ -61,6 +62,13 @@ _PROTOTYPES = {
 }
 
 _lib = None
+
+
+class KnnJob(ctypes.Structure):
+    """rpe_knn_job of include/rpeflow_hip.h."""
+    _fields_ = [("input", ctypes.c_void_p), ("in_sb", ctypes.c_int64), ("in_sn", ctypes.c_int64), ("in_sd", ctypes.c_int64),
+                ("query", ctypes.c_void_p), ("q_sb", ctypes.c_int64), ("q_sn", ctypes.c_int64), ("q_sd", ctypes.c_int64),
+                ("M", ctypes.c_int), ("Q", ctypes.c_int), ("idx", ctypes.c_void_p), ("dist", ctypes.c_void_p)]
 
 
 class HipLibraryMissing(RuntimeError):

@@ -48,12 +48,23 @@ struct Queries {
     }
 };
 
+// Several independent searches of one (B, D, k) in one launch: blockIdx.z picks the job.  The PointConv pyramid's five
+// neighbour searches depend on the sampled coordinates only (pointconv.py:46 per level); launched together, the small
+// levels fill the CUs the big one leaves idle instead of queueing behind it.
+struct KnnJobs {
+    rpe_knn_job job[RPE_KNN_MAX_JOBS];
+};
+
 // ---- k >= 2: cross-lane sorted list ----------------------------------------
 template <int D, int QW>
-__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(
-    const float *__restrict__ inp, int64_t in_sb, int64_t in_sn, int64_t in_sd,
-    const float *__restrict__ qry, int64_t q_sb, int64_t q_sn, int64_t q_sd,
-    int M, int Q, int k, int64_t *__restrict__ idx, float *__restrict__ dist) {
+__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(KnnJobs jobs, int k) {
+    const rpe_knn_job &J = jobs.job[blockIdx.z];
+    const float *__restrict__ inp = J.input;
+    const float *__restrict__ qry = J.query;
+    const int64_t in_sb = J.in_sb, in_sn = J.in_sn, in_sd = J.in_sd, q_sb = J.q_sb, q_sn = J.q_sn, q_sd = J.q_sd;
+    const int M = J.M, Q = J.Q;
+    int64_t *__restrict__ idx = J.idx;
+    float *__restrict__ dist = J.dist;
     const int lane = rpe_lane();
     const int wave = rpe_uniform((int)(threadIdx.x >> 6));
     const int b = blockIdx.y;
@@ -119,10 +130,14 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(
 
 // ---- k == 1: lane-local minimum ----------------------------------------------
 template <int D, int QW>
-__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_nearest_kernel(
-    const float *__restrict__ inp, int64_t in_sb, int64_t in_sn, int64_t in_sd,
-    const float *__restrict__ qry, int64_t q_sb, int64_t q_sn, int64_t q_sd,
-    int M, int Q, int64_t *__restrict__ idx, float *__restrict__ dist) {
+__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_nearest_kernel(KnnJobs jobs) {
+    const rpe_knn_job &J = jobs.job[blockIdx.z];
+    const float *__restrict__ inp = J.input;
+    const float *__restrict__ qry = J.query;
+    const int64_t in_sb = J.in_sb, in_sn = J.in_sn, in_sd = J.in_sd, q_sb = J.q_sb, q_sn = J.q_sn, q_sd = J.q_sd;
+    const int M = J.M, Q = J.Q;
+    int64_t *__restrict__ idx = J.idx;
+    float *__restrict__ dist = J.dist;
     const int lane = rpe_lane();
     const int wave = rpe_uniform((int)(threadIdx.x >> 6));
     const int b = blockIdx.y;
@@ -202,54 +217,55 @@ int pick_qw(int B, int Q) {
 }
 
 template <int D, int QW>
-void launch_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,
-                int64_t q_sn, int64_t q_sd, int B, int M, int Q, int k, int64_t *idx, float *dist, hipStream_t st) {
+void launch_knn(const KnnJobs &jobs, int njobs, int max_q, int B, int k, hipStream_t st) {
     const int per_block = kWavesPerBlock * QW;
-    dim3 grid((Q + per_block - 1) / per_block, B), block(kWavesPerBlock * RPE_WAVE);
-    if (k == 1)
-        hipLaunchKernelGGL((knn_nearest_kernel<D, QW>), grid, block, 0, st, input, in_sb, in_sn, in_sd, query, q_sb,
-                           q_sn, q_sd, M, Q, idx, dist);
-    else
-        hipLaunchKernelGGL((knn_select_kernel<D, QW>), grid, block, 0, st, input, in_sb, in_sn, in_sd, query, q_sb,
-                           q_sn, q_sd, M, Q, k, idx, dist);
+    dim3 grid((max_q + per_block - 1) / per_block, B, njobs), block(kWavesPerBlock * RPE_WAVE);
+    if (k == 1) hipLaunchKernelGGL((knn_nearest_kernel<D, QW>), grid, block, 0, st, jobs);
+    else hipLaunchKernelGGL((knn_select_kernel<D, QW>), grid, block, 0, st, jobs, k);
 }
 
 template <int D>
-void launch_knn_d(int qw, const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query,
-                  int64_t q_sb, int64_t q_sn, int64_t q_sd, int B, int M, int Q, int k, int64_t *idx, float *dist,
-                  hipStream_t st) {
-#define RPE_KNN_CASE(W)                                                                                       \
-    case W:                                                                                                   \
-        launch_knn<D, W>(input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, B, M, Q, k, idx, dist, st);     \
-        break;
+void launch_knn_d(int qw, const KnnJobs &jobs, int njobs, int max_q, int B, int k, hipStream_t st) {
     switch (qw) {
-        RPE_KNN_CASE(1)
-        RPE_KNN_CASE(2)
-        RPE_KNN_CASE(4)
-        RPE_KNN_CASE(8)
+        case 1: launch_knn<D, 1>(jobs, njobs, max_q, B, k, st); break;
+        case 2: launch_knn<D, 2>(jobs, njobs, max_q, B, k, st); break;
+        case 4: launch_knn<D, 4>(jobs, njobs, max_q, B, k, st); break;
+        default: launch_knn<D, 8>(jobs, njobs, max_q, B, k, st); break;
     }
-#undef RPE_KNN_CASE
 }
 
 }  // namespace
+
+RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, rpe_stream_t stream) {
+    if (!jobs || njobs < 1 || njobs > RPE_KNN_MAX_JOBS || B < 0 || D < 1 || D > 3 || k < 1) return RPE_EINVAL;
+    if (k > RPE_WAVE) return RPE_EUNSUPPORTED;
+    if (B > 65535) return RPE_EUNSUPPORTED;
+    KnnJobs packed;
+    int max_q = 0;
+    long total_q = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const rpe_knn_job &j = jobs[i];
+        if (!j.input || !j.query || !j.idx || j.M <= 0 || j.Q < 0 || k > j.M) return RPE_EINVAL;
+        packed.job[i] = j;
+        max_q = j.Q > max_q ? j.Q : max_q;
+        total_q += j.Q;
+    }
+    if (B == 0 || max_q == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int qw = pick_qw(B, (int)total_q);
+    if (D == 3) launch_knn_d<3>(qw, packed, njobs, max_q, B, k, st);
+    else if (D == 2) launch_knn_d<2>(qw, packed, njobs, max_q, B, k, st);
+    else launch_knn_d<1>(qw, packed, njobs, max_q, B, k, st);
+    return rpe_launch_status();
+}
 
 RPE_API int rpe_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,
                     int64_t q_sn, int64_t q_sd, int B, int M, int Q, int D, int k, int64_t *idx, float *dist,
                     rpe_stream_t stream) {
     if (!input || !query || !idx || B < 0 || M <= 0 || Q < 0 || D < 1 || D > 3) return RPE_EINVAL;
     if (k < 1 || k > M) return RPE_EINVAL;
-    if (k > RPE_WAVE) return RPE_EUNSUPPORTED;
-    if (B > 65535) return RPE_EUNSUPPORTED;
-    if (B == 0 || Q == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    const int qw = pick_qw(B, Q);
-    if (D == 3)
-        launch_knn_d<3>(qw, input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, B, M, Q, k, idx, dist, st);
-    else if (D == 2)
-        launch_knn_d<2>(qw, input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, B, M, Q, k, idx, dist, st);
-    else
-        launch_knn_d<1>(qw, input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, B, M, Q, k, idx, dist, st);
-    return rpe_launch_status();
+    const rpe_knn_job job{input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, M, Q, idx, dist};
+    return rpe_knn_multi(&job, 1, B, D, k, stream);
 }
 
 RPE_API int rpe_squared_distance(const float *xyz1, int64_t a_sb, int64_t a_sn, int64_t a_sd, const float *xyz2,

@@ -147,6 +147,34 @@ def k_nearest_neighbor(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int,
     return idx
 
 
+def k_nearest_neighbor_multi(pairs, k: int):
+    """[(input_xyz, query_xyz), ...] with one batch size, dimension and k -> [idx, ...], each exactly
+    k_nearest_neighbor(input_xyz, query_xyz, k), from ONE launch (at most 8 pairs)."""
+    jobs, outs, keep = (_lib.KnnJob * len(pairs))(), [], []
+    B = D = None
+    for i, (inp, qry) in enumerate(pairs):
+        _as_points(inp, "k_nearest_neighbor", "input_xyz")
+        _as_points(qry, "k_nearest_neighbor", "query_xyz")
+        if inp.shape[1] <= 3:
+            inp, qry = inp.transpose(1, 2), qry.transpose(1, 2)
+        _lib.require_gpu(inp, qry, op="k_nearest_neighbor")
+        if B is None:
+            B, D = inp.shape[0], inp.shape[2]
+        if inp.shape[0] != B or qry.shape[0] != B or inp.shape[2] != D or qry.shape[2] != D:
+            raise RuntimeError("k_nearest_neighbor_multi: all pairs must share batch size and dimension")
+        if k > inp.shape[1]:
+            raise RuntimeError("selected index k out of range")
+        idx = torch.empty((B, qry.shape[1], k), dtype=torch.int64, device=inp.device)
+        jobs[i] = _lib.KnnJob(inp.data_ptr(), *inp.stride(), qry.data_ptr(), *qry.stride(), inp.shape[1], qry.shape[1],
+                              idx.data_ptr(), None)
+        outs.append(idx)
+        keep += [inp, qry]
+    with torch.cuda.device(outs[0].device):
+        rc = _lib.lib().rpe_knn_multi(ctypes.byref(jobs), len(pairs), B, D, int(k), _lib.stream_of(outs[0]))
+    _lib.check(rc, "k_nearest_neighbor_multi")
+    return outs
+
+
 def k_nearest_neighbor_with_distances(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int):
     """k_nearest_neighbor plus the sorted squared distances the kernel selected on
     (what ``squared_distance(query, input).topk(k, largest=False).values`` holds)."""

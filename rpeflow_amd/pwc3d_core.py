@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from .csrc import furthest_point_sampling, k_nearest_neighbor
+from .csrc.wrapper import k_nearest_neighbor_multi
 from .pointconv import PointConvDownSampling, PointConvNoSampling
 from .utils import MLP1d, MLP2d, batch_indexing_channel_first
 
@@ -47,9 +48,11 @@ class FeaturePyramid3D(nn.Module):
 
     def forward(self, xyzs):
         assert len(xyzs) == len(self.pyramid_mlps) + 1
+        # the layers' neighbour searches (pointconv.py:46) need the coordinates only: all levels in one launch up front
+        knns = k_nearest_neighbor_multi([(xyzs[i], xyzs[i + 1]) for i in range(len(xyzs) - 1)], self.pyramid_convs[0].k)
         feats = [self.level0_mlp(torch.zeros_like(xyzs[0]))]
         for i in range(len(xyzs) - 1):
-            feats.append(self.pyramid_convs[i](xyzs[i], self.pyramid_mlps[i](feats[-1]), xyzs[i + 1]))
+            feats.append(self.pyramid_convs[i](xyzs[i], self.pyramid_mlps[i](feats[-1]), xyzs[i + 1], knn_indices=knns[i]))
         return feats
 
 

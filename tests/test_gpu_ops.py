@@ -275,3 +275,17 @@ def test_correlation_full_size_properties():
     full = W._correlation2d_algo(a, b, 4, 2)
     for algo in DMA_ALGOS:
         assert (full - W._correlation2d_algo(a, b, 4, algo)).abs().max().item() < 5e-6, algo
+
+
+def test_knn_multi_equals_separate_calls():
+    """rpe_knn_multi: the pyramid's five searches in one launch give exactly the five separate results."""
+    r = I.rng(8800)
+    cloud = I.ids_cloud(r, 3, 2048)
+    levels = [dev(cloud[:, :n].copy()) for n in (2048, 1024, 512, 100, 37)]
+    pairs = [(levels[i], levels[i + 1]) for i in range(4)]
+    got = W.k_nearest_neighbor_multi(pairs, 16)
+    for (inp, qry), g in zip(pairs, got):
+        assert torch.equal(g, ops.k_nearest_neighbor(inp, qry, 16))
+    cf = [(a.transpose(1, 2).contiguous(), b.transpose(1, 2).contiguous()) for a, b in pairs]  # channel-first layout, k = 1 kernel
+    for (inp, qry), g in zip(cf, W.k_nearest_neighbor_multi(cf, 1)):
+        assert torch.equal(g, ops.k_nearest_neighbor(inp, qry, 1))
