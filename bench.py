@@ -99,6 +99,14 @@ def corr_microbench(dev, iters=30):
             "algorithmic_bytes": alg, "workload": "correlation2d 1x256x544x960 md=4 fp32 NCHW (BASELINE config 2)"}
 
 
+def pmc_traffic(suffix):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process)."""
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith(suffix):
+            return int(json.load(open(os.path.join(ROOT, "profiles", name)))["derived"]["hbm_traffic_bytes"])
+    return None
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask, capped by a cgroup CPU quota if there is one
     (os.cpu_count() reports the host's cores even inside a quota-limited container)."""
@@ -274,7 +282,8 @@ def main():
                        "sharding": f"frame pairs over {world} rank(s), no data-path collective",
                        "launch": launch},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None, "us_per_launch": round(dom_us, 1),
+                         "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("fps_pmc.json") if dom == "fps+pyramid" else None,
+                         "us_per_launch": round(dom_us, 1),
                          "launches_per_step": single[dom][1] // args.steps,
                          **({"note": "FPS is bound by the latency of 4095 DEPENDENT sampling iterations per cloud (SURVEY.md 8d), "
                                      "one workgroup per cloud on 2B of 256 CUs, not by HBM or MFMA: the HBM fraction is reported for "
