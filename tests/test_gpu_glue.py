@@ -180,3 +180,19 @@ def test_events_to_voxel_edge_cases():
     assert np.array_equal(got.view(np.uint32), O.events_to_voxel(ev, 4, 3, 7, False).view(np.uint32))  # signed polarity weights
     with pytest.raises(IndexError):
         events_to_voxel(torch.tensor([[9.0, 0.0, 0.0, 1.0], [0.0, 0.0, 1.0, 1.0]], dtype=torch.float64, device="cuda:0"), 2, 3, 7)
+
+
+def test_events_to_voxel_full_size_conservation():
+    """One million events on a 540x960 sensor: every event spreads a total weight of exactly 1 over two neighbouring time
+    bins of its polarity grid, so grid sums count the events (up to fp32 summation error), and each event lands in its pixel."""
+    from rpeflow_amd.event_ops import events_to_voxel
+    r = I.rng(91)
+    n, H, W, bins = 1_000_000, 540, 960, 10
+    ev = np.stack([r.integers(0, W, n), r.integers(0, H, n), np.sort(r.integers(0, 50_000, n)), r.integers(0, 2, n)], 1).astype(np.float64)
+    vox = events_to_voxel(torch.from_numpy(ev).to("cuda:0"), num_bins=bins, height=H, width=W, event_polarity=True)
+    assert vox.shape == (2 * bins, H, W) and bool((vox >= 0).all())
+    pos, neg = float(vox[:bins].double().sum()), float(vox[bins:].double().sum())
+    n_pos = int((ev[:, 3] > 0).sum())
+    assert abs(pos - n_pos) < 1e-3 * n and abs(neg - (n - n_pos)) < 1e-3 * n
+    per_pixel = torch.zeros(H * W, dtype=torch.float64).index_add_(0, torch.from_numpy((ev[:, 1] * W + ev[:, 0]).astype(np.int64)), torch.ones(n, dtype=torch.float64))
+    assert float((vox.double().sum(0).cpu().reshape(-1) - per_pixel).abs().max()) < 1e-3
