@@ -118,9 +118,9 @@ class Correlation3D(nn.Module):
                                        batch_size, c_out, n_points, m_points, 0.1, _ptr(hidden), stream)
         _lib.check(rc, "Correlation3D (hidden)")
         # second cost_mlp layer: one GEMM over all (point, neighbour) pairs, then leaky_relu(0.1)
-        p2p_cost = torch.baddbmm(w["b_second"][None, :, None], w["w_second"][None].expand(batch_size, -1, -1),
-                                 hidden.view(batch_size, c_out, -1))
-        p2p_cost = torch.nn.functional.leaky_relu(p2p_cost, 0.1, inplace=True)
+        from .restormer_ops import channel_affine_act_
+        p2p_cost = torch.matmul(w["w_second"], hidden.view(batch_size, c_out, -1))
+        p2p_cost = channel_affine_act_(p2p_cost, None, w["b_second"], "leaky_relu", 0.1)  # bias + leaky_relu in one in-place pass
 
         p2n_cost = torch.empty((batch_size, c_out, n_points), dtype=torch.float32, device=xyz1.device)
         with torch.cuda.device(xyz1.device):
