@@ -41,10 +41,10 @@ def furthest_point_sampling(xyz, n_samples, cpp_impl=True):
     """wrapper.py:75-103, CPU branch: n_samples iterations of ~6 small tensor ops."""
     assert xyz.shape[2] == 3 and xyz.shape[1] > n_samples
     b, n, _ = xyz.shape
-    picked = torch.zeros(b, n_samples, dtype=torch.int64)
-    dist = torch.full((b, n), 1e10)
-    rows = torch.arange(b)
-    cur = torch.zeros(b, dtype=torch.int64)
+    picked = torch.zeros(b, n_samples, dtype=torch.int64, device=xyz.device)
+    dist = torch.full((b, n), 1e10, device=xyz.device)
+    rows = torch.arange(b, device=xyz.device)
+    cur = torch.zeros(b, dtype=torch.int64, device=xyz.device)
     for i in range(n_samples):
         picked[:, i] = cur
         centre = xyz[rows, cur, :].view(b, 1, 3)
@@ -79,7 +79,7 @@ def batch_indexing_channel_first(data, indices):
 def batch_indexing_channel_last(data, indices):
     """utils.py:101-116: advanced indexing with a broadcast batch index."""
     b = data.shape[0]
-    bidx = torch.arange(b).view([b] + [1] * (indices.dim() - 1)).expand(indices.shape)
+    bidx = torch.arange(b, device=indices.device).view([b] + [1] * (indices.dim() - 1)).expand(indices.shape)
     return data[bidx, indices.to(torch.long)] if data.dim() == 2 else data[bidx, indices.to(torch.long), :]
 
 
@@ -99,16 +99,16 @@ def backwarp_3d(xyz1, xyz2, flow12, k=3):
     return xyz2 + knn_interpolation(xyz1 + flow12, -flow12, xyz2, k)
 
 
-def _pixel_grid(b, h, w):
-    xs = torch.arange(w, dtype=torch.float32)[None, None, :].expand(b, h, w)
-    ys = torch.arange(h, dtype=torch.float32)[None, :, None].expand(b, h, w)
+def _pixel_grid(b, h, w, device=None):
+    xs = torch.arange(w, dtype=torch.float32, device=device)[None, None, :].expand(b, h, w)
+    ys = torch.arange(h, dtype=torch.float32, device=device)[None, :, None].expand(b, h, w)
     return torch.stack([xs, ys], 1)
 
 
 def backwarp_2d(x, flow12, padding_mode):
     """utils.py:186-198: normalise (pixel + flow) to [-1,1], F.grid_sample."""
     b, _, h, w = x.shape
-    g = _pixel_grid(b, h, w) + flow12
+    g = _pixel_grid(b, h, w, flow12.device) + flow12
     gn = torch.zeros_like(g)
     gn[:, 0] = 2.0 * g[:, 0] / (w - 1) - 1.0
     gn[:, 1] = 2.0 * g[:, 1] / (h - 1) - 1.0
@@ -128,7 +128,7 @@ def grid_sample_wrapper(feat_2d, xy):
 def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None):
     """utils.py:297-317."""
     b, _, h, w = feat_2d.shape
-    grid = _pixel_grid(b, h, w).reshape(b, 2, -1)
+    grid = _pixel_grid(b, h, w, xy.device).reshape(b, 2, -1)
     if nn_indices is None:
         nn_indices = k_nearest_neighbor(xy, grid, k=1)[..., 0]
     f2 = batch_indexing_channel_first(grid_sample_wrapper(feat_2d, xy), nn_indices)
@@ -210,7 +210,7 @@ def build_pc_pyramid(pc1, pc2, n_samples_list):
     b, _, n = pc1.shape
     both = furthest_point_sampling(torch.cat([pc1, pc2], 0).transpose(1, 2), max(n_samples_list))
     s1, s2 = both[:b], both[b:]
-    lv0 = torch.arange(n)[None, :].expand(b, n)
+    lv0 = torch.arange(n, device=pc1.device)[None, :].expand(b, n)
     xyzs1, xyzs2, idx1, idx2 = [pc1], [pc2], [lv0], [lv0]
     for m in n_samples_list:
         idx1.append(s1[:, :m])

@@ -699,7 +699,10 @@ class RPEFlow(nn.Module):
     """models/RPEFlow.py:9-99, inference branch: forward(inputs) -> {'flow_2d', 'flow_3d'}.
 
     ``ids_on_host``: compute the IDS transform (log/div of 2*B*3*N floats) on the CPU, as the
-    reference's CPU path does, so that FPS/KNN see bit-identical coordinates."""
+    reference's CPU path does, so that FPS/KNN see bit-identical coordinates -- bit-identical to a
+    reference run ON THE SAME HOST: torch.log differs by an ulp between CPU models.  An ``inputs["pcs_ids"]`` entry
+    ([B,6,N], both clouds already transformed) bypasses the transform; the parity tests feed the reference's own
+    coordinates that way."""
 
     def __init__(self, cfgs=None, ids_on_host=False, ops=None):
         """``ops``: namespace of hot-path callables/classes (rpeflow_amd.hotpath.OP_NAMES); default = this
@@ -734,7 +737,9 @@ class RPEFlow(nn.Module):
             div = self.cfgs.ids.sensor_size_divisor
             ph, pw = images.shape[2] // div, images.shape[3] // div
             paral = {"projection_mode": "parallel", "sensor_h": ph, "sensor_w": pw, "cx": (pw - 1) / 2, "cy": (ph - 1) / 2}
-            if self.ids_on_host:
+            if "pcs_ids" in inputs:  # the caller transformed the clouds already ([B,6,N]: frame 1, frame 2)
+                pc1, pc2 = inputs["pcs_ids"][:, :3].to(images.device), inputs["pcs_ids"][:, 3:].to(images.device)
+            elif self.ids_on_host:
                 host = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in persp.items()}
                 pc1 = perspect2parallel(pc1.cpu(), host, paral).to(images.device)
                 pc2 = perspect2parallel(pc2.cpu(), host, paral).to(images.device)

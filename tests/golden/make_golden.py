@@ -149,7 +149,27 @@ def reference_model():
     for cls in (mi.Mutual_info_reg_2D, mi.Mutual_info_reg_2D_Event, mi.Mutual_info_reg_3D, mi.Mutual_info_reg_3D_Event):
         cls.reparametrize = lambda self, mu, logvar: torch.randn_like(mu) * logvar.mul(0.5).exp() + mu
     from rpeflow_amd.model import things_config
+    # record what the reference's host-side IDS transform (RPEFlow.py:68-69) hands to FPS / KNN: its log() differs by an
+    # ulp between CPU models (AVX2 / AVX-512 paths), so the goldens carry the transformed clouds and the GPU tests feed them
+    import models.RPEFlow as ref_mod
+    original = ref_mod.perspect2parallel.__wrapped__ if hasattr(ref_mod.perspect2parallel, "__wrapped__") else ref_mod.perspect2parallel
+    IDS_LOG.clear()
+
+    def recording(xyz, persp, paral):
+        out = original(xyz, persp, paral)
+        IDS_LOG.append(out.detach().numpy().copy())
+        return out
+    recording.__wrapped__ = original
+    ref_mod.perspect2parallel = recording
     return RPEFlow(things_config())
+
+
+IDS_LOG = []
+
+
+def ids_clouds():
+    assert len(IDS_LOG) == 2, "one forward = two transformed clouds"
+    return dict(pc1_ids=IDS_LOG[0], pc2_ids=IDS_LOG[1])
 
 
 def model_params(module):
@@ -172,7 +192,7 @@ def gen_model():
     f2, f3 = out["flow_2d"].numpy(), out["flow_3d"].numpy()
     assert np.isfinite(f2).all() and np.isfinite(f3).all()
     print("flow_2d |max|", np.abs(f2).max(), "flow_3d |max|", np.abs(f3).max())
-    save("model_128x192", flow_2d=f2, flow_3d=f3)
+    save("model_128x192", flow_2d=f2, flow_3d=f3, **ids_clouds())
 
 
 @torch.no_grad()
@@ -190,11 +210,29 @@ def gen_model_dsec():
     epe2 = float(np.sqrt(((f2 - sample["flow_2d"][None, :2]) ** 2).sum(1)).mean())
     epe3 = float(np.sqrt(((f3 - sample["flow_3d"][None, :3]) ** 2).sum(1)).mean())
     print("dsec flow_2d |max|", np.abs(f2).max(), "flow_3d |max|", np.abs(f3).max(), "EPE", epe2, epe3)
-    save("model_dsec_480x640", flow_2d_s8=f2[:, :, ::8, ::8].copy(), flow_3d=f3, epe2d=np.float64(epe2), epe3d=np.float64(epe3))
+    save("model_dsec_480x640", flow_2d_s8=f2[:, :, ::8, ::8].copy(), flow_3d=f3, epe2d=np.float64(epe2), epe3d=np.float64(epe3), **ids_clouds())
+
+
+@torch.no_grad()
+def gen_model_full():
+    """BASELINE config 3 shape: one 544x960 frame pair + 8192 points through the reference on the CPU.
+    flow_2d is stored on a stride-8 grid (the full map is 4 MB) together with the EPE scalars."""
+    m = reference_model()
+    m.load_state_dict({k: T(v) for k, v in model_params(m).items()}, strict=True)
+    m.eval()
+    sample = I.frame_pair(3000, H=544, W=960, N=8192)
+    batch = {k: T(v)[None] for k, v in sample.items()}
+    out = m(batch, is_Train=False)
+    f2, f3 = out["flow_2d"].numpy(), out["flow_3d"].numpy()
+    assert np.isfinite(f2).all() and np.isfinite(f3).all()
+    epe2 = float(np.sqrt(((f2 - sample["flow_2d"][None, :2]) ** 2).sum(1)).mean())
+    epe3 = float(np.sqrt(((f3 - sample["flow_3d"][None, :3]) ** 2).sum(1)).mean())
+    print("full flow_2d |max|", np.abs(f2).max(), "flow_3d |max|", np.abs(f3).max(), "EPE", epe2, epe3)
+    save("model_544x960", flow_2d_s8=f2[:, :, ::8, ::8].copy(), flow_3d=f3, epe2d=np.float64(epe2), epe3d=np.float64(epe3), **ids_clouds())
 
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "events"]
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events"]
     for w in which:
         globals()["gen_" + w]()
