@@ -119,6 +119,165 @@ ORC_API int orc_knn(const float *input, const float *query, int B, int M, int Q,
     return 0;
 }
 
+/* ---- torch.topk(k, largest=False, sorted=True) on the CPU, including its order among EQUAL values -----------------
+ * The reference's k_nearest_neighbor is squared_distance + topk (wrapper.py:115-117).  ATen's CPU topk
+ * (aten/src/ATen/native/TopKImpl.h) copies a row into (value, index) pairs and calls std::partial_sort when
+ * k * 64 <= n, else std::nth_element followed by std::sort of the first k - 1 pairs; the comparator looks at the value
+ * only (NaN last), so which of several equal values survives, and in which order, is whatever libstdc++'s heap /
+ * introselect code does with them.  Restated here from libstdc++ (bits/stl_heap.h, bits/stl_algo.h: __adjust_heap,
+ * __push_heap, __make_heap, __pop_heap, __heap_select, __sort_heap, __introselect, __move_median_to_first,
+ * __unguarded_partition, __insertion_sort), for k - 1 <= 16 (std::sort is then a plain insertion sort). */
+typedef struct { float v; int64_t i; } orc_pair;
+
+static int pair_less(const orc_pair *x, const orc_pair *y) {
+    return (!(x->v != x->v) && (y->v != y->v)) || (x->v < y->v);
+}
+static void heap_push(orc_pair *first, long hole, long top, orc_pair value) {
+    long parent = (hole - 1) / 2;
+    while (hole > top && pair_less(first + parent, &value)) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+static void heap_adjust(orc_pair *first, long hole, long len, orc_pair value) {
+    const long top = hole;
+    long second = hole;
+    while (second < (len - 1) / 2) {
+        second = 2 * (second + 1);
+        if (pair_less(first + second, first + (second - 1))) second--;
+        first[hole] = first[second];
+        hole = second;
+    }
+    if ((len & 1) == 0 && second == (len - 2) / 2) {
+        second = 2 * (second + 1);
+        first[hole] = first[second - 1];
+        hole = second - 1;
+    }
+    heap_push(first, hole, top, value);
+}
+static void heap_make(orc_pair *first, long len) {
+    if (len < 2) return;
+    long parent = (len - 2) / 2;
+    for (;;) {
+        heap_adjust(first, parent, len, first[parent]);
+        if (parent == 0) return;
+        parent--;
+    }
+}
+static void heap_select(orc_pair *first, orc_pair *middle, orc_pair *last) {
+    heap_make(first, middle - first);
+    for (orc_pair *i = middle; i < last; ++i)
+        if (pair_less(i, first)) { /* __pop_heap(first, middle, i) */
+            orc_pair value = *i;
+            *i = *first;
+            heap_adjust(first, 0, middle - first, value);
+        }
+}
+static void heap_sort(orc_pair *first, orc_pair *last) {
+    while (last - first > 1) {
+        --last;
+        orc_pair value = *last;
+        *last = *first;
+        heap_adjust(first, 0, last - first, value);
+    }
+}
+static void pair_swap(orc_pair *a, orc_pair *b) { orc_pair t = *a; *a = *b; *b = t; }
+static void insertion_sort(orc_pair *first, orc_pair *last) {
+    if (first == last) return;
+    for (orc_pair *i = first + 1; i != last; ++i) {
+        orc_pair val = *i;
+        if (pair_less(i, first)) {
+            for (orc_pair *j = i; j != first; --j) *j = *(j - 1);
+            *first = val;
+        } else { /* __unguarded_linear_insert */
+            orc_pair *pos = i, *next = i - 1;
+            while (pair_less(&val, next)) { *pos = *next; pos = next; --next; }
+            *pos = val;
+        }
+    }
+}
+static orc_pair *partition_pivot(orc_pair *first, orc_pair *last) {
+    orc_pair *mid = first + (last - first) / 2, *a = first + 1, *b = mid, *c = last - 1;
+    if (pair_less(a, b)) { /* __move_median_to_first(first, first + 1, mid, last - 1) */
+        if (pair_less(b, c)) pair_swap(first, b);
+        else if (pair_less(a, c)) pair_swap(first, c);
+        else pair_swap(first, a);
+    } else if (pair_less(a, c)) pair_swap(first, a);
+    else if (pair_less(b, c)) pair_swap(first, c);
+    else pair_swap(first, b);
+    orc_pair *lo = first + 1, *hi = last; /* __unguarded_partition(first + 1, last, first) */
+    for (;;) {
+        while (pair_less(lo, first)) ++lo;
+        --hi;
+        while (pair_less(first, hi)) --hi;
+        if (!(lo < hi)) return lo;
+        pair_swap(lo, hi);
+        ++lo;
+    }
+}
+static void introselect(orc_pair *first, orc_pair *nth, orc_pair *last, long depth_limit) {
+    while (last - first > 3) {
+        if (depth_limit == 0) {
+            heap_select(first, nth + 1, last);
+            pair_swap(first, nth);
+            return;
+        }
+        --depth_limit;
+        orc_pair *cut = partition_pivot(first, last);
+        if (cut <= nth) first = cut;
+        else last = cut;
+    }
+    insertion_sort(first, last);
+}
+static long floor_log2(long n) { long l = 0; while (n > 1) { n >>= 1; ++l; } return l; }
+
+/* queue: n scratch pairs; returns 1 if k is outside what this restatement covers */
+static int topk_smallest_like_torch(const float *vals, long n, long k, orc_pair *queue, int64_t *out_idx, float *out_val) {
+    if (k < 1 || k > n || k > 17) return 1;
+    for (long j = 0; j < n; ++j) { queue[j].v = vals[j]; queue[j].i = j; }
+    if (k * 64 <= n) { /* std::partial_sort(begin, begin + k, end) */
+        heap_select(queue, queue + k, queue + n);
+        heap_sort(queue, queue + k);
+    } else { /* std::nth_element(begin, begin + k - 1, end); std::sort(begin, begin + k - 1) */
+        introselect(queue, queue + (k - 1), queue + n, floor_log2(n) * 2);
+        insertion_sort(queue, queue + (k - 1)); /* std::sort of <= 16 elements == __insertion_sort */
+    }
+    for (long j = 0; j < k; ++j) { out_idx[j] = queue[j].i; if (out_val) out_val[j] = queue[j].v; }
+    return 0;
+}
+
+ORC_API int orc_topk_smallest(const float *vals, int rows, int n, int k, int64_t *idx, float *out) {
+    orc_pair *queue = (orc_pair *)malloc(sizeof(orc_pair) * (size_t)n);
+    int rc = 0;
+    for (int r = 0; r < rows && !rc; ++r)
+        rc = topk_smallest_like_torch(vals + (size_t)r * n, n, k, queue, idx + (size_t)r * k, out ? out + (size_t)r * k : 0);
+    free(queue);
+    return rc;
+}
+
+/* k_nearest_neighbor exactly as the reference's CPU fallback returns it: the distances of orc_knn, the selection (ties
+ * and their order included) of torch.topk */
+ORC_API int orc_knn_torch_ties(const float *input, const float *query, int B, int M, int Q, int D, int k, int64_t *idx, float *dist) {
+    if (k > M || k <= 0) return 1;
+    float *pp = (float *)malloc(sizeof(float) * (size_t)M), *row = (float *)malloc(sizeof(float) * (size_t)M);
+    orc_pair *queue = (orc_pair *)malloc(sizeof(orc_pair) * (size_t)M);
+    int rc = 0;
+    for (int b = 0; b < B && !rc; ++b) {
+        const float *pb = input + (size_t)b * M * D, *qb = query + (size_t)b * Q * D;
+        for (int j = 0; j < M; ++j) pp[j] = sqnorm(pb + (size_t)j * D, D);
+        for (int i = 0; i < Q && !rc; ++i) {
+            const float *qv = qb + (size_t)i * D;
+            const float qq = sqnorm(qv, D);
+            for (int j = 0; j < M; ++j) row[j] = pair_dist(qv, pb + (size_t)j * D, D, qq, pp[j]);
+            rc = topk_smallest_like_torch(row, M, k, queue, idx + ((size_t)b * Q + i) * k, dist ? dist + ((size_t)b * Q + i) * k : 0);
+        }
+    }
+    free(pp); free(row); free(queue);
+    return rc;
+}
+
 /* furthest_point_sampling, CPU fallback: models/csrc/wrapper.py:83-96
  *   start at index 0; distances = 1e10;
  *   nd = sum((xyz - cur)**2, -1) = fl(fl(dx*dx + dy*dy) + dz*dz), each square rounded

@@ -49,6 +49,7 @@ _PROTOTYPES = {
     "rpe_knn_multi": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr],
     "rpe_debug_set_fps_variant": [_c_int],
     "rpe_debug_stamp": [_c_ptr, _c_ptr],
+    "rpe_debug_set_knn_exact_ties": [_c_int],
     "rpe_gather_channel_first": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_gather_channel_last": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_knn_interpolate": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,

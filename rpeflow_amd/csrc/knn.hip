@@ -48,6 +48,149 @@ struct Queries {
     }
 };
 
+// ---- equal distances exactly as the reference resolves them ---------------------------------------------------------
+// The reference's k_nearest_neighbor is squared_distance + torch.topk (wrapper.py:115-117).  ATen's CPU topk runs
+// std::partial_sort when k * 64 <= M, else std::nth_element + std::sort of the first k - 1; its comparator sees the
+// value only, so which of several EQUAL distances is kept, and their order, is whatever libstdc++'s heap / introselect
+// code does (aten/src/ATen/native/TopKImpl.h; bits/stl_heap.h, bits/stl_algo.h).  The sweep below keeps one entry more
+// than k: any two equal neighbours among the k + 1 best mean the result could depend on that code, and only then the
+// query is redone by a literal restatement of it -- heap_* on a lane-distributed heap for the partial_sort case,
+// seq_* by one lane on an LDS copy of the row for the (small M) nth_element case.  k <= 17; NaN distances are not
+// modelled (the sweep never selects them).
+struct LaneHeap {  // element r of the heap lives in lane r
+    float v;
+    int i;
+    __device__ __forceinline__ float val(int r) const { return rpe_readlane(v, r); }
+    __device__ __forceinline__ void move(int dst, int src, int lane) {  // heap[dst] = heap[src]
+        const float sv = rpe_readlane(v, src);
+        const int si = rpe_readlane(i, src);
+        v = lane == dst ? sv : v;
+        i = lane == dst ? si : i;
+    }
+    __device__ __forceinline__ void set(int dst, float nv, int ni, int lane) {
+        v = lane == dst ? nv : v;
+        i = lane == dst ? ni : i;
+    }
+    // std::__adjust_heap(first, hole, len, value) followed by its __push_heap
+    __device__ __forceinline__ void adjust(int hole, int len, float nv, int ni, int lane) {
+        const int top = hole;
+        int second = hole;
+        while (second < (len - 1) / 2) {
+            second = 2 * (second + 1);
+            if (val(second) < val(second - 1)) second--;
+            move(hole, second, lane);
+            hole = second;
+        }
+        if ((len & 1) == 0 && second == (len - 2) / 2) {
+            second = 2 * (second + 1);
+            move(hole, second - 1, lane);
+            hole = second - 1;
+        }
+        int parent = (hole - 1) / 2;
+        while (hole > top && val(parent) < nv) {
+            move(hole, parent, lane);
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        set(hole, nv, ni, lane);
+    }
+};
+
+// libstdc++ on an array of (value, index) pairs in LDS, executed by one lane (M < 64 k: at most ~1100 elements)
+struct SeqPairs {
+    float *v;
+    int *i;
+    __device__ __forceinline__ void swap(int a, int b) {
+        const float tv = v[a]; v[a] = v[b]; v[b] = tv;
+        const int ti = i[a]; i[a] = i[b]; i[b] = ti;
+    }
+    __device__ void insertion_sort(int first, int last) {  // std::__insertion_sort
+        if (first == last) return;
+        for (int p = first + 1; p != last; ++p) {
+            const float pv = v[p];
+            const int pi = i[p];
+            if (pv < v[first]) {
+                for (int q = p; q != first; --q) { v[q] = v[q - 1]; i[q] = i[q - 1]; }
+                v[first] = pv; i[first] = pi;
+            } else {
+                int pos = p, next = p - 1;
+                while (pv < v[next]) { v[pos] = v[next]; i[pos] = i[next]; pos = next; --next; }
+                v[pos] = pv; i[pos] = pi;
+            }
+        }
+    }
+    __device__ int partition_pivot(int first, int last) {  // std::__unguarded_partition_pivot
+        const int mid = first + (last - first) / 2, a = first + 1, b = mid, c = last - 1;
+        if (v[a] < v[b]) {
+            if (v[b] < v[c]) swap(first, b);
+            else if (v[a] < v[c]) swap(first, c);
+            else swap(first, a);
+        } else if (v[a] < v[c]) swap(first, a);
+        else if (v[b] < v[c]) swap(first, c);
+        else swap(first, b);
+        int lo = first + 1, hi = last;
+        for (;;) {
+            while (v[lo] < v[first]) ++lo;
+            --hi;
+            while (v[first] < v[hi]) --hi;
+            if (!(lo < hi)) return lo;
+            swap(lo, hi);
+            ++lo;
+        }
+    }
+    __device__ void adjust_heap(int first, int hole, int len, float nv, int ni) {
+        const int top = hole;
+        int second = hole;
+        while (second < (len - 1) / 2) {
+            second = 2 * (second + 1);
+            if (v[first + second] < v[first + second - 1]) second--;
+            v[first + hole] = v[first + second]; i[first + hole] = i[first + second];
+            hole = second;
+        }
+        if ((len & 1) == 0 && second == (len - 2) / 2) {
+            second = 2 * (second + 1);
+            v[first + hole] = v[first + second - 1]; i[first + hole] = i[first + second - 1];
+            hole = second - 1;
+        }
+        int parent = (hole - 1) / 2;
+        while (hole > top && v[first + parent] < nv) {
+            v[first + hole] = v[first + parent]; i[first + hole] = i[first + parent];
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        v[first + hole] = nv; i[first + hole] = ni;
+    }
+    __device__ void heap_select(int first, int middle, int last) {  // std::__heap_select
+        const int len = middle - first;
+        if (len >= 2)
+            for (int parent = (len - 2) / 2;; --parent) {
+                adjust_heap(first, parent, len, v[first + parent], i[first + parent]);
+                if (parent == 0) break;
+            }
+        for (int p = middle; p < last; ++p)
+            if (v[p] < v[first]) {
+                const float pv = v[p];
+                const int pi = i[p];
+                v[p] = v[first]; i[p] = i[first];
+                adjust_heap(first, 0, len, pv, pi);
+            }
+    }
+    __device__ void introselect(int first, int nth, int last, int depth_limit) {  // std::__introselect
+        while (last - first > 3) {
+            if (depth_limit == 0) {
+                heap_select(first, nth + 1, last);
+                swap(first, nth);
+                return;
+            }
+            --depth_limit;
+            const int cut = partition_pivot(first, last);
+            if (cut <= nth) first = cut;
+            else last = cut;
+        }
+        insertion_sort(first, last);
+    }
+};
+
 // Several independent searches of one (B, D, k) in one launch: blockIdx.z picks the job.  The PointConv pyramid's five
 // neighbour searches depend on the sampled coordinates only (pointconv.py:46 per level); launched together, the small
 // levels fill the CUs the big one leaves idle instead of queueing behind it.
@@ -56,8 +199,9 @@ struct KnnJobs {
 };
 
 // ---- k >= 2: cross-lane sorted list ----------------------------------------
-template <int D, int QW>
-__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(KnnJobs jobs, int k) {
+template <int D, int QW, bool SMALL>  // SMALL: some job has M < 64 k (topk's nth_element form): LDS room for one row per wave
+__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(KnnJobs jobs, int k, int exact_ties, int row_stride) {
+    extern __shared__ float seq_lds[];  // SMALL: per wave row_stride values then row_stride indices
     const rpe_knn_job &J = jobs.job[blockIdx.z];
     const float *__restrict__ inp = J.input;
     const float *__restrict__ qry = J.query;
@@ -84,6 +228,8 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
         Li[j] = 0;
         tau[j] = INFINITY;
     }
+    // keep one entry more than asked for: it shows whether anything outside the top k ties with the k-th distance
+    const int kk = (exact_ties && k < M && k < RPE_WAVE) ? k + 1 : k;
 
     for (int base = 0; base < M; base += RPE_WAVE) {
         const int pi = base + lane;
@@ -111,7 +257,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
                     const bool gtp = (lane > 0) && (nd < upd);
                     Ld[j] = gt ? (gtp ? upd : nd) : Ld[j];
                     Li[j] = gt ? (gtp ? upi : ni) : Li[j];
-                    tau[j] = rpe_readlane(Ld[j], k - 1);
+                    tau[j] = rpe_readlane(Ld[j], kk - 1);
                 }
             }
         }
@@ -120,7 +266,89 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
 #pragma unroll
     for (int j = 0; j < QW; ++j) {
         const int qi = qbase + j;
-        if (qi < Q && lane < k) {
+        if (qi >= Q) continue;  // wave-uniform
+        if (exact_ties && k <= 17) {
+            // equal neighbours among the kk best (lane r against lane r + 1)?  Then redo this query as libstdc++ would.
+            const float nxt = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Ld[j]), __float_as_int(Ld[j]), 0x130, 0xf, 0xf, false));  // wave_shl:1
+            // exact_ties 1: only a tie ACROSS the boundary (k-th against (k+1)-th distance) can change WHICH neighbours are
+            // returned; ties inside the top k change their order only and keep the sweep's index order.  3: any tie.
+            unsigned long long dup = __ballot(lane + 1 < kk && Ld[j] == nxt);
+            if (exact_ties == 1) dup &= 1ull << (k - 1);
+            if (dup && exact_ties != 2) {
+                if (!SMALL || k * 64 <= M) {  // std::partial_sort: __heap_select over the row in index order, then __sort_heap
+                    LaneHeap h;
+                    h.v = INFINITY;
+                    h.i = 0;
+                    float top = 0.f;
+                    for (int base = 0; base < M; base += RPE_WAVE) {
+                        const int pi = base + lane;
+                        const bool valid = pi < M;
+                        float p[3] = {0.f, 0.f, 0.f};
+                        if (valid) load_point<D>(inp, in_sn, in_sd, pi, p);
+                        const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;
+                        const float d = rpe_pair_dist<D>(qs.qm2[j], qs.qq[j], p, pp);
+                        unsigned long long m;
+                        if (base == 0) {  // the first k elements form the heap: std::__make_heap
+                            h.v = d;
+                            h.i = lane;
+                            for (int parent = (k - 2) / 2;; --parent) {
+                                h.adjust(parent, k, h.val(parent), rpe_readlane(h.i, parent), lane);
+                                if (parent == 0) break;
+                            }
+                            top = h.val(0);
+                            m = __ballot(lane >= k && d < top);
+                        } else {
+                            m = __ballot(d < top);
+                        }
+                        while (m) {  // __pop_heap(first, middle, i) for every later element below the heap's top, in order
+                            const int l = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const float nd = rpe_readlane(d, l);
+                            if (nd < top) {
+                                h.adjust(0, k, nd, base + l, lane);
+                                top = h.val(0);
+                            }
+                        }
+                    }
+                    for (int last = k - 1; last >= 1; --last) {  // std::__sort_heap
+                        const float lv = h.val(last);
+                        const int li = rpe_readlane(h.i, last);
+                        h.move(last, 0, lane);
+                        h.adjust(0, last, lv, li, lane);
+                    }
+                    Ld[j] = h.v;
+                    Li[j] = h.i;
+                } else {  // std::nth_element(begin, begin + k - 1, end) + std::sort(begin, begin + k - 1) by one lane
+                    SeqPairs sp{seq_lds + (size_t)wave * 2 * row_stride,
+                                reinterpret_cast<int *>(seq_lds + (size_t)wave * 2 * row_stride + row_stride)};
+                    for (int base = 0; base < M; base += RPE_WAVE) {
+                        const int pi = base + lane;
+                        if (pi < M) {
+                            float p[3] = {0.f, 0.f, 0.f};
+                            load_point<D>(inp, in_sn, in_sd, pi, p);
+                            sp.v[pi] = rpe_pair_dist<D>(qs.qm2[j], qs.qq[j], p, rpe_sqnorm<D>(p));
+                            sp.i[pi] = pi;
+                        }
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) {
+                        int lg = 0;
+                        for (int t = M; t > 1; t >>= 1) ++lg;
+                        sp.introselect(0, k - 1, M, 2 * lg);
+                        sp.insertion_sort(0, k - 1);
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < k) {
+                        Ld[j] = sp.v[lane];
+                        Li[j] = sp.i[lane];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (lane < k) {
             const int64_t o = ((int64_t)b * Q + qi) * k + lane;
             idx[o] = (int64_t)Li[j];
             if (dist) dist[o] = Ld[j];
@@ -216,21 +444,32 @@ int pick_qw(int B, int Q) {
     return 1;
 }
 
+int g_knn_exact_ties = 1;
+
 template <int D, int QW>
-void launch_knn(const KnnJobs &jobs, int njobs, int max_q, int B, int k, hipStream_t st) {
+void launch_knn(const KnnJobs &jobs, int njobs, int max_q, int min_m, int max_m, int B, int k, hipStream_t st) {
     const int per_block = kWavesPerBlock * QW;
     dim3 grid((max_q + per_block - 1) / per_block, B, njobs), block(kWavesPerBlock * RPE_WAVE);
-    if (k == 1) hipLaunchKernelGGL((knn_nearest_kernel<D, QW>), grid, block, 0, st, jobs);
-    else hipLaunchKernelGGL((knn_select_kernel<D, QW>), grid, block, 0, st, jobs, k);
+    // k == 1 with M >= 64 is std::partial_sort with a one-element heap: the first minimum, which the lane-local kernel keeps
+    if (k == 1 && (min_m >= 64 || !g_knn_exact_ties)) {
+        hipLaunchKernelGGL((knn_nearest_kernel<D, QW>), grid, block, 0, st, jobs);
+    } else if (g_knn_exact_ties && min_m < 64 * k) {
+        // some job is in topk's nth_element regime: every wave gets LDS room for one such row (values + indices)
+        const int row = max_m < 64 * k ? max_m : 64 * k;  // only rows shorter than 64 k are ever copied
+        const size_t lds = (size_t)kWavesPerBlock * 2 * row * sizeof(float);
+        hipLaunchKernelGGL((knn_select_kernel<D, QW, true>), grid, block, lds, st, jobs, k, g_knn_exact_ties, row);
+    } else {
+        hipLaunchKernelGGL((knn_select_kernel<D, QW, false>), grid, block, 0, st, jobs, k, g_knn_exact_ties, 0);
+    }
 }
 
 template <int D>
-void launch_knn_d(int qw, const KnnJobs &jobs, int njobs, int max_q, int B, int k, hipStream_t st) {
+void launch_knn_d(int qw, const KnnJobs &jobs, int njobs, int max_q, int min_m, int max_m, int B, int k, hipStream_t st) {
     switch (qw) {
-        case 1: launch_knn<D, 1>(jobs, njobs, max_q, B, k, st); break;
-        case 2: launch_knn<D, 2>(jobs, njobs, max_q, B, k, st); break;
-        case 4: launch_knn<D, 4>(jobs, njobs, max_q, B, k, st); break;
-        default: launch_knn<D, 8>(jobs, njobs, max_q, B, k, st); break;
+        case 1: launch_knn<D, 1>(jobs, njobs, max_q, min_m, max_m, B, k, st); break;
+        case 2: launch_knn<D, 2>(jobs, njobs, max_q, min_m, max_m, B, k, st); break;
+        case 4: launch_knn<D, 4>(jobs, njobs, max_q, min_m, max_m, B, k, st); break;
+        default: launch_knn<D, 8>(jobs, njobs, max_q, min_m, max_m, B, k, st); break;
     }
 }
 
@@ -241,22 +480,29 @@ RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int 
     if (k > RPE_WAVE) return RPE_EUNSUPPORTED;
     if (B > 65535) return RPE_EUNSUPPORTED;
     KnnJobs packed;
-    int max_q = 0;
+    int max_q = 0, min_m = 0x7fffffff, max_m = 0;
     long total_q = 0;
     for (int i = 0; i < njobs; ++i) {
         const rpe_knn_job &j = jobs[i];
         if (!j.input || !j.query || !j.idx || j.M <= 0 || j.Q < 0 || k > j.M) return RPE_EINVAL;
         packed.job[i] = j;
         max_q = j.Q > max_q ? j.Q : max_q;
+        min_m = j.M < min_m ? j.M : min_m;
+        max_m = j.M > max_m ? j.M : max_m;
         total_q += j.Q;
     }
     if (B == 0 || max_q == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int qw = pick_qw(B, (int)total_q);
-    if (D == 3) launch_knn_d<3>(qw, packed, njobs, max_q, B, k, st);
-    else if (D == 2) launch_knn_d<2>(qw, packed, njobs, max_q, B, k, st);
-    else launch_knn_d<1>(qw, packed, njobs, max_q, B, k, st);
+    if (D == 3) launch_knn_d<3>(qw, packed, njobs, max_q, min_m, max_m, B, k, st);
+    else if (D == 2) launch_knn_d<2>(qw, packed, njobs, max_q, min_m, max_m, B, k, st);
+    else launch_knn_d<1>(qw, packed, njobs, max_q, min_m, max_m, B, k, st);
     return rpe_launch_status();
+}
+
+RPE_API int rpe_debug_set_knn_exact_ties(int on) {
+    g_knn_exact_ties = on;  // 3: also reproduce the ORDER of equal distances inside the top k; 2 (timing): detect only
+    return 0;
 }
 
 RPE_API int rpe_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,

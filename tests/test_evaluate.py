@@ -134,4 +134,10 @@ def test_graph_replayed_evaluation_matches_eager():
     eager, acc_e = E.evaluate(model, data, batch_size=2, device="cuda:0", graph=False)
     graphed, acc_g = E.evaluate(model, data, batch_size=2, device="cuda:0", graph=True)
     assert eager["counts"] == graphed["counts"]
-    np.testing.assert_allclose(acc_g.cpu().numpy(), acc_e.cpu().numpy(), rtol=1e-4)
+    a_g, a_e = acc_g.cpu().numpy(), acc_e.cpu().numpy()
+    sums = [E.FIELDS.index(f) for f in E.FIELDS if f.startswith(("count", "epe"))]
+    hits = [i for i in range(len(E.FIELDS)) if i not in sums]
+    np.testing.assert_allclose(a_g[sums], a_e[sums], rtol=1e-4)
+    # threshold hit counts: the library convs may pick another solver under capture (~1e-5 on the flow), which can
+    # move a few points of a random-weight model across a threshold
+    np.testing.assert_allclose(a_g[hits], a_e[hits], atol=16, rtol=1e-3)

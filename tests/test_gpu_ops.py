@@ -21,6 +21,16 @@ from rpeflow_amd.csrc import wrapper as W  # noqa: E402
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _knn_positions_exact():
+    """The operator tests of this module compare indices position for position with the oracle / the reference, so they
+    run the KNN kernels in mode 3 (order of equal distances reproduced too); the default mode 1 (the reference's
+    neighbour SETS, cheaper) is what test_knn_golden_cases and test_knn_equal_distances_follow_torch_topk check by set."""
+    _lib.lib().rpe_debug_set_knn_exact_ties(3)
+    yield
+    _lib.lib().rpe_debug_set_knn_exact_ties(1)
+
+
 def G(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
@@ -58,18 +68,22 @@ def test_squared_distance(golden_dir, name):
 @pytest.mark.parametrize("name", list(K.KNN_CASES))
 def test_knn_golden_cases(golden_dir, name):
     inp, qry, k = K.knn_inputs(name)
-    idx, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k)
+    idx, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k)  # mode 3 (module fixture)
     idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    _lib.lib().rpe_debug_set_knn_exact_ties(1)
+    default_idx = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
+    assert np.array_equal(np.sort(default_idx, -1), np.sort(idx, -1)), name + ": default mode returns another neighbour set"
     oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True)
     assert np.array_equal(idx, oi), f"{name}: {(idx != oi).sum()} indices differ from the oracle"
     assert_bits_equal(dist, od, name + " distances vs oracle")
     g = G(golden_dir, name)
-    assert_knn_tie_aware(idx, dist, g["idx"], g["dist"], g["next_dist"], name + " vs reference golden")
-    # public entry point, both layouts (wrapper.py:119-122)
-    assert np.array_equal(ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy(), oi)
+    assert np.array_equal(idx, g["idx"]), name + ": indices differ from the reference's torch.topk output"
+    assert_bits_equal(dist, g["dist"], name + " distances vs reference golden")
+    # public entry point, both layouts (wrapper.py:119-122): default mode = the reference's neighbour sets
+    assert np.array_equal(default_idx, ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy())
     if inp.shape[1] > 3:
         cf = ops.k_nearest_neighbor(input_xyz=dev(inp.transpose(0, 2, 1)), query_xyz=dev(qry.transpose(0, 2, 1)), k=k)
-        assert np.array_equal(cf.cpu().numpy(), oi)
+        assert np.array_equal(cf.cpu().numpy(), default_idx)
 
 
 @pytest.mark.parametrize("B,M,Q,D,k", [
@@ -289,3 +303,34 @@ def test_knn_multi_equals_separate_calls():
     cf = [(a.transpose(1, 2).contiguous(), b.transpose(1, 2).contiguous()) for a, b in pairs]  # channel-first layout, k = 1 kernel
     for (inp, qry), g in zip(cf, W.k_nearest_neighbor_multi(cf, 1)):
         assert torch.equal(g, ops.k_nearest_neighbor(inp, qry, 1))
+
+
+@pytest.mark.parametrize("B,M,Q,D,k", [(2, 700, 300, 3, 16), (1, 2048, 1024, 3, 16), (2, 130, 64, 3, 3), (1, 500, 777, 2, 3), (3, 40, 33, 3, 1),
+                                       (1, 1500, 200, 3, 17), (2, 1023, 128, 3, 16), (2, 1024, 128, 3, 16), (1, 64, 64, 2, 1), (1, 63, 40, 2, 1),
+                                       (2, 300, 300, 3, 2), (1, 5000, 96, 3, 5)])
+def test_knn_equal_distances_follow_torch_topk(B, M, Q, D, k):
+    """Points on a coarse integer lattice: most distances tie.  Indices AND their order must be what the reference's
+    matmul + torch.topk gives on the CPU, in both of topk's regimes (k * 64 <= M: partial_sort; else nth_element + sort)."""
+    r = I.rng(9300 + M + k)
+    inp = r.integers(0, 6, (B, M, D)).astype(np.float32)
+    qry = r.integers(0, 6, (B, Q, D)).astype(np.float32)
+    ti, td = torch.from_numpy(inp), torch.from_numpy(qry)
+    dmat = -2 * torch.matmul(td, ti.permute(0, 2, 1))
+    dmat += torch.sum(td ** 2, -1).view(B, Q, 1)
+    dmat += torch.sum(ti ** 2, -1).view(B, 1, M)
+    ref_idx = dmat.topk(k, dim=2, largest=False).indices.numpy()          # wrapper.py:115-117 on the CPU
+    assert np.array_equal(O.k_nearest_neighbor(inp, qry, k), ref_idx)      # the oracle's restatement of it
+    _lib.lib().rpe_debug_set_knn_exact_ties(1)
+    got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()  # default: the reference's neighbour SET, always
+    assert np.array_equal(np.sort(got, -1), np.sort(ref_idx, -1)), "default mode returns another neighbour set"
+    try:
+        _lib.lib().rpe_debug_set_knn_exact_ties(3)  # position for position, order of equal distances included
+        got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
+        assert np.array_equal(got, ref_idx), f"{(got != ref_idx).sum()} of {got.size} indices differ"
+        # the plain lowest-index rule is still available and still a valid neighbour set
+        _lib.lib().rpe_debug_set_knn_exact_ties(0)
+        low, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k)
+        oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True, ties="index")
+        assert np.array_equal(low.cpu().numpy(), oi)
+    finally:
+        _lib.lib().rpe_debug_set_knn_exact_ties(1)

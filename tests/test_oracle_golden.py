@@ -30,7 +30,32 @@ def test_knn(golden_dir, name):
     inp, qry, k = K.knn_inputs(name)
     g = G(golden_dir, name)
     idx, dist = O.k_nearest_neighbor(inp, qry, k, return_dists=True)
-    assert_knn_tie_aware(idx, dist, g["idx"], g["dist"], g["next_dist"], name)
+    # the reference's own indices, element for element: distances restated bit-exactly, torch.topk's handling of equal
+    # values (libstdc++ partial_sort / nth_element) restated in rpe_oracle.c
+    assert np.array_equal(idx, g["idx"]), name
+    assert_bits_equal(dist, g["dist"], name)
+    idx_low, dist_low = O.k_nearest_neighbor(inp, qry, k, return_dists=True, ties="index")
+    assert_knn_tie_aware(idx_low, dist_low, g["idx"], g["dist"], g["next_dist"], name)
+
+
+def test_topk_restatement_matches_torch_on_duplicate_heavy_rows():
+    """orc_topk_smallest against torch.topk(largest=False) itself: few distinct values, both algorithm regimes
+    (k * 64 <= n partial_sort, else nth_element + sort), NaNs."""
+    import ctypes
+    import torch
+    r = np.random.default_rng(5)
+    for trial in range(400):
+        n = int(r.integers(1, 2500))
+        k = int(min(n, r.choice([1, 2, 3, 4, 5, 8, 15, 16, 17])))
+        vals = (r.integers(0, int(r.choice([2, 3, 5, 20, 1000])), (2, n)) / np.float32(7.0)).astype(np.float32)
+        if trial % 10 == 0:
+            vals[0, r.integers(0, n)] = np.nan
+        idx, out = np.empty((2, k), np.int64), np.empty((2, k), np.float32)
+        assert O.lib().orc_topk_smallest(vals.ctypes.data_as(ctypes.c_void_p), 2, n, k, idx.ctypes.data_as(ctypes.c_void_p),
+                                         out.ctypes.data_as(ctypes.c_void_p)) == 0
+        tv, ti = torch.from_numpy(vals).topk(k, dim=1, largest=False)
+        assert np.array_equal(ti.numpy(), idx), (n, k)
+        assert np.array_equal(tv.numpy().view(np.uint32), out.view(np.uint32)), (n, k)
 
 
 def test_knn_channel_first_sniff():
