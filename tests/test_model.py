@@ -29,15 +29,12 @@ def sample_batch(device):
     return {k: torch.from_numpy(v)[None].to(device) for k, v in s.items()}
 
 
-# GPU forward against the reference's CPU output.  Two things separate them that no implementation of the hot path can
-# remove: (1) the reference's k_nearest_neighbor is matmul + torch.topk, whose choice among candidates at EXACTLY the k-th
-# distance follows libstdc++'s partial_sort heap (wrapper.py:115-117; "arbitrary" per SURVEY a-3) while the kernels here
-# keep the lowest index -- on the 544x960 sample 7 of the PointConv pyramid's 7936 queries have such a boundary tie
-# (distances bit-identical, tools/exp check), and exchanging just those moves EPE2D by 5.5e-4; (2) MIOpen and oneDNN round
-# convolutions differently, which flips near-tied neighbours on the warped clouds.  The strict 1e-4 bound is therefore
-# asserted where both sides resolve ties alike: test_model_matches_pytorch_port_with_same_selection below (and, on the
-# CPU, test_model_wiring_on_cpu_with_ported_ops against the reference golden itself).
-GOLDEN_EPE_TOL = 1e-3
+# GPU forward against the reference's CPU output: north_star's bound, |EPE - reference EPE| < 1e-4, on all three golden
+# shapes.  It holds because the neighbour SETS are the reference's: k_nearest_neighbor there is matmul + torch.topk
+# (wrapper.py:115-117), whose pick among candidates at exactly the k-th distance follows libstdc++'s partial_sort /
+# nth_element, and the KNN kernel restates that.  Measured: 3.8e-6 / 1.9e-6 / 4.0e-5 on EPE2D
+# (128x192, DSEC 480x640, 544x960), <= 5e-6 on EPE3D; what is left is MIOpen vs oneDNN convolution rounding.
+GOLDEN_EPE_TOL = 1e-4
 
 
 def with_reference_ids(batch, golden, device):
