@@ -92,30 +92,60 @@ class GraphedForward:
     """model(batch) replayed from one HIP graph per input signature: the first batch of a shape runs eagerly (MIOpen
     search, caches) and is then captured with static input buffers; later batches of that shape are copied into the
     buffers and replayed -- ~1400 kernel launches and the Python between them become one call.  The returned tensors
-    are the graph's static outputs: consume them before the next call."""
-    INPUTS = ("images", "pcs", "intrinsics", "event_voxel")  # what RPEFlow.forward reads (models/RPEFlow.py:36-47)
+    are the graph's static outputs: consume them before the next call.
 
-    def __init__(self, model, warmup=2):
+    ``ahead=True`` (default) captures RPEFlow.forward_ahead instead: a call that is also given the NEXT batch runs that
+    batch's furthest-point sampling inside this replay, on its own stream, and the next call starts from the finished
+    order.  A call whose batch is not the one announced by the previous call (first batch, shape change, skipped
+    announcement) samples before replaying, so results never depend on the announcements being right."""
+    INPUTS = ("images", "pcs", "intrinsics", "event_voxel")  # what RPEFlow.forward reads (models/RPEFlow.py:36-47)
+    SAMPLING_INPUTS = ("pcs", "intrinsics")                  # what the sampling order depends on (plus the frame shape)
+
+    def __init__(self, model, warmup=2, ahead=True):
         self.model, self.warmup, self.entries = model, warmup, {}
+        self.ahead = ahead and hasattr(model, "forward_ahead")
+
+    def _key(self, batch):
+        return tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self.INPUTS)
+
+    def _capture(self, batch):
+        static = {k: batch[k].clone() for k in self.INPUTS}
+        for _ in range(self.warmup):
+            self.model(static)
+        entry = {"static": static, "announced": None}
+        if self.ahead:
+            # the next batch's sampling inputs; ``images`` rides along for its shape only
+            entry["next"] = {"images": static["images"], **{k: static[k].clone() for k in self.SAMPLING_INPUTS}}
+            entry["order"] = self.model.sample_order(static)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            if self.ahead:
+                entry["out"] = self.model.forward_ahead(static, entry["order"], entry["next"])
+            else:
+                entry["out"] = self.model(static)
+        entry["graph"] = graph
+        return entry
 
     @torch.no_grad()
-    def __call__(self, batch):
-        key = tuple((k, tuple(batch[k].shape), batch[k].dtype) for k in self.INPUTS)
+    def __call__(self, batch, next_batch=None):
+        key = self._key(batch)
         entry = self.entries.get(key)
         if entry is None:
-            static = {k: batch[k].clone() for k in self.INPUTS}
-            for _ in range(self.warmup):
-                self.model(static)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self.model(static)
-            entry = self.entries[key] = (graph, static, out)
-        graph, static, out = entry
+            entry = self.entries[key] = self._capture(batch)
+        static = entry["static"]
         for k in self.INPUTS:
             static[k].copy_(batch[k], non_blocking=True)
-        graph.replay()
-        return out
+        if self.ahead:
+            if entry["announced"] is not batch["pcs"]:  # nobody sampled this batch ahead of time
+                entry["order"].copy_(self.model.sample_order(static))
+            entry["announced"] = None
+            if next_batch is not None and self._key(next_batch) == key:
+                for k in self.SAMPLING_INPUTS:
+                    entry["next"][k].copy_(next_batch[k], non_blocking=True)
+                entry["announced"] = next_batch["pcs"]
+        entry["graph"].replay()
+        return entry["out"]
 
 
 @torch.no_grad()
@@ -127,10 +157,14 @@ def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=Non
     if graph is None:  # capture costs a few seconds once: worth it from a few dozen batches on
         graph = (torch.device(device).type == "cuda" and not getattr(model, "ids_on_host", False)
                  and len(mine) >= 32 * batch_size)
-    forward = GraphedForward(model) if graph else model
-    for start in range(0, len(mine), batch_size):  # the last batch may be short
-        batch = to_device(collate([dataset[i] for i in mine[start:start + batch_size]]), device)
-        accumulate(acc, forward(batch), batch)
+    forward = GraphedForward(model) if graph else None
+    load = lambda start: to_device(collate([dataset[i] for i in mine[start:start + batch_size]]), device)
+    starts = list(range(0, len(mine), batch_size))  # the last batch may be short
+    batch = load(starts[0]) if starts else None
+    for n, start in enumerate(starts):
+        upcoming = load(starts[n + 1]) if n + 1 < len(starts) else None  # resident one batch early: its sampling runs now
+        accumulate(acc, forward(batch, upcoming) if graph else model(batch), batch)
+        batch = upcoming
     if world_size > 1:
         import torch.distributed as dist
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # the one collective of the evaluation

@@ -714,40 +714,86 @@ class RPEFlow(nn.Module):
         self._streams = {}
         self.pwc_fusion_core = RPEFlow_core(self.cfgs.pwc2d, self.cfgs.pwc3d, self.cfgs.get("attention"), ops=ops)
 
+    def _pyramid(self, pc1, pc2, n_samples, fps_order):
+        build = self.pwc_fusion_core.ops.build_pc_pyramid
+        return build(pc1, pc2, n_samples) if fps_order is None else build(pc1, pc2, n_samples, sample_index_both=fps_order)
+
     def _side_stream(self, device, name="side"):
         key = (torch.device(device).index, name)
         if key not in self._streams:
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
 
-    @torch.no_grad()
-    def forward(self, inputs, is_Train=False):
-        images = inputs["images"].float() / 255.0
-        pc1, pc2 = inputs["pcs"][:, :3], inputs["pcs"][:, 3:]
-        intrinsics = inputs["intrinsics"]
-        origin_h, origin_w = images.shape[2:]
-        images = resize_to_64x(images)
-        event_voxel = resize_to_64x(inputs["event_voxel"])
-        image1, image2 = images[:, :3], images[:, 3:]
+    N_SAMPLES = [4096, 2048, 1024, 512, 256]
 
+    def _cameras(self, inputs):
+        """The perspective camera of the inputs and the parallel one of the IDS transform (RPEFlow.py:52-66); shapes only."""
+        origin_h, origin_w = inputs["images"].shape[2:]
+        intrinsics = inputs["intrinsics"]
         persp = {"projection_mode": "perspective", "sensor_h": origin_h, "sensor_w": origin_w,
                  "f": intrinsics[:, 0], "cx": intrinsics[:, 1], "cy": intrinsics[:, 2]}
         paral = None
         if self.cfgs.ids.enabled:
             div = self.cfgs.ids.sensor_size_divisor
-            ph, pw = images.shape[2] // div, images.shape[3] // div
+            ph, pw = (origin_h + 63) // 64 * 64 // div, (origin_w + 63) // 64 * 64 // div
             paral = {"projection_mode": "parallel", "sensor_h": ph, "sensor_w": pw, "cx": (pw - 1) / 2, "cy": (ph - 1) / 2}
-            if "pcs_ids" in inputs:  # the caller transformed the clouds already ([B,6,N]: frame 1, frame 2)
-                pc1, pc2 = inputs["pcs_ids"][:, :3].to(images.device), inputs["pcs_ids"][:, 3:].to(images.device)
-            elif self.ids_on_host:
-                host = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in persp.items()}
-                pc1 = perspect2parallel(pc1.cpu(), host, paral).to(images.device)
-                pc2 = perspect2parallel(pc2.cpu(), host, paral).to(images.device)
-            else:
-                pc1, pc2 = perspect2parallel(pc1, persp, paral), perspect2parallel(pc2, persp, paral)
+        return persp, paral
+
+    def _clouds(self, inputs, persp, paral):
+        """Both clouds as the pyramids see them: IDS-transformed when enabled (RPEFlow.py:60-66)."""
+        device = inputs["images"].device
+        pc1, pc2 = inputs["pcs"][:, :3], inputs["pcs"][:, 3:]
+        if paral is None:
+            return pc1, pc2
+        if "pcs_ids" in inputs:  # the caller transformed the clouds already ([B,6,N]: frame 1, frame 2)
+            return inputs["pcs_ids"][:, :3].to(device), inputs["pcs_ids"][:, 3:].to(device)
+        if self.ids_on_host:
+            host = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in persp.items()}
+            return perspect2parallel(pc1.cpu(), host, paral).to(device), perspect2parallel(pc2.cpu(), host, paral).to(device)
+        return perspect2parallel(pc1, persp, paral), perspect2parallel(pc2, persp, paral)
+
+    @torch.no_grad()
+    def sample_order(self, inputs):
+        """[2B, 4096] int64: the furthest-point order of frame-1 then frame-2 clouds, exactly what forward() computes first
+        (build_pc_pyramid, pwc3d_core.py:8-28).  It depends on ``pcs`` / ``intrinsics`` / the frame size only, so a caller
+        that holds the NEXT batch can run it beside the current forward and hand the result over as
+        ``inputs["fps_order"]`` (forward_ahead below)."""
+        pc1, pc2 = self._clouds(inputs, *self._cameras(inputs))
+        from .csrc import furthest_point_sampling
+        return furthest_point_sampling(torch.cat([pc1, pc2], dim=0).transpose(1, 2), max(self.N_SAMPLES))
+
+    @torch.no_grad()
+    def forward_ahead(self, inputs, order, next_inputs):
+        """forward(inputs) with the sampling software-pipelined by one batch.  ``order`` ([2B,4096] int64, caller-owned)
+        holds sample_order(inputs) on entry and sample_order(next_inputs) on return: the 4095 dependent FPS iterations
+        (3.5 ms on 2B of the 256 CUs, the longest serial stretch of the forward) run for the NEXT batch on their own
+        stream under this batch's convolutions instead of in front of this batch's 3-D encoder.  Every call still runs
+        one full FPS over one batch of clouds.  Capturable: the harness replays it as one HIP graph per batch."""
+        mine = order.clone()
+        main = torch.cuda.current_stream(order.device)
+        ahead = self._side_stream(order.device, "ahead")
+        ahead.wait_stream(main)
+        with torch.cuda.stream(ahead):
+            order.copy_(self.sample_order(next_inputs))
+            _stamp("ahead sampling done")
+        out = self.forward({**inputs, "fps_order": mine})
+        main.wait_stream(ahead)
+        return out
+
+    @torch.no_grad()
+    def forward(self, inputs, is_Train=False):
+        images = inputs["images"].float() / 255.0
+        intrinsics = inputs["intrinsics"]
+        origin_h, origin_w = images.shape[2:]
+        images = resize_to_64x(images)
+        event_voxel = resize_to_64x(inputs["event_voxel"])
+        image1, image2 = images[:, :3], images[:, 3:]
+        persp, paral = self._cameras(inputs)
+        pc1, pc2 = self._clouds(inputs, persp, paral)
+        fps_order = inputs.get("fps_order")
 
         core = self.pwc_fusion_core
-        n_samples = [4096, 2048, 1024, 512, 256]
+        n_samples = self.N_SAMPLES
         # frames 1 and 2 go through the shared-weight pyramids as one 2B batch (the reference calls encode() twice,
         # RPEFlow.py:78-79; eval-mode BatchNorm makes the two forms equal sample by sample)
         image_both = torch.cat([image1, image2], dim=0)
@@ -761,7 +807,7 @@ class RPEFlow(nn.Module):
             side = self._side_stream(pc1.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, n_samples)
+                xyzs1, xyzs2, _, _ = self._pyramid(pc1, pc2, n_samples, fps_order)
                 both = [torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)]
                 _stamp("side fps done")
             feats_2d_both = core.feature_pyramid_2d(image_both)
@@ -775,7 +821,7 @@ class RPEFlow(nn.Module):
             for t in list(xyzs1) + list(xyzs2) + list(feats_3d_both):
                 t.record_stream(main)  # allocated on the side stream, consumed on the main one
         else:
-            xyzs1, xyzs2, _, _ = core.ops.build_pc_pyramid(pc1, pc2, n_samples)
+            xyzs1, xyzs2, _, _ = self._pyramid(pc1, pc2, n_samples, fps_order)
             feats_3d_both = core.feature_pyramid_3d([torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)])
             feats_2d_both = core.feature_pyramid_2d(image_both)
             efeats_2d = core.encode_event(event_voxel)

@@ -13,11 +13,13 @@ from .pointconv import PointConvDownSampling, PointConvNoSampling
 from .utils import MLP1d, MLP2d, batch_indexing_channel_first
 
 
-def build_pc_pyramid(pc1, pc2, n_samples_list):
-    """pwc3d_core.py:8-28: one FPS over both clouds, every level a prefix of its order."""
+def build_pc_pyramid(pc1, pc2, n_samples_list, sample_index_both=None):
+    """pwc3d_core.py:8-28: one FPS over both clouds, every level a prefix of its order.
+    ``sample_index_both`` ([2B, >=max(n_samples_list)] int64): that order, when the caller computed it already."""
     batch_size, _, n_points = pc1.shape
-    pc_both = torch.cat([pc1, pc2], dim=0)
-    sample_index_both = furthest_point_sampling(pc_both.transpose(1, 2), max(n_samples_list))
+    if sample_index_both is None:
+        pc_both = torch.cat([pc1, pc2], dim=0)
+        sample_index_both = furthest_point_sampling(pc_both.transpose(1, 2), max(n_samples_list))
     sample_index1, sample_index2 = sample_index_both[:batch_size], sample_index_both[batch_size:]
 
     lv0_index = torch.arange(n_points, device=pc1.device)[None, :].expand(batch_size, n_points)

@@ -209,3 +209,37 @@ def test_model_matches_pytorch_port_with_same_selection(golden_dir, name, H, W, 
     d2, d3 = abs(epe(flows[0][0], t2) - epe(flows[1][0], t2)), abs(epe(flows[0][1], t3) - epe(flows[1][1], t3))
     print(name, "EPE2D diff", d2, "EPE3D diff", d3)
     assert d2 < 1e-4 and d3 < 1e-4
+
+
+@pytest.mark.gpu
+def test_sampling_one_batch_ahead_changes_nothing():
+    """forward_ahead(A, order, next=B): the output is forward(A)'s, ``order`` leaves as sample_order(B) -- eagerly and
+    replayed from one HIP graph over three different batches (the harness's schedule)."""
+    from rpeflow_amd.model import RPEFlow
+    torch.manual_seed(0)
+    model = RPEFlow().to("cuda:0").eval()
+    batches = [{k: torch.from_numpy(v)[None].to("cuda:0") for k, v in I.frame_pair(4000 + i, H=128, W=192, N=8192).items()}
+               for i in range(3)]
+    plain = [{k: v.clone() for k, v in model(b).items()} for b in batches]
+    # two runs of the forward differ by convolution-solver rounding only; another sampling order would be O(1) off
+    same = lambda a, ref: ((a - ref).abs().mean() / (ref.abs().mean() + 1e-6)).item() < 1e-3
+    orders = [model.sample_order(b) for b in batches]
+    assert not torch.equal(orders[0], orders[1]) and not same(plain[1]["flow_3d"], plain[0]["flow_3d"])
+    order = orders[0].clone()
+    out = model.forward_ahead(batches[0], order, batches[1])
+    torch.cuda.synchronize()
+    assert torch.equal(order, orders[1])
+    for key in ("flow_2d", "flow_3d"):
+        assert same(out[key], plain[0][key])
+
+    from rpeflow_amd.evaluate import GraphedForward
+    replayed = GraphedForward(model, warmup=1)
+    for i, b in enumerate(batches):
+        out = replayed(b, batches[i + 1] if i + 1 < len(batches) else None)
+        for key in ("flow_2d", "flow_3d"):
+            assert same(out[key], plain[i][key]), (i, key)
+    # an unannounced batch (and a wrongly announced one) still gets its own sampling
+    out = replayed(batches[0], batches[2])
+    assert same(out["flow_3d"], plain[0]["flow_3d"])
+    out = replayed(batches[1])
+    assert same(out["flow_3d"], plain[1]["flow_3d"])

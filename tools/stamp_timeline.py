@@ -1,5 +1,6 @@
 """Real multi-stream timeline of the graph-replayed forward (rocprofv3 serialises graph branches): GPU wall-clock
-stamps dropped by one-thread kernels at stage boundaries of every stream.  Usage: python tools/stamp_timeline.py"""
+stamps dropped by one-thread kernels at stage boundaries of every stream.
+Usage: python tools/stamp_timeline.py [--no-ahead]   (default: the harness's schedule, sampling one batch ahead)"""
 import os
 import sys
 
@@ -18,8 +19,12 @@ for _ in range(3):
 torch.cuda.synchronize()
 M.TRACE = M.StampTrace(dev)
 graph = torch.cuda.CUDAGraph()
+order = model.sample_order(batch)
 with torch.cuda.graph(graph):
-    model(batch)
+    if "--no-ahead" in sys.argv:
+        model(batch)
+    else:
+        model.forward_ahead(batch, order, batch)
 for _ in range(3):
     graph.replay()
 torch.cuda.synchronize()
