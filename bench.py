@@ -27,10 +27,11 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import rpeflow_amd  # noqa: F401,E402 -- first: sets the HIP runtime's graph-queue count before the GPU is initialised
+
+import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 H, W, NPTS = 544, 960, 8192
