@@ -74,12 +74,12 @@ def algorithmic_bytes(workload, B):
     return out
 
 
-def corr_microbench(dev, iters=30):
+def corr_microbench(dev, iters=40):
     """BASELINE config 2: correlation2d 1x256x544x960, md=4, fp32, NCHW in/out."""
     import rpeflow_amd.csrc as ops
     a = torch.randn(1, 256, H, W, device=dev)
     b = torch.randn(1, 256, H, W, device=dev)
-    for _ in range(10):  # also lets the clocks settle after the latency-bound steps before it
+    for _ in range(120):  # the clocks need ~40 ms of sustained load to settle (first 20 launches: 500 us, then 405)
         ops.correlation2d(a, b, 4)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
