@@ -16,7 +16,8 @@ int main(int argc, char **argv) {
     hipMalloc(&a, n * 4); hipMalloc(&b, n * 4); hipMalloc(&o, no * 4);
     std::vector<float> h(n);
     std::mt19937 gen(1); std::normal_distribution<float> nd(0.f, 1.f);
-    for (size_t i = 0; i < n; ++i) h[i] = nd(gen);
+    const float scale = argc > 2 ? (float)atof(argv[2]) : 1.f;  // 0: all-zero inputs (no operand toggling: the power-unlimited time)
+    for (size_t i = 0; i < n; ++i) h[i] = nd(gen) * scale;
     hipMemcpy(a, h.data(), n * 4, hipMemcpyHostToDevice); hipMemcpy(b, h.data(), n * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 120; ++i) rpe_correlation2d_forward(a, b, B, C, H, W, 4, 0.f, algo, o, nullptr);
