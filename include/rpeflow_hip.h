@@ -138,6 +138,11 @@ int rpe_knn_interpolate(const float *in_xyz, int64_t x_sb, int64_t x_sd, int64_t
 int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W,
                         const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sp, int P,
                         int add_pixel_grid, int border, float *out, rpe_stream_t stream);
+/* rpe_upsample2x_pair: the 2-D decoder's coarse-to-fine hand-over (models/RPEFlow_core.py:364-369): a [B,Ca,h,w] (times
+ *   scale_a) and b [B,Cb,h,w], both F.interpolate(scale_factor=2, mode='bilinear', align_corners=True), in one launch.
+ *   out_a [B,Ca,2h,2w], out_b [B,Cb,2h,2w] contiguous.  Either tensor may be absent (C = 0, pointers NULL).        */
+int rpe_upsample2x_pair(const float *a, int Ca, float scale_a, const float *b, int Cb, int B, int h, int w,
+                        float *out_a, float *out_b, rpe_stream_t stream);
 
 /* ---- project_feat_with_nn_corr (models/utils.py:297-317) -------------------------
  * For pixel p with nearest projected point i = nn_idx[b][p]:

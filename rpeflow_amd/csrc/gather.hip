@@ -149,6 +149,37 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__
     for (; c < c1; ++c) out[((int64_t)b * C + c) * P + p] = bl.sample(feat + ((int64_t)b * C + c) * HW);
 }
 
+// Coarse-to-fine hand-over of the 2-D decoder (RPEFlow_core.py:364-369 / pwc2d_core usage): the coarser level's flow (times
+// `scale_a`, 2 in the model) and flow features, both up-sampled x2 with F.interpolate(bilinear, align_corners=True), in ONE
+// launch instead of a multiply and two interpolations.  Arithmetic as ATen's upsample_bilinear2d: source = dst * (in-1)/(out-1),
+// h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11).  Channels of a (Ca) then b (Cb) form one virtual channel axis.
+__global__ __launch_bounds__(256) void upsample2x_pair_kernel(const float *__restrict__ a, int Ca, float scale_a, const float *__restrict__ b,
+                                                              int Cb, int h, int w, int c_per_block, float *__restrict__ out_a,
+                                                              float *__restrict__ out_b) {
+    const int H = 2 * h, W = 2 * w, P = H * W;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.z;
+    if (p >= P) return;
+    const int y = p / W, x = p - y * W;
+    const float ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, rx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const float sy = ry * (float)y, sx = rx * (float)x;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int yp = y0 < h - 1 ? 1 : 0, xp = x0 < w - 1 ? 1 : 0;
+    const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+    const int o00 = y0 * w + x0, o01 = o00 + xp, o10 = o00 + yp * w, o11 = o10 + xp;
+    const int hw = h * w;
+    const int c0 = blockIdx.y * c_per_block, c1 = min(Ca + Cb, c0 + c_per_block);
+    for (int c = c0; c < c1; ++c) {
+        const bool first = c < Ca;
+        const float *src = first ? a + ((int64_t)n * Ca + c) * hw : b + ((int64_t)n * Cb + (c - Ca)) * hw;
+        const float k = first ? scale_a : 1.f;
+        const float v00 = src[o00] * k, v01 = src[o01] * k, v10 = src[o10] * k, v11 = src[o11] * k;
+        const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        float *dst = first ? out_a + ((int64_t)n * Ca + c) * P : out_b + ((int64_t)n * Cb + (c - Ca)) * P;
+        dst[p] = v;
+    }
+}
+
 // project_feat_with_nn_corr (utils.py:297-317) in two launches.
 //   point_rows_kernel:   rows[b][i][:] = [ sample(feat_2d[b], xy_i)[0..C2) | feat_3d[b][:, i] ]   (channel-last, per POINT)
 //   project_rows_kernel: for pixel p with nearest point i = nn[b][p]:
@@ -280,6 +311,18 @@ RPE_API int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W, c
     dim3 grid((P + 255) / 256, (C + cpb - 1) / cpb, B);
     hipLaunchKernelGGL(bilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, C, H, W, xy, xy_sb, xy_sd, xy_sp, P,
                        add_pixel_grid, border, cpb, out);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_upsample2x_pair(const float *a, int Ca, float scale_a, const float *b, int Cb, int B, int h, int w, float *out_a,
+                                float *out_b, rpe_stream_t stream) {
+    if (B < 0 || Ca < 0 || Cb < 0 || h < 1 || w < 1 || (Ca > 0 && (!a || !out_a)) || (Cb > 0 && (!b || !out_b))) return RPE_EINVAL;
+    if (B == 0 || Ca + Cb == 0) return 0;
+    if (B > 65535 || (int64_t)h * w * 4 >= (1ll << 31)) return RPE_EUNSUPPORTED;
+    const int P = 4 * h * w;
+    const int cpb = channel_split(Ca + Cb, P, B);
+    dim3 grid((P + 255) / 256, (Ca + Cb + cpb - 1) / cpb, B);
+    hipLaunchKernelGGL(upsample2x_pair_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, Ca, scale_a, b, Cb, h, w, cpb, out_a, out_b);
     return rpe_launch_status();
 }
 

@@ -18,7 +18,8 @@ import torch.nn.functional as F
 from .csrc import correlation2d as native_correlation2d
 from .csrc.wrapper import _correlation2d_algo as correlation2d_fused_leaky
 from .hotpath import native_ops
-from .utils import Conv1dNormRelu, Conv2dNormRelu, mesh_grid
+from .utils import Conv1dNormRelu, Conv2dNormRelu, mesh_grid, upsample2x_pair
+from .utils import backwarp_2d as native_backwarp_2d
 
 
 class Config(dict):
@@ -626,8 +627,11 @@ class RPEFlow_core(nn.Module):
                 last_flow_2d, last_flow_feat_2d = zeros(batch_size, 2, image_h, image_w), zeros(batch_size, 32, image_h, image_w)
                 feat2_2d_warp = feat2_2d_fused
             else:
-                last_flow_2d = F.interpolate(flows_2d[-1] * 2, scale_factor=2, mode="bilinear", align_corners=True)
-                last_flow_feat_2d = F.interpolate(flow_feats_2d[-1], scale_factor=2, mode="bilinear", align_corners=True)
+                if flows_2d[-1].is_cuda and backwarp_2d is native_backwarp_2d:
+                    last_flow_2d, last_flow_feat_2d = upsample2x_pair(flows_2d[-1], flow_feats_2d[-1], scale_a=2.0)
+                else:
+                    last_flow_2d = F.interpolate(flows_2d[-1] * 2, scale_factor=2, mode="bilinear", align_corners=True)
+                    last_flow_feat_2d = F.interpolate(flow_feats_2d[-1], scale_factor=2, mode="bilinear", align_corners=True)
                 feat2_2d_warp = backwarp_2d(feat2_2d_fused, last_flow_2d, padding_mode="border")
             if feat1_2d.is_cuda and correlation2d is native_correlation2d:  # leaky_relu of :362 fused into the kernel's epilogue
                 feat_corr_2d = correlation2d_fused_leaky(feat1_2d, feat2_2d_warp, md, 0, leaky_slope=0.1)

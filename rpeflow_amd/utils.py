@@ -237,6 +237,22 @@ def backwarp_2d(x, flow12, padding_mode):
     return out
 
 
+def upsample2x_pair(a, b, scale_a=1.0):
+    """(F.interpolate(a * scale_a, x2), F.interpolate(b, x2)), bilinear with align_corners=True, for two [B,C,h,w] tensors
+    of one spatial size in one launch: the coarse flow (x2) and its features on their way to the next finer level
+    (RPEFlow_core.py:364-369)."""
+    _lib.require_gpu(a, b, op="upsample2x_pair")
+    a, b = _f32(a).contiguous(), _f32(b).contiguous()
+    assert a.shape[0] == b.shape[0] and a.shape[2:] == b.shape[2:]
+    B, Ca, h, w = a.shape
+    Cb = b.shape[1]
+    out_a = torch.empty((B, Ca, 2 * h, 2 * w), dtype=torch.float32, device=a.device)
+    out_b = torch.empty((B, Cb, 2 * h, 2 * w), dtype=torch.float32, device=a.device)
+    _launch(a, "upsample2x_pair", _lib.lib().rpe_upsample2x_pair, _ptr(a), Ca, float(scale_a), _ptr(b), Cb, B, h, w,
+            _ptr(out_a), _ptr(out_b))
+    return out_a, out_b
+
+
 def grid_sample_wrapper(feat_2d, xy):
     """utils.py:288-294.  feat_2d [B,C,H,W], xy [B,2,N] -> [B,C,N]; zeros outside the image."""
     _lib.require_gpu(feat_2d, xy, op="grid_sample_wrapper")

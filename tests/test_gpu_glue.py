@@ -196,3 +196,19 @@ def test_events_to_voxel_full_size_conservation():
     assert abs(pos - n_pos) < 1e-3 * n and abs(neg - (n - n_pos)) < 1e-3 * n
     per_pixel = torch.zeros(H * W, dtype=torch.float64).index_add_(0, torch.from_numpy((ev[:, 1] * W + ev[:, 0]).astype(np.int64)), torch.ones(n, dtype=torch.float64))
     assert float((vox.double().sum(0).cpu().reshape(-1) - per_pixel).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("B,Ca,Cb,h,w", [(4, 2, 32, 9, 15), (2, 2, 32, 18, 30), (1, 3, 5, 1, 7), (2, 2, 0, 36, 60), (1, 1, 1, 1, 1)])
+def test_upsample2x_pair_matches_interpolate(B, Ca, Cb, h, w):
+    """The decoder's coarse-to-fine hand-over in one launch == F.interpolate(a*2, x2), F.interpolate(b, x2) (align_corners)."""
+    import torch.nn.functional as F
+    from rpeflow_amd.utils import upsample2x_pair
+    g = torch.Generator().manual_seed(B * 100 + h)
+    a, b = torch.randn(B, Ca, h, w, generator=g), torch.randn(B, Cb, h, w, generator=g)
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True)
+    want_a, want_b = up(a * 2), (up(b) if Cb else b.new_zeros(B, 0, 2 * h, 2 * w))   # CPU: the reference's path
+    got_a, got_b = upsample2x_pair(a.cuda(), b.cuda(), scale_a=2.0)
+    assert got_a.shape == want_a.shape and got_b.shape == want_b.shape
+    assert (got_a.cpu() - want_a).abs().max().item() <= 2e-6 * max(1.0, want_a.abs().max().item())
+    if Cb:
+        assert (got_b.cpu() - want_b).abs().max().item() <= 2e-6 * max(1.0, want_b.abs().max().item())
