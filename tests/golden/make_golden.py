@@ -231,8 +231,69 @@ def gen_model_full():
     save("model_544x960", flow_2d_s8=f2[:, :, ::8, ::8].copy(), flow_3d=f3, epe2d=np.float64(epe2), epe3d=np.float64(epe3), **ids_clouds())
 
 
+def gen_eval():
+    """The reference's evaluation loops themselves (eval_withocc.py:45-135, eval_noocc.py:45-116), unmodified, over the
+    synthetic frame pairs and the stand-in predictions of tests/test_evaluate.py; stored: the accumulated metric sums.
+    The scripts import their whole project at module level -- datasets, visualisation, configuration -- through modules
+    that are not installed here (cv2, imageio, h5py, omegaconf) and that ``Evaluator.run`` never touches: empty placeholder
+    modules satisfy those import statements and ``factory`` (dataset / model construction, unused by ``run``) is a
+    placeholder as a whole.  ``Evaluator.__init__`` (dataset, checkpoint) is bypassed: the object gets a list of batches
+    and a stand-in model.  torch.cuda.synchronize() is a no-op for the CPU run.  The metric dictionaries are locals of
+    ``run``; a profile hook copies them when the function returns."""
+    import types
+    from rpeflow_amd.evaluate import collate
+    from rpeflow_amd.synthetic import SyntheticPairs
+    from tests.test_evaluate import fake_model
+    for name in ("cv2", "imageio", "h5py"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    if "omegaconf" not in sys.modules:
+        omegaconf = types.ModuleType("omegaconf")
+        omegaconf.DictConfig = dict
+        sys.modules["omegaconf"] = omegaconf
+    factory = types.ModuleType("factory")
+    factory.model_factory = factory.dataset_factory = None
+    sys.modules["factory"] = factory
+
+    class StandIn:
+        def eval(self):
+            return self
+
+        def forward(self, inputs, is_Train=False):
+            return fake_model(inputs)
+
+    def run(module_name, dsec):
+        module = __import__(module_name)
+        data = SyntheticPairs(5, H=24, W=40, N=512, dsec=dsec)
+        ev = object.__new__(module.Evaluator)
+        ev.device, ev.cfgs, ev.model = torch.device("cpu"), None, StandIn()
+        ev.test_loader = [collate([data[i] for i in idx]) for idx in ((0, 1), (2, 3), (4,))]
+        got = {}
+
+        def hook(frame, event, arg):
+            if event == "return" and frame.f_code.co_name == "run" and frame.f_code.co_filename.endswith(module_name + ".py"):
+                got.update({k: dict(v) for k, v in frame.f_locals.items() if k.startswith("metrics_")})
+        sync, torch.cuda.synchronize = torch.cuda.synchronize, (lambda *a, **k: None)
+        sys.setprofile(hook)
+        try:
+            with contextlib.redirect_stderr(io.StringIO()):  # tqdm
+                ev.run()
+        finally:
+            sys.setprofile(None)
+            torch.cuda.synchronize = sync
+        return got
+
+    m = run("eval_withocc", dsec=False)
+    withocc = [m["metrics_2d"][k] for k in ("counts", "EPE2d", "1px", "Fl")] + [m["metrics_3d"][k] for k in ("counts", "EPE3d", "5cm", "10cm")] + [
+        m["metrics_3d_noc"][k] for k in ("counts", "EPE3d", "5cm", "10cm")]
+    m = run("eval_noocc", dsec=True)
+    noocc = [m["metrics_2d"][k] for k in ("counts", "EPE2d", "1px", "Fl")] + [m["metrics_3d"][k] for k in ("counts", "EPE3d", "5cm", "10cm")]
+    print("withocc", withocc, "\nnoocc", noocc)
+    save("eval_accumulators", withocc=np.asarray(withocc, np.float64), noocc=np.asarray(noocc, np.float64))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events"]
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval"]
     for w in which:
         globals()["gen_" + w]()

@@ -39,6 +39,7 @@ def reference_style(outputs, inputs):
 def fake_model(batch):
     """Deterministic stand-in: the targets plus a sample-dependent error (and a few NaNs to exercise the mask)."""
     f2 = batch["flow_2d"][:, :2].float() + 0.8 * torch.sin(batch["event_voxel"][:, :2].float() * 3.0)
+    f2 = f2 + 6.0 * (batch["event_voxel"][:, 2:4].float() > 1.2).float()  # a tenth of the pixels far off: the Fl criterion fires
     f3 = batch["flow_3d"][:, :3].float() + 0.06 * torch.cos(batch["pcs"][:, :3].float() * 5.0)
     f3[:, :, ::97] = float("nan")
     return {"flow_2d": f2, "flow_3d": f3}
@@ -121,6 +122,26 @@ def test_two_process_gloo_all_reduce_equals_single_process(tmp_path):
     _, single = E.evaluate(fake_model, data, batch_size=2, device="cpu")
     np.testing.assert_allclose(np.array(accs[0]), single.numpy(), rtol=1e-12)
     assert accs[0][0] == single[0].item() and accs[0][4] == single[4].item()
+
+
+def test_accumulators_match_the_reference_loops():
+    """tests/golden/eval_accumulators.npz: the metric sums the reference's own Evaluator.run loops (eval_withocc.py:45-135,
+    eval_noocc.py:45-116, run unmodified by tests/golden/make_golden.py) reach on these frame pairs and predictions."""
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "eval_accumulators.npz"))
+    for dsec, key, n in ((False, "withocc", 12), (True, "noocc", 8)):
+        data = SyntheticPairs(5, H=24, W=40, N=512, dsec=dsec)
+        acc = E.new_accumulator("cpu")
+        for idx in ((0, 1), (2, 3), (4,)):
+            batch = E.collate([data[i] for i in idx])
+            E.accumulate(acc, fake_model(batch), batch)
+        got, want = acc.numpy()[:n], golden[key]
+        hits = [0, 2, 3, 4, 6, 7, 8, 10, 11][:6 if n == 8 else 9]
+        assert np.array_equal(got[hits], want[hits]), (key, got, want)          # counts and threshold hits: exact
+        sums = [i for i in range(n) if i not in hits]
+        np.testing.assert_allclose(got[sums], want[sums], rtol=2e-6)             # fp32 per-sample sums there, float64 here
+        assert want[3] > 0 and want[2] > 0                                       # the case exercises 1px and Fl
+        if n == 8:
+            assert acc.numpy()[8:].sum() == 0                                    # no occlusion group without occ_mask_3d
 
 
 @pytest.mark.gpu
