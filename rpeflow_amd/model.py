@@ -715,6 +715,7 @@ class RPEFlow(nn.Module):
         self.cfgs = cfgs or things_config()
         self.ids_on_host = ids_on_host
         self.overlap_streams = True
+        self.keep_levels = False  # also return every pyramid level's up-sampled flows, as decode() hands them over (tests)
         self._streams = {}
         self.pwc_fusion_core = RPEFlow_core(self.cfgs.pwc2d, self.cfgs.pwc3d, self.cfgs.get("attention"), ops=ops)
 
@@ -832,10 +833,14 @@ class RPEFlow(nn.Module):
         side = self._side_stream(pc1.device) if (pc1.is_cuda and self.overlap_streams) else None
         pre = self._side_stream(pc1.device, "pre") if side is not None else None
         flows_2d, flows_3d = core.decode(xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d,
-                                         paral if self.cfgs.ids.enabled else persp, side_stream=side, pre_stream=pre)
+                                         paral if self.cfgs.ids.enabled else persp, side_stream=side, pre_stream=pre,
+                                         all_levels=self.keep_levels)
         _stamp("main decode done")
         flow_3d = flows_3d[0]
         if self.cfgs.ids.enabled:
             xyz1 = xyzs1[0]
             flow_3d = parallel2perspect(xyz1 + flow_3d, persp, paral) - parallel2perspect(xyz1, persp, paral)
-        return {"flow_2d": resize_flow2d(flows_2d[0], origin_h, origin_w), "flow_3d": flow_3d}
+        out = {"flow_2d": resize_flow2d(flows_2d[0], origin_h, origin_w), "flow_3d": flow_3d}
+        if self.keep_levels:  # what RPEFlow_core.decode returns (RPEFlow_core.py:432), 3-D flows still in IDS space
+            out["levels_2d"], out["levels_3d"] = list(flows_2d), list(flows_3d)
+        return out

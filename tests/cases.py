@@ -117,6 +117,8 @@ BLOCK_CASES = {
     "pointconv_down": dict(B=2, M=300, Q=120, C=13, Cout=20, k=16, norm="batch_norm", seed=601),
     "pointconv_nosample": dict(B=2, M=150, Q=150, C=29, Cout=17, k=16, norm=None, seed=602),
     "correlation3d": dict(B=2, N=140, C=12, k=16, seed=603),
+    "flow_estimator3d": dict(B=2, N=200, channels=[20, 24, 24, 16], k=16, seed=604),
+    "feature_pyramid3d": dict(B=2, N=512, samples=[256, 128, 64], channels=[8, 12, 16, 20], norm="batch_norm", k=16, seed=605),
 }
 
 
@@ -129,6 +131,11 @@ def block_inputs(name):
         feat = r.standard_normal((c["B"], c["C"], c["M"]), dtype=np.float32)
         sampled = xyz[:, :, : c["Q"]].copy() if name == "pointconv_down" else None
         return dict(xyz=xyz, feat=feat, sampled=sampled)
+    if name == "flow_estimator3d":
+        return dict(xyz=cl(I.ids_cloud(r, c["B"], c["N"])), feat=r.standard_normal((c["B"], c["channels"][0], c["N"]), dtype=np.float32))
+    if name == "feature_pyramid3d":
+        pc1 = cl(I.ids_cloud(r, c["B"], c["N"]))
+        return dict(pc1=pc1, pc2=(pc1 + r.standard_normal(pc1.shape, dtype=np.float32) * np.float32(0.05)).astype(np.float32))
     xyz1 = cl(I.ids_cloud(r, c["B"], c["N"]))
     xyz2 = (xyz1 + r.standard_normal(xyz1.shape, dtype=np.float32) * np.float32(0.2)).astype(np.float32)
     feat1 = r.standard_normal((c["B"], c["C"], c["N"]), dtype=np.float32)

@@ -139,6 +139,23 @@ def gen_blocks():
     x = K.block_inputs("correlation3d")
     save("correlation3d", out=m(T(x["xyz1"]), T(x["feat1"]), T(x["xyz2"]), T(x["feat2"])).numpy())
 
+    c = K.BLOCK_CASES["flow_estimator3d"]
+    m = ref_3d.FlowEstimator3D(c["channels"], k=c["k"])
+    load_params(m, c["seed"] + 1000)
+    x = K.block_inputs("flow_estimator3d")
+    knn = ref_ops.k_nearest_neighbor(T(x["xyz"]), T(x["xyz"]), k=c["k"])
+    feat, flow = m(T(x["xyz"]), T(x["feat"]), knn)
+    save("flow_estimator3d", feat=feat.numpy(), flow=flow.numpy())
+
+    c = K.BLOCK_CASES["feature_pyramid3d"]
+    m = ref_3d.FeaturePyramid3D(c["channels"], norm=c["norm"], k=c["k"])
+    load_params(m, c["seed"] + 1000)
+    x = K.block_inputs("feature_pyramid3d")
+    xyzs1, xyzs2, idx1, idx2 = ref_3d.build_pc_pyramid(T(x["pc1"]), T(x["pc2"]), c["samples"])
+    feats = m(xyzs1)
+    save("feature_pyramid3d", **{"feat%d" % i: f.numpy() for i, f in enumerate(feats)},
+         **{"index1_%d" % i: v.numpy() for i, v in enumerate(idx1)}, **{"index2_%d" % i: v.numpy() for i, v in enumerate(idx2)})
+
 
 def reference_model():
     """The reference RPEFlow on CPU: things.yaml model section, MI noise drawn on the CPU (the reference
@@ -188,11 +205,22 @@ def gen_model():
     m.eval()
     sample = I.frame_pair(1000, H=128, W=192, N=8192)
     batch = {k: T(v)[None] for k, v in sample.items()}
+    # per-level intermediates: what RPEFlow_core.decode returns (RPEFlow_core.py:432), every pyramid level's up-sampled flows,
+    # before RPEFlow.forward maps the 3-D ones back through the IDS transform
+    levels, decode = {}, m.pwc_fusion_core.decode
+
+    def recording(*a, **k):
+        flows_2d, flows_3d, mi = decode(*a, **k)
+        levels.update({"level%d_flow_2d" % i: f.numpy().copy() for i, f in enumerate(flows_2d)})
+        levels.update({"level%d_flow_3d" % i: f.numpy().copy() for i, f in enumerate(flows_3d)})
+        return flows_2d, flows_3d, mi
+    m.pwc_fusion_core.decode = recording
     out = m(batch, is_Train=False)
+    m.pwc_fusion_core.decode = decode
     f2, f3 = out["flow_2d"].numpy(), out["flow_3d"].numpy()
     assert np.isfinite(f2).all() and np.isfinite(f3).all()
-    print("flow_2d |max|", np.abs(f2).max(), "flow_3d |max|", np.abs(f3).max())
-    save("model_128x192", flow_2d=f2, flow_3d=f3, **ids_clouds())
+    print("flow_2d |max|", np.abs(f2).max(), "flow_3d |max|", np.abs(f3).max(), {k: v.shape for k, v in levels.items()})
+    save("model_128x192", flow_2d=f2, flow_3d=f3, **ids_clouds(), **levels)
 
 
 @torch.no_grad()

@@ -142,6 +142,42 @@ def test_correlation3d_module(golden_dir):
     close_sum(out2, O.correlation3d(p, x["xyz1"], x["feat1"], x["xyz2"], x["feat2"], knn11, c["k"]))
 
 
+def _own_shapes(module):
+    """(key, shape) in state-dict order: the reference's order when the module tree mirrors the reference's."""
+    return [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+
+
+@torch.no_grad()
+def test_flow_estimator3d_module(golden_dir):
+    """pwc3d_core.py:120-148 (two PointConvNoSampling on a shared neighbour table, MLP, 1x1 head) against the reference."""
+    c, x = K.BLOCK_CASES["flow_estimator3d"], K.block_inputs("flow_estimator3d")
+    m = P3.FlowEstimator3D(c["channels"], k=c["k"])
+    m, _ = _load(m, _own_shapes(m), c["seed"] + 1000)
+    xyz = dev(x["xyz"])
+    from rpeflow_amd.csrc import k_nearest_neighbor
+    knn = k_nearest_neighbor(xyz, xyz, k=c["k"])
+    feat, flow = m(xyz, dev(x["feat"]), knn)
+    g = G(golden_dir, "flow_estimator3d")
+    close_sum(feat, g["feat"], what="features vs reference golden")
+    close_sum(flow, g["flow"], what="flow vs reference golden")
+
+
+@torch.no_grad()
+def test_feature_pyramid3d_module(golden_dir):
+    """build_pc_pyramid + FeaturePyramid3D (pwc3d_core.py:8-57): sample indices exactly, every level's features."""
+    c, x = K.BLOCK_CASES["feature_pyramid3d"], K.block_inputs("feature_pyramid3d")
+    m = P3.FeaturePyramid3D(c["channels"], norm=c["norm"], k=c["k"])
+    m, _ = _load(m, _own_shapes(m), c["seed"] + 1000)
+    xyzs1, xyzs2, idx1, idx2 = P3.build_pc_pyramid(dev(x["pc1"]), dev(x["pc2"]), c["samples"])
+    g = G(golden_dir, "feature_pyramid3d")
+    for i in range(len(c["samples"]) + 1):
+        assert np.array_equal(idx1[i].cpu().numpy(), g["index1_%d" % i]) and np.array_equal(idx2[i].cpu().numpy(), g["index2_%d" % i])
+    feats = m(xyzs1)
+    assert len(feats) == len(c["channels"])
+    for i, f in enumerate(feats):
+        close_sum(f, g["feat%d" % i], what="level %d vs reference golden" % i)
+
+
 @torch.no_grad()
 def test_build_pc_pyramid_prefix_property():
     r = I.rng(6200)

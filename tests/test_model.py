@@ -243,3 +243,24 @@ def test_sampling_one_batch_ahead_changes_nothing():
     assert same(out["flow_3d"], plain[0]["flow_3d"])
     out = replayed(batches[1])
     assert same(out["flow_3d"], plain[1]["flow_3d"])
+
+
+@pytest.mark.gpu
+def test_every_pyramid_level_matches_the_reference(golden_dir):
+    """Per-level intermediates: the up-sampled flows of all five decoder levels (what RPEFlow_core.decode returns,
+    RPEFlow_core.py:426-432) against the reference's on the 128x192 golden sample."""
+    from rpeflow_amd.model import RPEFlow
+    model = RPEFlow(ids_on_host=True).eval()
+    model.load_state_dict(seeded_state(model), strict=True)
+    model = model.to("cuda:0")
+    model.keep_levels = True
+    g = np.load(os.path.join(golden_dir, "model_128x192.npz"))
+    out = model(with_reference_ids(sample_batch("cuda:0"), g, "cuda:0"))
+    assert len(out["levels_2d"]) == 5 and len(out["levels_3d"]) == 5
+    for i in range(5):
+        want2, want3 = g["level%d_flow_2d" % i], g["level%d_flow_3d" % i]
+        got2, got3 = out["levels_2d"][i].cpu().numpy(), out["levels_3d"][i].cpu().numpy()
+        assert got2.shape == want2.shape and got3.shape == want3.shape
+        d2, d3 = np.abs(got2 - want2).mean(), np.abs(got3 - want3).mean()
+        print("level %d: mean |d flow_2d| %.2e (|flow| %.2e), mean |d flow_3d| %.2e (|flow| %.2e)" % (i, d2, np.abs(want2).mean(), d3, np.abs(want3).mean()))
+        assert d2 <= 1e-4 * max(1.0, np.abs(want2).mean()) and d3 <= 1e-4 * max(1.0, np.abs(want3).mean())  # measured: 2e-7 relative
