@@ -251,7 +251,8 @@ def main():
                 # sampling of the FOLLOWING batch runs inside this batch's graph on its own stream, this batch starts from
                 # the order the previous replay left; every replay still runs one full FPS over one batch of clouds
                 order = None if args.no_ahead else model.sample_order(batch)
-                with torch.cuda.graph(graph):
+                # thread_local: a query from another thread (the RCCL watchdog of a multi-rank run) must not invalidate the capture
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     out = model(batch) if args.no_ahead else model.forward_ahead(batch, order, batch)
                 for _ in range(max(args.warmup, 1)):  # untimed replays: graph upload, clocks back up after the capture
                     graph.replay()

@@ -119,7 +119,7 @@ class GraphedForward:
             entry["order"] = self.model.sample_order(static)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # other threads (RCCL watchdog) may query events meanwhile
             if self.ahead:
                 entry["out"] = self.model.forward_ahead(static, entry["order"], entry["next"])
             else:

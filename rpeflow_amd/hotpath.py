@@ -80,7 +80,7 @@ class SegmentGraphs(Timer):
         if not self.capturing:
             raise RuntimeError("SegmentGraphs.span outside capture()")
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool):
+        with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
             yield
         self.segments.append((name, g))
 
