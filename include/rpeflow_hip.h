@@ -138,6 +138,13 @@ int rpe_knn_interpolate(const float *in_xyz, int64_t x_sb, int64_t x_sd, int64_t
 int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W,
                         const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sp, int P,
                         int add_pixel_grid, int border, float *out, rpe_stream_t stream);
+/* rpe_resize_frames: RPEFlow.forward's input preparation (models/RPEFlow.py:40-47, utils.py:227-241): src [B,C,H,W]
+ *   (uint8 when src_is_u8, else float) resized to [Ho,Wo] with F.interpolate(bilinear, align_corners=True); each tap is
+ *   divided by ``divisor`` first when divisor != 0 (the images' / 255).  pair_split: C = 2*c channels are the two frames of
+ *   a pair and land stacked on the batch axis, out [2B,c,Ho,Wo] (frame 1 of every sample, then frame 2); else out
+ *   [B,C,Ho,Wo].                                                                                              */
+int rpe_resize_frames(const void *src, int src_is_u8, float divisor, int pair_split, int B, int C, int H, int W,
+                      int Ho, int Wo, float *out, rpe_stream_t stream);
 /* rpe_upsample2x_pair: the 2-D decoder's coarse-to-fine hand-over (models/RPEFlow_core.py:364-369): a [B,Ca,h,w] (times
  *   scale_a) and b [B,Cb,h,w], both F.interpolate(scale_factor=2, mode='bilinear', align_corners=True), in one launch.
  *   out_a [B,Ca,2h,2w], out_b [B,Cb,2h,2w] contiguous.  Either tensor may be absent (C = 0, pointers NULL).        */

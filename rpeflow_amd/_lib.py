@@ -54,6 +54,7 @@ _PROTOTYPES = {
     "rpe_gather_channel_last": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_knn_interpolate": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                             _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
+    "rpe_resize_frames": [_c_ptr, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_upsample2x_pair": [_c_ptr, _c_int, _c_float, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_bilinear_sample": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
                             _c_int, _c_int, _c_ptr, _c_ptr],

@@ -180,6 +180,37 @@ __global__ __launch_bounds__(256) void upsample2x_pair_kernel(const float *__res
     }
 }
 
+// Input preparation of RPEFlow.forward (models/RPEFlow.py:40-47 with utils.py:227-241): the frames resized to multiples
+// of 64 (F.interpolate bilinear, align_corners=True) in one pass -- for the uint8 image pair the conversion to float, the
+// division by 255 and the split into frame 1 / frame 2 stacked on the batch axis ([B,6,H,W] -> [2B,3,Ho,Wo]) are folded in.
+// Per tap v = float(u8) / 255 (a true division, as the reference's), then ATen's h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11).
+template <typename T>
+__global__ __launch_bounds__(256) void resize_frames_kernel(const T *__restrict__ src, int B, int C, int H, int W, int Ho, int Wo, float divisor,
+                                                            int pair_split, int c_per_block, float *__restrict__ out) {
+    const int P = Ho * Wo;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = blockIdx.z;
+    if (p >= P) return;
+    const int y = p / Wo, x = p - y * Wo;
+    const float ry = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, rx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const float sy = ry * (float)y, sx = rx * (float)x;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int yp = y0 < H - 1 ? 1 : 0, xp = x0 < W - 1 ? 1 : 0;
+    const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+    const int o00 = y0 * W + x0, o01 = o00 + xp, o10 = o00 + yp * W, o11 = o10 + xp;
+    const int64_t hw = (int64_t)H * W;
+    const int c0 = blockIdx.y * c_per_block, c1 = min(C, c0 + c_per_block);
+    const int half = C / 2;
+    for (int c = c0; c < c1; ++c) {
+        const T *s = src + ((int64_t)n * C + c) * hw;
+        float v00 = (float)s[o00], v01 = (float)s[o01], v10 = (float)s[o10], v11 = (float)s[o11];
+        if (divisor != 0.f) { v00 = v00 / divisor; v01 = v01 / divisor; v10 = v10 / divisor; v11 = v11 / divisor; }
+        const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        const int64_t plane = pair_split ? ((int64_t)(c / half) * B + n) * half + (c % half) : (int64_t)n * C + c;
+        out[plane * P + p] = v;
+    }
+}
+
 // project_feat_with_nn_corr (utils.py:297-317) in two launches.
 //   point_rows_kernel:   rows[b][i][:] = [ sample(feat_2d[b], xy_i)[0..C2) | feat_3d[b][:, i] ]   (channel-last, per POINT)
 //   project_rows_kernel: for pixel p with nearest point i = nn[b][p]:
@@ -311,6 +342,23 @@ RPE_API int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W, c
     dim3 grid((P + 255) / 256, (C + cpb - 1) / cpb, B);
     hipLaunchKernelGGL(bilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, C, H, W, xy, xy_sb, xy_sd, xy_sp, P,
                        add_pixel_grid, border, cpb, out);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_resize_frames(const void *src, int src_is_u8, float divisor, int pair_split, int B, int C, int H, int W, int Ho, int Wo,
+                              float *out, rpe_stream_t stream) {
+    if (!src || !out || B < 0 || C < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1 || (pair_split && (C & 1))) return RPE_EINVAL;
+    if (B == 0) return 0;
+    if (B > 65535 || (int64_t)Ho * Wo >= (1ll << 31) || (int64_t)H * W >= (1ll << 31)) return RPE_EUNSUPPORTED;
+    const int P = Ho * Wo;
+    const int cpb = channel_split(C, P, B);
+    dim3 grid((P + 255) / 256, (C + cpb - 1) / cpb, B);
+    if (src_is_u8)
+        hipLaunchKernelGGL(resize_frames_kernel<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char *)src, B, C, H, W, Ho,
+                           Wo, divisor, pair_split, cpb, out);
+    else
+        hipLaunchKernelGGL(resize_frames_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, B, C, H, W, Ho, Wo, divisor,
+                           pair_split, cpb, out);
     return rpe_launch_status();
 }
 

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 from .csrc import correlation2d as native_correlation2d
 from .csrc.wrapper import _correlation2d_algo as correlation2d_fused_leaky
 from .hotpath import native_ops
-from .utils import Conv1dNormRelu, Conv2dNormRelu, mesh_grid, upsample2x_pair
+from .utils import Conv1dNormRelu, Conv2dNormRelu, mesh_grid, resize_frames, upsample2x_pair
 from .utils import backwarp_2d as native_backwarp_2d
 
 
@@ -787,21 +787,25 @@ class RPEFlow(nn.Module):
 
     @torch.no_grad()
     def forward(self, inputs, is_Train=False):
-        images = inputs["images"].float() / 255.0
-        intrinsics = inputs["intrinsics"]
-        origin_h, origin_w = images.shape[2:]
-        images = resize_to_64x(images)
-        event_voxel = resize_to_64x(inputs["event_voxel"])
-        image1, image2 = images[:, :3], images[:, 3:]
+        raw, raw_events = inputs["images"], inputs["event_voxel"]
+        origin_h, origin_w = raw.shape[2:]
+        # frames 1 and 2 go through the shared-weight pyramids as one 2B batch (the reference calls encode() twice,
+        # RPEFlow.py:78-79; eval-mode BatchNorm makes the two forms equal sample by sample)
+        if raw.is_cuda and raw.dtype in (torch.uint8, torch.float32) and raw_events.dtype == torch.float32:
+            # / 255, the resize to multiples of 64 and the frame split in one launch; the event grid in one more (or none)
+            size = ((origin_h + 63) // 64 * 64, (origin_w + 63) // 64 * 64)
+            image_both = resize_frames(raw, size, divisor=255.0, pair_split=True)
+            event_voxel = raw_events if tuple(raw_events.shape[2:]) == size else resize_frames(raw_events, size)
+        else:
+            images = resize_to_64x(raw.float() / 255.0)
+            event_voxel = resize_to_64x(raw_events)
+            image_both = torch.cat([images[:, :3], images[:, 3:]], dim=0)
         persp, paral = self._cameras(inputs)
         pc1, pc2 = self._clouds(inputs, persp, paral)
         fps_order = inputs.get("fps_order")
 
         core = self.pwc_fusion_core
         n_samples = self.N_SAMPLES
-        # frames 1 and 2 go through the shared-weight pyramids as one 2B batch (the reference calls encode() twice,
-        # RPEFlow.py:78-79; eval-mode BatchNorm makes the two forms equal sample by sample)
-        image_both = torch.cat([image1, image2], dim=0)
         _stamp("main start")
 
         if pc1.is_cuda and self.overlap_streams:

@@ -237,6 +237,21 @@ def backwarp_2d(x, flow12, padding_mode):
     return out
 
 
+def resize_frames(x, size, divisor=0.0, pair_split=False):
+    """F.interpolate(x.float() / divisor, size, mode='bilinear', align_corners=True) for a uint8 or float [B,C,H,W] tensor
+    in one launch (divisor 0: no division); pair_split: the 2*c channels are two frames, returned as [2B,c,*size] with
+    frame 1 of every sample first -- the input preparation of RPEFlow.forward (RPEFlow.py:40-47, utils.py:227-241)."""
+    _lib.require_gpu(x, op="resize_frames")
+    assert x.dtype in (torch.uint8, torch.float32) and x.dim() == 4
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    shape = (2 * B, C // 2, *size) if pair_split else (B, C, *size)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    _launch(x, "resize_frames", _lib.lib().rpe_resize_frames, _ptr(x), int(x.dtype == torch.uint8), float(divisor), int(pair_split),
+            B, C, H, W, int(size[0]), int(size[1]), _ptr(out))
+    return out
+
+
 def upsample2x_pair(a, b, scale_a=1.0):
     """(F.interpolate(a * scale_a, x2), F.interpolate(b, x2)), bilinear with align_corners=True, for two [B,C,h,w] tensors
     of one spatial size in one launch: the coarse flow (x2) and its features on their way to the next finer level

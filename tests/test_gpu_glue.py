@@ -248,3 +248,25 @@ def test_upsample2x_pair_matches_interpolate(B, Ca, Cb, h, w):
     assert (got_a.cpu() - want_a).abs().max().item() <= 2e-6 * max(1.0, want_a.abs().max().item())
     if Cb:
         assert (got_b.cpu() - want_b).abs().max().item() <= 2e-6 * max(1.0, want_b.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 40, 100), (1, 64, 128), (3, 30, 64)])
+def test_resize_frames_matches_the_reference_preparation(B, H, W):
+    """RPEFlow.forward's input preparation (RPEFlow.py:40-47): images.float()/255 and event grid resized to multiples of 64
+    (utils.py:227-241), frames split -- one launch each, against the same steps on the CPU."""
+    import torch.nn.functional as F
+    from rpeflow_amd.utils import resize_frames
+    g = torch.Generator().manual_seed(H)
+    images = torch.randint(0, 256, (B, 6, H, W), generator=g, dtype=torch.uint8)
+    events = torch.randn(B, 5, H, W, generator=g)
+    size = ((H + 63) // 64 * 64, (W + 63) // 64 * 64)
+    up = lambda t: t if tuple(t.shape[2:]) == size else F.interpolate(t, size=size, mode="bilinear", align_corners=True)
+    ref = up(images.float() / 255.0)
+    want_both, want_events = torch.cat([ref[:, :3], ref[:, 3:]], dim=0), up(events)
+    got_both = resize_frames(images.cuda(), size, divisor=255.0, pair_split=True).cpu()
+    got_float = resize_frames(images.float().cuda(), size, divisor=255.0, pair_split=True).cpu()
+    got_events = resize_frames(events.cuda(), size).cpu()
+    assert got_both.shape == want_both.shape and torch.equal(got_both, got_float)
+    assert (got_both - want_both).abs().max().item() <= 1e-6 and (got_events - want_events).abs().max().item() <= 2e-6 * events.abs().max().item()
+    if size == (H, W):
+        assert torch.equal(got_both, want_both) and torch.equal(got_events, want_events)
