@@ -261,10 +261,11 @@ int rpe_probe_mfma4x4(float *out256, rpe_stream_t stream);
 int rpe_debug_set_fps_variant(int variant);
 /* How k_nearest_neighbor treats EQUAL distances (k <= 17; the reference is matmul + torch.topk on the CPU, i.e.
  * libstdc++'s partial_sort / nth_element, restated in knn.hip):
- *   1 (default) a query whose k-th and (k+1)-th distances tie is redone exactly as torch.topk does it, so the returned
- *               neighbour SET always equals the reference's; equal distances inside the top k stay in index order;
- *   3           any tie among the k+1 best triggers the redo: indices equal the reference's position for position
- *               (a few waves then run much longer: +45 % on a 8192 -> 4096, k = 16 search);
+ *   3 (default) any tie among the k+1 best makes the query redo its selection exactly as torch.topk does it: indices
+ *               equal the reference's position for position (the few waves that redo run much longer: +45 % on a
+ *               8192 -> 4096, k = 16 search, 1 % on the whole forward);
+ *   1           only a tie between the k-th and the (k+1)-th distance triggers the redo: the returned neighbour SET
+ *               still always equals the reference's, equal distances inside the top k stay in index order;
  *   0           lowest index first everywhere (no redo).                                                         */
 int rpe_debug_set_knn_exact_ties(int on);
 /* Writes the GPU's constant-rate clock (100 MHz wall_clock64) to *slot when the stream reaches this point: a

@@ -444,7 +444,7 @@ int pick_qw(int B, int Q) {
     return 1;
 }
 
-int g_knn_exact_ties = 1;
+int g_knn_exact_ties = 3;  // indices equal the reference's position for position; 1: neighbour sets only (cheaper), 0: lowest index
 
 template <int D, int QW>
 void launch_knn(const KnnJobs &jobs, int njobs, int max_q, int min_m, int max_m, int B, int k, hipStream_t st) {

@@ -22,13 +22,12 @@ DEV = "cuda:0"
 
 
 @pytest.fixture(autouse=True)
-def _knn_positions_exact():
-    """The operator tests of this module compare indices position for position with the oracle / the reference, so they
-    run the KNN kernels in mode 3 (order of equal distances reproduced too); the default mode 1 (the reference's
-    neighbour SETS, cheaper) is what test_knn_golden_cases and test_knn_equal_distances_follow_torch_topk check by set."""
+def _knn_default_mode():
+    """Every test starts and ends in the library's default tie mode (3: the reference's indices position for position);
+    the tests that exercise the cheaper modes 1 (sets only) and 0 (lowest index) switch explicitly."""
     _lib.lib().rpe_debug_set_knn_exact_ties(3)
     yield
-    _lib.lib().rpe_debug_set_knn_exact_ties(1)
+    _lib.lib().rpe_debug_set_knn_exact_ties(3)
 
 
 def G(golden_dir, name):
@@ -68,18 +67,21 @@ def test_squared_distance(golden_dir, name):
 @pytest.mark.parametrize("name", list(K.KNN_CASES))
 def test_knn_golden_cases(golden_dir, name):
     inp, qry, k = K.knn_inputs(name)
-    idx, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k)  # mode 3 (module fixture)
+    idx, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k)  # default mode: position for position
     idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
-    _lib.lib().rpe_debug_set_knn_exact_ties(1)
     default_idx = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
-    assert np.array_equal(np.sort(default_idx, -1), np.sort(idx, -1)), name + ": default mode returns another neighbour set"
+    assert np.array_equal(default_idx, idx)
+    _lib.lib().rpe_debug_set_knn_exact_ties(1)
+    sets_only = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
+    _lib.lib().rpe_debug_set_knn_exact_ties(3)
+    assert np.array_equal(np.sort(sets_only, -1), np.sort(idx, -1)), name + ": mode 1 returns another neighbour set"
     oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True)
     assert np.array_equal(idx, oi), f"{name}: {(idx != oi).sum()} indices differ from the oracle"
     assert_bits_equal(dist, od, name + " distances vs oracle")
     g = G(golden_dir, name)
     assert np.array_equal(idx, g["idx"]), name + ": indices differ from the reference's torch.topk output"
     assert_bits_equal(dist, g["dist"], name + " distances vs reference golden")
-    # public entry point, both layouts (wrapper.py:119-122): default mode = the reference's neighbour sets
+    # public entry point, both layouts (wrapper.py:119-122)
     assert np.array_equal(default_idx, ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy())
     if inp.shape[1] > 3:
         cf = ops.k_nearest_neighbor(input_xyz=dev(inp.transpose(0, 2, 1)), query_xyz=dev(qry.transpose(0, 2, 1)), k=k)
@@ -320,17 +322,16 @@ def test_knn_equal_distances_follow_torch_topk(B, M, Q, D, k):
     dmat += torch.sum(ti ** 2, -1).view(B, 1, M)
     ref_idx = dmat.topk(k, dim=2, largest=False).indices.numpy()          # wrapper.py:115-117 on the CPU
     assert np.array_equal(O.k_nearest_neighbor(inp, qry, k), ref_idx)      # the oracle's restatement of it
-    _lib.lib().rpe_debug_set_knn_exact_ties(1)
-    got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()  # default: the reference's neighbour SET, always
-    assert np.array_equal(np.sort(got, -1), np.sort(ref_idx, -1)), "default mode returns another neighbour set"
+    got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()  # default: position for position, order of equal distances included
+    assert np.array_equal(got, ref_idx), f"{(got != ref_idx).sum()} of {got.size} indices differ"
     try:
-        _lib.lib().rpe_debug_set_knn_exact_ties(3)  # position for position, order of equal distances included
+        _lib.lib().rpe_debug_set_knn_exact_ties(1)  # cheaper: the reference's neighbour SET, always
         got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
-        assert np.array_equal(got, ref_idx), f"{(got != ref_idx).sum()} of {got.size} indices differ"
+        assert np.array_equal(np.sort(got, -1), np.sort(ref_idx, -1)), "mode 1 returns another neighbour set"
         # the plain lowest-index rule is still available and still a valid neighbour set
         _lib.lib().rpe_debug_set_knn_exact_ties(0)
         low, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k)
         oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True, ties="index")
         assert np.array_equal(low.cpu().numpy(), oi)
     finally:
-        _lib.lib().rpe_debug_set_knn_exact_ties(1)
+        _lib.lib().rpe_debug_set_knn_exact_ties(3)
