@@ -12,11 +12,18 @@ voxel + two 8192-point clouds), random-init weights, inputs resident in HBM.
 --workload hotpath times the hot-path operator sequence alone (rpeflow_amd/hotpath.py).
 Frame pairs are independent, so ranks shard them with no data-path collective (weak
 scaling: B per GPU); the only collective is the MAX over ranks of the timed region.
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line.  Started without a launcher (no WORLD_SIZE in the environment),
+``--gpus N`` with N > 1 starts N fresh child processes itself, one per GPU, before this
+process touches the GPU (cf. the reference's mp.spawn, train.py:289, 65).
 
 Extra objects on the line ("Measurement"):
   roofline       the dominant single-kernel category of the step: algorithmic bytes per
                  launch / average launch duration (HIP events inside the timed region)
+  hotpath        the hot-path operator sequence alone, per category: ms, algorithmic bytes,
+                 fraction of the 8 TB/s roofline, and the whole-forward hot-path fraction
+                 (sum of bytes / sum of durations / 8 TB/s)
+  epe_delta      |EPE2D|, |EPE3D| differences of THIS configuration's output (the replayed
+                 graph, untimed) against the reference's CPU forward on the same batch
   roofline_corr  BASELINE config 2, the correlation-only microbench 1x256x544x960 (N=1 only)
   cpu_baseline   the PyTorch-CPU port of the reference fallback (oracle/torch_ref.py) on the
                  host cores, bounded sample (rank 0, N=1 only)
@@ -29,7 +36,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import rpeflow_amd  # noqa: F401,E402 -- first: sets the HIP runtime's graph-queue count before the GPU is initialised
+from rpeflow_amd import runtime  # noqa: E402
+
+RUNTIME = runtime.configure()  # before anything initialises the HIP runtime (graph-queue count; MIOpen solvers stay at defaults)
 
 import torch  # noqa: E402
 
@@ -48,30 +57,10 @@ def parse():
     p.add_argument("--no-corr-microbench", action="store_true")
     p.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     p.add_argument("--no-ahead", action="store_true", help="sample each batch's clouds inside its own forward instead of one batch ahead")
-    p.add_argument("--workload", choices=["forward", "hotpath"], default="forward")
+    p.add_argument("--workload", choices=["forward", "hotpath", "selftest"], default="forward",
+                   help="selftest: the rank launcher and timing protocol alone, on CPU tensors (tests/test_bench_launcher.py)")
+    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
     return p.parse_args()
-
-
-def algorithmic_bytes(workload, B):
-    """Per-LAUNCH algorithmic bytes of each single-kernel category,
-    averaged over the launches of that category in one step."""
-    sizes, N = workload.sizes, [NPTS, 4096, 2048, 1024, 512, 256]
-    C2 = [16, 32, 64, 96, 128, 192]
-    out = {}
-    # FPS(B,N,S): 12*B*N + 8*B*S ; one launch over 2B clouds
-    out["fps+pyramid"] = 12 * 2 * B * NPTS + 8 * 2 * B * 4096
-    # KNN(B,Q,M,D,k): 4*B*D*(Q+M) + 8*B*Q*k
-    knn2d = [4 * B * 2 * (sizes[l][0] * sizes[l][1] + N[l]) + 8 * B * sizes[l][0] * sizes[l][1] for l in range(1, 6)]
-    out["knn2d_k1"] = sum(2 * b for b in knn2d) / (2 * len(knn2d))
-    knn3d = [4 * B * 3 * 2 * N[l] + 8 * B * N[l] * 16 for l in range(1, 6)]
-    out["knn3d_k16"] = sum(knn3d) / len(knn3d)
-    # correlation2d: 2*B*C*H*W*4 + B*81*H*W*4
-    corr = [(2 * C2[l] + 81) * 4 * B * sizes[l][0] * sizes[l][1] for l in range(1, 6)]
-    out["correlation2d"] = sum(corr) / len(corr)
-    # backwarp_2d: 4*B*H*W*(2C+2), levels 4..1
-    bw = [4 * B * sizes[l][0] * sizes[l][1] * (2 * C2[l] + 2) for l in range(1, 5)]
-    out["backwarp_2d"] = sum(bw) / len(bw)
-    return out
 
 
 def corr_microbench(dev, iters=40):
@@ -128,9 +117,26 @@ def make_batch(B, device, first_seed=1000):
     return {k: torch.stack([torch.from_numpy(s[k]) for s in samples]).to(device) for k in samples[0]}
 
 
+def golden_epe_delta(out, batch, golden):
+    """|EPE - reference EPE| of a forward over the benched batch: EPE2D / EPE3D against the synthetic targets, compared with
+    the EPEs of the reference's CPU forward on the same batch and parameters (tests/golden/model_bench_b4_544x960.npz, made
+    by tests/golden/make_golden.py model_bench), plus the mean absolute flow differences."""
+    import numpy as np
+    f2, f3 = out["flow_2d"].float().cpu().numpy(), out["flow_3d"].float().cpu().numpy()
+    t2, t3 = batch["flow_2d"].cpu().numpy()[:, :2], batch["flow_3d"].cpu().numpy()[:, :3]
+    epe2 = float(np.sqrt(((f2 - t2) ** 2).sum(1)).mean())
+    epe3 = float(np.sqrt(((f3 - t3) ** 2).sum(1)).mean())
+    return {"epe2d": abs(epe2 - float(golden["epe2d"])), "epe3d": abs(epe3 - float(golden["epe3d"])),
+            "mean_abs_flow_2d": float(np.abs(f2[:, :, ::8, ::8] - golden["flow_2d_s8"]).mean()),
+            "mean_abs_flow_3d": float(np.abs(f3 - golden["flow_3d"]).mean())}
+
+
+CPU_BATCH = 4  # conf/test/things.yaml batch_size, the benched batch
+
+
 def cpu_baseline_worker(workload):
     """Child process (never touches the GPU): the reference's CPU/PyTorch fallback path, restated in
-    oracle/torch_ref.py, on the host cores.  Sample: batch 1, full size, 1 untimed + 2 timed steps."""
+    oracle/torch_ref.py, on the host cores.  Sample: batch 4 (the benched batch), full size, 1 untimed + 3 timed steps."""
     from types import SimpleNamespace
     from oracle import torch_ref
     from rpeflow_amd.hotpath import OP_NAMES, HotPathWorkload
@@ -139,21 +145,21 @@ def cpu_baseline_worker(workload):
     ops = SimpleNamespace(**{n: getattr(torch_ref, n) for n in OP_NAMES})
     if workload == "forward":
         from rpeflow_amd.model import RPEFlow
-        torch.manual_seed(0)
-        model = RPEFlow(ops=ops).eval()
-        batch = make_batch(1, "cpu")
+        from rpeflow_amd.synthetic import load_seeded_parameters
+        model = load_seeded_parameters(RPEFlow(ops=ops)).eval()
+        batch = make_batch(CPU_BATCH, "cpu")
         step, what = (lambda: model(batch)), "full RPEFlow forward"
     else:
-        wl = HotPathWorkload(batch=1, height=H, width=W, n_points=NPTS, device="cpu", ops=ops)
+        wl = HotPathWorkload(batch=CPU_BATCH, height=H, width=W, n_points=NPTS, device="cpu", ops=ops)
         step, what = wl, "hot-path operator sequence"
     step()
-    steps = 2
+    steps = 3
     t0 = time.time()
     for _ in range(steps):
         step()
     dt = (time.time() - t0) / steps
-    print(json.dumps({"value": round(1.0 / dt, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-                      "sample": f"{steps} timed steps (+1 warm-up) of the {what}, batch 1, 544x960 + 8192 pts, "
+    print(json.dumps({"value": round(CPU_BATCH / dt, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+                      "sample": f"{steps} timed steps (+1 warm-up) of the {what}, batch {CPU_BATCH}, 544x960 + 8192 pts, "
                                 f"PyTorch-CPU port of the reference fallback path (matmul+topk KNN, Python-loop FPS, "
                                 f"81-slice correlation, stock CPU convs/attention), {dt:.2f} s/step, "
                                 f"host cpu_count={os.cpu_count()}"}))
@@ -174,33 +180,71 @@ def cpu_baseline(workload, timeout_s=420):
                 "sample": f"worker exceeded {timeout_s} s"}
 
 
+def launch_ranks(n_ranks, argv):
+    """``--gpus N`` without a launcher: start N fresh processes of this script, one per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, the reference's mp.spawn pattern of train.py:289, 65), before this
+    process has initialised the GPU (it never does).  Rank 0 prints the JSON line; the exit code is the worst child's."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT))
+    worst = 0
+    while procs:
+        for proc in list(procs):
+            rc = proc.poll()
+            if rc is None:
+                continue
+            procs.remove(proc)
+            if rc != 0:  # one rank failed: the others would wait in a collective for ever
+                worst = worst or rc
+                for other in procs:
+                    other.terminate()
+        time.sleep(0.05)
+    return worst
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.workload)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    on_gpu = args.workload != "selftest"
+    if on_gpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation in rpeflow_amd")
+    if not on_gpu and args.backend != "gloo":
+        raise SystemExit("--workload selftest runs on CPU tensors: use --backend gloo")
     dist = None
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": dev} if on_gpu else {}))
+        assert dist.get_world_size() == args.gpus
 
-    from rpeflow_amd import _lib
-    from rpeflow_amd.hotpath import HotPathWorkload, SegmentGraphs, Timer
-    _lib.lib()  # fail loudly now if librpeflow_hip.so is missing
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     def timed(step):
         barrier()
@@ -214,6 +258,27 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
+
+    def finish(line):
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+
+    if not on_gpu:  # launcher + timing protocol only
+        a = torch.randn(64, 64)
+        for _ in range(args.warmup):
+            a @ a
+        dt = timed(lambda: a @ a)
+        return finish({"metric": "selftest steps/s (launcher and timing protocol only, CPU tensors)", "value": round(args.steps * world / dt, 3),
+                       "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                       "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                       "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": {"workload": "selftest", "backend": args.backend}})
+
+    from rpeflow_amd import _lib, roofline
+    from rpeflow_amd.hotpath import HotPathWorkload, SegmentGraphs, Timer
+    _lib.lib()  # fail loudly now if librpeflow_hip.so is missing
 
     # ---- hot-path sequence: per-category events (and the timed workload if --workload hotpath)
     wl = HotPathWorkload(batch=args.batch, height=H, width=W, n_points=NPTS, device=dev, seed=1000 + rank)
@@ -232,82 +297,97 @@ def main():
     dt = dt_hot
 
     # ---- full forward
+    epe_delta = None
     if args.workload == "forward":
         from rpeflow_amd.model import RPEFlow
+        from rpeflow_amd.synthetic import load_seeded_parameters
         # (eval_withocc.py:159 sets cudnn.benchmark; measured here it buys <1 % and costs minutes of MIOpen search per process)
-        torch.manual_seed(0)
-        model = RPEFlow().to(dev).eval()
+        model = load_seeded_parameters(RPEFlow()).to(dev).eval()  # the parameters of the committed model goldens
         batch = make_batch(args.batch, dev, first_seed=1000 + rank * args.batch)
         for _ in range(max(args.warmup, 1)):
             out = model(batch)
-        torch.cuda.synchronize()
+        sync()
         assert torch.isfinite(out["flow_2d"]).all() and torch.isfinite(out["flow_3d"]).all(), "non-finite flow"
         fwd_step, launch = (lambda: model(batch)), "eager"
         if not args.eager:
-            try:  # the whole forward as ONE HIP graph: ~3000 launches and the Python between them replayed in one call
-                graph = torch.cuda.CUDAGraph()
-                eager_out = {k: v.clone() for k, v in out.items()}
-                # default: the evaluation harness's schedule (rpeflow_amd.evaluate.GraphedForward) -- the furthest-point
-                # sampling of the FOLLOWING batch runs inside this batch's graph on its own stream, this batch starts from
-                # the order the previous replay left; every replay still runs one full FPS over one batch of clouds
-                order = None if args.no_ahead else model.sample_order(batch)
-                # thread_local: a query from another thread (the RCCL watchdog of a multi-rank run) must not invalidate the capture
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    out = model(batch) if args.no_ahead else model.forward_ahead(batch, order, batch)
-                for _ in range(max(args.warmup, 1)):  # untimed replays: graph upload, clocks back up after the capture
-                    graph.replay()
-                torch.cuda.synchronize()
-                fwd_step, launch = graph.replay, "one HIP graph per forward" + (
-                    "" if args.no_ahead else "; furthest-point sampling runs one batch ahead (the next batch's FPS inside this graph)")
-            except Exception as e:  # noqa: BLE001 -- capture is an optimisation, not a requirement
-                torch.cuda.synchronize()
-                launch = "eager (graph capture failed: %s)" % type(e).__name__
-            if fwd_step == graph.replay:  # the replayed graph (two-stream branches included) must reproduce the eager forward
-                for key in ("flow_2d", "flow_3d"):
-                    err = (out[key] - eager_out[key]).abs().mean().item() / (eager_out[key].abs().mean().item() + 1e-6)
-                    assert err < 1e-3, "graph replay differs from the eager forward: relative mean |d %s| = %g" % (key, err)
+            # the whole forward as ONE HIP graph: ~1400 launches and the Python between them replayed in one call.  A failed
+            # capture is an error, not a reason to time something else.
+            graph = torch.cuda.CUDAGraph()
+            eager_out = {k: v.clone() for k, v in out.items()}
+            # default: the evaluation harness's schedule (rpeflow_amd.evaluate.GraphedForward) -- the furthest-point
+            # sampling of the FOLLOWING batch runs inside this batch's graph on its own stream, this batch starts from
+            # the order the previous replay left; every replay still runs one full FPS over one batch of clouds
+            order = None if args.no_ahead else model.sample_order(batch)
+            # thread_local: a query from another thread (the RCCL watchdog of a multi-rank run) must not invalidate the capture
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                out = model(batch) if args.no_ahead else model.forward_ahead(batch, order, batch)
+            for _ in range(max(args.warmup, 1)):  # untimed replays: graph upload, clocks back up after the capture
+                graph.replay()
+            sync()
+            fwd_step, launch = graph.replay, "one HIP graph per forward" + (
+                "" if args.no_ahead else "; furthest-point sampling runs one batch ahead (the next batch's FPS inside this graph)")
+            for key in ("flow_2d", "flow_3d"):  # the replayed graph (multi-stream branches included) must reproduce the eager forward
+                err = (out[key] - eager_out[key]).abs().mean().item() / (eager_out[key].abs().mean().item() + 1e-6)
+                assert err < 1e-3, "graph replay differs from the eager forward: relative mean |d %s| = %g" % (key, err)
+        golden = os.path.join(ROOT, "tests", "golden", "model_bench_b4_544x960.npz")
+        if rank == 0 and args.batch == 4 and os.path.exists(golden):  # untimed: this configuration's output vs the reference's
+            import numpy as np
+            d = golden_epe_delta(out, batch, np.load(golden))
+            epe_delta = {"epe2d": float("%.3g" % d["epe2d"]), "epe3d": float("%.3g" % d["epe3d"]), "bound": 1e-4,
+                         "against": "the reference's CPU forward on this batch and these parameters (tests/golden/model_bench_b4_544x960.npz)"}
+            assert d["epe2d"] < 1e-4 and d["epe3d"] < 1e-4, "benched configuration is off the reference: %r" % (d,)
         dt = timed(fwd_step)
 
     totals = timer.totals_ms()
+    line = None
     if rank == 0:
         pairs = args.batch * args.steps * world
-        breakdown = {k: round(v[0] / args.steps, 3) for k, v in sorted(totals.items(), key=lambda kv: -kv[1][0])}
-        alg = algorithmic_bytes(wl, args.batch)
-        single = {k: totals[k] for k in alg if k in totals}
-        dom = max(single, key=lambda k: single[k][0])
-        dom_us = single[dom][0] / single[dom][1] * 1e3
-        gbs = alg[dom] / dom_us / 1e3
+        alg = roofline.hotpath_bytes(args.batch, wl.sizes, NPTS)
+        table, sum_b, sum_ms = {}, 0, 0.0
+        for k, (ms, n) in sorted(totals.items(), key=lambda kv: -kv[1][0]):
+            ms_step = ms / args.steps
+            b = alg.get(k, 0)
+            table[k] = {"ms": round(ms_step, 3), "algorithmic_MB": round(b / 1e6, 2),
+                        "frac": round(b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_step > 0 else None}
+            sum_b, sum_ms = sum_b + b, sum_ms + ms_step
+        fps_us = totals["fps+pyramid"][0] / totals["fps+pyramid"][1] * 1e3
+        fps_bytes = roofline.fps(2 * args.batch, NPTS, 4096)
         line = {
             "metric": "frame-pairs/sec (544x960 + 8192 pts)",
             "value": round(pairs / dt, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("full RPEFlow forward (RGB pair + 20-ch event voxel + 2x8192 pts), random-init weights, "
+            "config": {"workload": ("full RPEFlow forward (RGB pair + 20-ch event voxel + 2x8192 pts), seeded random-init weights, "
                                     "FlyingThings3D val shapes (BASELINE config 3)") if args.workload == "forward" else
                                    ("RPEFlow hot path only (FPS, 43 KNN, correlation2d, warps, gathers, PointConv, Correlation3D) "
                                     "at FlyingThings3D shapes; dense 2D convs/attention excluded"),
                        "frame": [H, W], "points": NPTS, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "sharding": f"frame pairs over {world} rank(s), no data-path collective",
-                       "launch": launch},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("fps_pmc.json") if dom == "fps+pyramid" else None,
-                         "us_per_launch": round(dom_us, 1),
-                         "launches_per_step": single[dom][1] // args.steps,
-                         **({"note": "FPS is bound by the latency of 4095 DEPENDENT sampling iterations per cloud (SURVEY.md 8d), "
-                                     "one workgroup per cloud on 2B of 256 CUs, not by HBM or MFMA: the HBM fraction is reported for "
-                                     "form only; see us_per_iteration against the measured floor of the per-iteration "
-                                     "reduce-barrier-broadcast chain (DESIGN.md section 4.3); roofline_corr is the bandwidth-bound kernel",
-                             "us_per_iteration": round(dom_us / 4095, 4), "iteration_sync_floor_us": 0.41}
-                            if dom == "fps+pyramid" else {})},
+                       "launch": launch, "runtime": RUNTIME},
+            "roofline": {"kernel": "fps_pruned2_kernel (furthest_point_sampling, 2B clouds 8192 -> 4096)", "bound": "latency",
+                         "achieved": round(fps_bytes / fps_us / 1e3, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(fps_bytes / fps_us / 1e3 / HBM_PEAK_GBS, 6), "algorithmic_bytes": fps_bytes,
+                         "traffic": pmc_traffic("fps_pmc.json"), "us_per_launch": round(fps_us, 1), "launches_per_step": 1,
+                         "us_per_iteration": round(fps_us / 4095, 4), "iteration_sync_floor_us": 0.41,
+                         "note": "the dominant single kernel of the step.  FPS is 4095 DEPENDENT sampling iterations per cloud "
+                                 "(SURVEY.md 8d), one workgroup per cloud: bound by the per-iteration reduce-barrier-broadcast latency, "
+                                 "not by HBM or MFMA -- the HBM fraction is reported for form; compare us_per_iteration with "
+                                 "iteration_sync_floor_us (DESIGN.md 4.3).  roofline_corr is the bandwidth-bound kernel, "
+                                 "hotpath.roofline_frac the whole hot path"},
             "hotpath": {"frame_pairs_per_s": round(pairs / dt_hot, 3), "ms_per_step": round(dt_hot / args.steps * 1e3, 3),
-                        "breakdown_ms_per_step": breakdown,
-                        "note": "the hot-path operator sequence of one forward alone (rpeflow_amd/hotpath.py), timed in this run; "
-                                "the roofline kernel is its dominant single-kernel category"},
+                        "roofline_frac": round(sum_b / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "algorithmic_bytes": sum_b, "kernel_ms": round(sum_ms, 3), "categories": table,
+                        "note": "the hot-path operator sequence of one forward alone (rpeflow_amd/hotpath.py), timed in this run with "
+                                "HIP events per category; roofline_frac = sum of algorithmic bytes (rpeflow_amd/roofline.py, SURVEY.md "
+                                "8d) / sum of category durations / 8 TB/s"},
         }
+        if epe_delta is not None:
+            line["epe_delta"] = epe_delta
         if world == 1 and not args.no_corr_microbench:
             line["roofline_corr"] = corr_microbench(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

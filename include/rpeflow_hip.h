@@ -145,11 +145,33 @@ int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W,
  *   [B,C,Ho,Wo].                                                                                              */
 int rpe_resize_frames(const void *src, int src_is_u8, float divisor, int pair_split, int B, int C, int H, int W,
                       int Ho, int Wo, float *out, rpe_stream_t stream);
+/* rpe_resize_flow2d: the forward's last step (models/utils.py:217-224, called from RPEFlow.py:95): flow [B,2,H,W] resized to
+ *   [Ho,Wo] with F.interpolate(bilinear, align_corners=True), channel 0 then times scale_x (= Wo / W rounded to fp32),
+ *   channel 1 times scale_y, in one launch.  out [B,2,Ho,Wo] contiguous.                                         */
+int rpe_resize_flow2d(const float *flow, int B, int H, int W, int Ho, int Wo, float scale_x, float scale_y,
+                      float *out, rpe_stream_t stream);
 /* rpe_upsample2x_pair: the 2-D decoder's coarse-to-fine hand-over (models/RPEFlow_core.py:364-369): a [B,Ca,h,w] (times
  *   scale_a) and b [B,Cb,h,w], both F.interpolate(scale_factor=2, mode='bilinear', align_corners=True), in one launch.
  *   out_a [B,Ca,2h,2w], out_b [B,Cb,2h,2w] contiguous.  Either tensor may be absent (C = 0, pointers NULL).        */
 int rpe_upsample2x_pair(const float *a, int Ca, float scale_a, const float *b, int Cb, int B, int h, int w,
                         float *out_a, float *out_b, rpe_stream_t stream);
+
+/* ---- IDS transforms of the clouds (models/utils.py:320-377; RPEFlow.py:68-69, 88-93) ---------------------------
+ * rpe_ids_forward: perspect2parallel for n_clouds clouds stored as channel triples of pcs [B,3*n_clouds,N]
+ *   (pcs[b][c][n] = pcs[b*sb + c*sc + n*sn]); intrinsics[b] = (f, cx, cy) at intrinsics[b*i_sb + 0..2];
+ *   x' = (cx + f/z*x)*sw - hw,  y' = (cy + f/z*y)*sh - hh,  z' = (f*log z + 1)*sz, every operation rounded to fp32
+ *   as the reference's CPU path rounds it, log = the correctly rounded fp32 logarithm.  sw = (Wp-1)/(W-1),
+ *   sh = (Hp-1)/(H-1), hw = (Wp-1)/2, hh = (Hp-1)/2, sz = min(sw, sh), rounded to fp32 by the caller.
+ *   out [n_clouds*B,3,N] contiguous, cloud-major: torch.cat([pc1, pc2], dim=0) of RPEFlow.py:68-69 + pwc3d_core.py:12.
+ * rpe_ids_flow_inverse: out = parallel2perspect(xyz + flow) - parallel2perspect(xyz)   (RPEFlow.py:91-93),
+ *   xyz, flow [B,3,N] through strides (batch, channel, point), out [B,3,N] contiguous.                        */
+int rpe_ids_forward(const float *pcs, int64_t sb, int64_t sc, int64_t sn, const float *intrinsics, int64_t i_sb,
+                    int B, int n_clouds, int N, float sw, float sh, float hw, float hh, float sz,
+                    float *out, rpe_stream_t stream);
+int rpe_ids_flow_inverse(const float *xyz, int64_t x_sb, int64_t x_sc, int64_t x_sn,
+                         const float *flow, int64_t f_sb, int64_t f_sc, int64_t f_sn,
+                         const float *intrinsics, int64_t i_sb, int B, int N,
+                         float sw, float sh, float hw, float hh, float sz, float *out, rpe_stream_t stream);
 
 /* ---- project_feat_with_nn_corr (models/utils.py:297-317) -------------------------
  * For pixel p with nearest projected point i = nn_idx[b][p]:

@@ -300,3 +300,35 @@ def events_to_voxel(events, num_bins, height, width, event_polarity):
             np.add.at(img, (ys, xs), (wgt * np.maximum(0.0, 1.0 - np.abs(t_norm - b))).astype(np.float32))
             out.append(img)
     return np.stack(out)
+
+
+# --------------------------------------------------------------------------
+# IDS transforms (models/utils.py:320-377).  fp32 numpy arithmetic rounds every operation like the reference's
+# CPU tensors do; the logarithm / exponential are the correctly rounded fp32 ones (float64 function, rounded once).
+# The reference's own CPU log (MKL high-accuracy vsLn behind torch.log) is correctly rounded on all but ~2e-4 of
+# its inputs and differs between CPU models; tests/test_oracle_golden.py bounds the difference against the clouds
+# the reference produced in the build container.
+def _ids_scales(H, W, Hp, Wp):
+    sw, sh = (Wp - 1) / (W - 1), (Hp - 1) / (H - 1)
+    return [np.float32(v) for v in (sw, sh, (Wp - 1) / 2, (Hp - 1) / 2, min(sw, sh))]
+
+
+def perspect2parallel(xyz, intrinsics, H, W, Hp, Wp):
+    """utils.py:320-346.  xyz [B,3,N], intrinsics [B,3] = (f, cx, cy); sensor H x W -> parallel sensor Hp x Wp."""
+    xyz, intr = _f32(xyz), _f32(intrinsics)
+    sw, sh, hw, hh, sz = _ids_scales(H, W, Hp, Wp)
+    f, cx, cy = intr[:, 0:1], intr[:, 1:2], intr[:, 2:3]
+    x, y, z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    fz = f / z
+    log_z = np.log(z.astype(np.float64)).astype(np.float32)
+    return np.stack([(cx + fz * x) * sw - hw, (cy + fz * y) * sh - hh, (f * log_z + np.float32(1)) * sz], axis=1).astype(np.float32)
+
+
+def parallel2perspect(xyz, intrinsics, H, W, Hp, Wp):
+    """utils.py:349-377."""
+    xyz, intr = _f32(xyz), _f32(intrinsics)
+    sw, sh, hw, hh, sz = _ids_scales(H, W, Hp, Wp)
+    f, cx, cy = intr[:, 0:1], intr[:, 1:2], intr[:, 2:3]
+    x, y, z = (xyz[:, 0] + hw) / sw, (xyz[:, 1] + hh) / sh, xyz[:, 2] / sz
+    oz = np.exp(((z - np.float32(1)) / f).astype(np.float64)).astype(np.float32)
+    return np.stack([(x - cx) * oz / f, (y - cy) * oz / f, oz], axis=1).astype(np.float32)

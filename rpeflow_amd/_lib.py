@@ -55,11 +55,16 @@ _PROTOTYPES = {
     "rpe_knn_interpolate": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                             _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
     "rpe_resize_frames": [_c_ptr, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
+    "rpe_resize_flow2d": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_ptr, _c_ptr],
     "rpe_upsample2x_pair": [_c_ptr, _c_int, _c_float, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_bilinear_sample": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
                             _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_project_feat_nn_corr": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int,
                                  _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
+    "rpe_ids_forward": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int, _c_int,
+                        _c_float, _c_float, _c_float, _c_float, _c_float, _c_ptr, _c_ptr],
+    "rpe_ids_flow_inverse": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int,
+                             _c_float, _c_float, _c_float, _c_float, _c_float, _c_ptr, _c_ptr],
     "rpe_pointconv_group": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64,
                             _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
 }

@@ -1,15 +1,19 @@
-"""Build librpeflow_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+"""Build librpeflow_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+One object per csrc/*.hip (compiled in parallel, only when the source or a header changed), then one link."""
 import glob
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC_DIR = os.path.join(HERE, "csrc")
+OBJ_DIR = os.path.join(SRC_DIR, "build")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(SRC_DIR, "librpeflow_hip.so")
 
 # -ffp-contract=off: KNN/FPS must round exactly where the source says ("Exact arithmetic")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-fvisibility=hidden", "-Wno-unused-result"]
 
 
@@ -17,24 +21,50 @@ def sources():
     return sorted(glob.glob(os.path.join(SRC_DIR, "*.hip")))
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def headers():
+    return glob.glob(os.path.join(SRC_DIR, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+
+
+def _obj(src):
+    return os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(SRC_DIR, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def needs_build():
+    return _stale(LIB, sources() + headers())
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-I", SRC_DIR, "-o", LIB] + sources()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdrs = headers()
+    todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdrs)]
+
+    def compile_one(src):
+        cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-I", SRC_DIR, "-c", src, "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as pool:
+        list(pool.map(compile_one, todo))
+    for stale in set(glob.glob(os.path.join(OBJ_DIR, "*.o"))) - {_obj(s) for s in sources()}:
+        os.remove(stale)  # object of a source file that no longer exists
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in sources()]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -186,7 +186,8 @@ __global__ __launch_bounds__(256) void upsample2x_pair_kernel(const float *__res
 // Per tap v = float(u8) / 255 (a true division, as the reference's), then ATen's h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11).
 template <typename T>
 __global__ __launch_bounds__(256) void resize_frames_kernel(const T *__restrict__ src, int B, int C, int H, int W, int Ho, int Wo, float divisor,
-                                                            int pair_split, int c_per_block, float *__restrict__ out) {
+                                                            int pair_split, int c_per_block, float post_x, float post_y, int post,
+                                                            float *__restrict__ out) {
     const int P = Ho * Wo;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = blockIdx.z;
@@ -205,7 +206,8 @@ __global__ __launch_bounds__(256) void resize_frames_kernel(const T *__restrict_
         const T *s = src + ((int64_t)n * C + c) * hw;
         float v00 = (float)s[o00], v01 = (float)s[o01], v10 = (float)s[o10], v11 = (float)s[o11];
         if (divisor != 0.f) { v00 = v00 / divisor; v01 = v01 / divisor; v10 = v10 / divisor; v11 = v11 / divisor; }
-        const float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        float v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        if (post) v = v * (c == 0 ? post_x : post_y);  // resize_flow2d: flow[:, 0] *= tw / w, flow[:, 1] *= th / h (utils.py:222-223)
         const int64_t plane = pair_split ? ((int64_t)(c / half) * B + n) * half + (c % half) : (int64_t)n * C + c;
         out[plane * P + p] = v;
     }
@@ -355,10 +357,21 @@ RPE_API int rpe_resize_frames(const void *src, int src_is_u8, float divisor, int
     dim3 grid((P + 255) / 256, (C + cpb - 1) / cpb, B);
     if (src_is_u8)
         hipLaunchKernelGGL(resize_frames_kernel<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char *)src, B, C, H, W, Ho,
-                           Wo, divisor, pair_split, cpb, out);
+                           Wo, divisor, pair_split, cpb, 1.f, 1.f, 0, out);
     else
         hipLaunchKernelGGL(resize_frames_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float *)src, B, C, H, W, Ho, Wo, divisor,
-                           pair_split, cpb, out);
+                           pair_split, cpb, 1.f, 1.f, 0, out);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_resize_flow2d(const float *flow, int B, int H, int W, int Ho, int Wo, float scale_x, float scale_y, float *out,
+                              rpe_stream_t stream) {
+    if (!flow || !out || B < 0 || H < 1 || W < 1 || Ho < 1 || Wo < 1) return RPE_EINVAL;
+    if (B == 0) return 0;
+    if (B > 65535 || (int64_t)Ho * Wo >= (1ll << 31) || (int64_t)H * W >= (1ll << 31)) return RPE_EUNSUPPORTED;
+    dim3 grid((Ho * Wo + 255) / 256, 2, B);
+    hipLaunchKernelGGL(resize_frames_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, flow, B, 2, H, W, Ho, Wo, 0.f, 0, 1, scale_x,
+                       scale_y, 1, out);
     return rpe_launch_status();
 }
 

@@ -182,6 +182,8 @@ def main():
     p.add_argument("--weights", default=None, help="reference checkpoint ({'state_dict': ...}); default: seeded random init")
     p.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     args = p.parse_args()
+    from . import runtime
+    runtime.configure()  # before the first GPU call: graph-queue count; MIOpen solvers stay at the library defaults
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device("cuda", local)
@@ -191,8 +193,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     from .model import RPEFlow
-    torch.manual_seed(0)
-    model = RPEFlow().to(device).eval()
+    from .synthetic import load_seeded_parameters
+    model = load_seeded_parameters(RPEFlow()).to(device).eval()
     if args.weights:
         model.load_state_dict(torch.load(args.weights, map_location=device)["state_dict"], strict=True)
     from .synthetic import SyntheticPairs

@@ -30,7 +30,11 @@ class Config(dict):
         for k, v in (d or {}).items():
             self[k] = Config(v) if isinstance(v, dict) else v
 
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None  # hasattr(), copy.deepcopy(), pickling rely on AttributeError
 
 
 def things_config():
@@ -96,7 +100,7 @@ class _MutualAttention(nn.Module):
             v = qkv.reshape(shape[0], 3 * shape[1], -1)[:, 2 * shape[1]:]
             if self.project_out.bias is not None:
                 bias = self.project_out.bias.view(1, -1, 1)
-                residual = bias if residual is None else residual.reshape(shape[0], shape[1], -1) + bias
+                residual = bias.expand(shape[0], shape[1], v.shape[2]) if residual is None else residual.reshape(shape[0], shape[1], -1) + bias
             if residual is None:
                 return torch.bmm(m, v).reshape(shape)
             return torch.baddbmm(residual.reshape(shape[0], shape[1], -1), m, v).reshape(shape)
@@ -385,6 +389,9 @@ def resize_flow2d(flow, target_h, target_w):
     h, w = flow.shape[2:]
     if (h, w) == (target_h, target_w):
         return flow
+    if flow.is_cuda:
+        from .utils import resize_flow2d as fused
+        return fused(flow, target_h, target_w)
     flow = F.interpolate(flow, size=(target_h, target_w), mode="bilinear", align_corners=True)
     flow *= _pair_scale(target_w / w, target_h / h, flow)
     return flow
@@ -755,6 +762,11 @@ class RPEFlow(nn.Module):
         if self.ids_on_host:
             host = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in persp.items()}
             return perspect2parallel(pc1.cpu(), host, paral).to(device), perspect2parallel(pc2.cpu(), host, paral).to(device)
+        if pc1.is_cuda and self.pwc_fusion_core.ops.correlation2d is native_correlation2d:
+            # one kernel, the reference's CPU rounding operation for operation (csrc/ids.hip): FPS is chaotic in these values
+            from .utils import ids_forward
+            both = ids_forward(inputs["pcs"], inputs["intrinsics"], persp, paral)
+            return both[:pc1.shape[0]], both[pc1.shape[0]:]
         return perspect2parallel(pc1, persp, paral), perspect2parallel(pc2, persp, paral)
 
     @torch.no_grad()
@@ -843,7 +855,11 @@ class RPEFlow(nn.Module):
         flow_3d = flows_3d[0]
         if self.cfgs.ids.enabled:
             xyz1 = xyzs1[0]
-            flow_3d = parallel2perspect(xyz1 + flow_3d, persp, paral) - parallel2perspect(xyz1, persp, paral)
+            if xyz1.is_cuda and core.ops.correlation2d is native_correlation2d:
+                from .utils import ids_flow_inverse
+                flow_3d = ids_flow_inverse(xyz1, flow_3d, inputs["intrinsics"], persp, paral)
+            else:
+                flow_3d = parallel2perspect(xyz1 + flow_3d, persp, paral) - parallel2perspect(xyz1, persp, paral)
         out = {"flow_2d": resize_flow2d(flows_2d[0], origin_h, origin_w), "flow_3d": flow_3d}
         if self.keep_levels:  # what RPEFlow_core.decode returns (RPEFlow_core.py:432), 3-D flows still in IDS space
             out["levels_2d"], out["levels_3d"] = list(flows_2d), list(flows_3d)

@@ -252,6 +252,21 @@ def resize_frames(x, size, divisor=0.0, pair_split=False):
     return out
 
 
+def resize_flow2d(flow, target_h, target_w):
+    """utils.py:217-224: bilinear (align_corners=True) resize of a [B,2,H,W] flow to the frame size, x / y components
+    rescaled with it; one launch; the input itself when the size already matches."""
+    origin_h, origin_w = flow.shape[2:]
+    if target_h == origin_h and target_w == origin_w:
+        return flow
+    _lib.require_gpu(flow, op="resize_flow2d")
+    assert flow.dim() == 4 and flow.shape[1] == 2
+    flow = _f32(flow).contiguous()
+    out = torch.empty((flow.shape[0], 2, target_h, target_w), dtype=torch.float32, device=flow.device)
+    _launch(flow, "resize_flow2d", _lib.lib().rpe_resize_flow2d, _ptr(flow), flow.shape[0], origin_h, origin_w, int(target_h),
+            int(target_w), target_w / origin_w, target_h / origin_h, _ptr(out))
+    return out
+
+
 def upsample2x_pair(a, b, scale_a=1.0):
     """(F.interpolate(a * scale_a, x2), F.interpolate(b, x2)), bilinear with align_corners=True, for two [B,C,h,w] tensors
     of one spatial size in one launch: the coarse flow (x2) and its features on their way to the next finer level
@@ -300,4 +315,39 @@ def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None):
     _launch(feat_2d, "project_feat_with_nn_corr", _lib.lib().rpe_project_feat_nn_corr,
             _ptr(xy), *xy.stride(), _ptr(feat_2d), C2, H, W, _ptr(feat_3d), *feat_3d.stride(), C3,
             _ptr(nn_indices), B, N, _ptr(rows), _ptr(out))
+    return out
+
+
+# ------------------------------------------------------------------ IDS transforms (utils.py:320-377)
+def _ids_scales(persp, paral):
+    """The five scalars of utils.py:333-343 / 355-361 as torch hands them to an fp32 tensor: computed in Python double,
+    rounded to fp32 once."""
+    sw = (paral["sensor_w"] - 1) / (persp["sensor_w"] - 1)
+    sh = (paral["sensor_h"] - 1) / (persp["sensor_h"] - 1)
+    return sw, sh, (paral["sensor_w"] - 1) / 2, (paral["sensor_h"] - 1) / 2, min(sw, sh)
+
+
+def ids_forward(pcs, intrinsics, persp, paral):
+    """perspect2parallel (utils.py:320-346) of every cloud in ``pcs`` [B,3*n,N] (RPEFlow.py:38, 68-69) in one launch:
+    returns [n*B,3,N], cloud-major -- frame-1 clouds of the batch, then frame-2 clouds -- in the reference's CPU
+    rounding (csrc/ids.hip)."""
+    _lib.require_gpu(pcs, intrinsics, op="ids_forward")
+    pcs, intrinsics = _f32(pcs), _f32(intrinsics)
+    B, C, N = pcs.shape
+    assert C % 3 == 0 and intrinsics.shape == (B, 3) and intrinsics.stride(1) == 1
+    out = torch.empty((C // 3 * B, 3, N), dtype=torch.float32, device=pcs.device)
+    _launch(pcs, "ids_forward", _lib.lib().rpe_ids_forward, _ptr(pcs), *pcs.stride(), _ptr(intrinsics), intrinsics.stride(0),
+            B, C // 3, N, *_ids_scales(persp, paral), _ptr(out))
+    return out
+
+
+def ids_flow_inverse(xyz, flow, intrinsics, persp, paral):
+    """parallel2perspect(xyz + flow) - parallel2perspect(xyz) (RPEFlow.py:91-93, utils.py:349-377), [B,3,N]."""
+    _lib.require_gpu(xyz, flow, intrinsics, op="ids_flow_inverse")
+    xyz, flow, intrinsics = _f32(xyz), _f32(flow), _f32(intrinsics)
+    B, _, N = xyz.shape
+    assert xyz.shape == flow.shape == (B, 3, N) and intrinsics.shape == (B, 3) and intrinsics.stride(1) == 1
+    out = torch.empty((B, 3, N), dtype=torch.float32, device=xyz.device)
+    _launch(xyz, "ids_flow_inverse", _lib.lib().rpe_ids_flow_inverse, _ptr(xyz), *xyz.stride(), _ptr(flow), *flow.stride(),
+            _ptr(intrinsics), intrinsics.stride(0), B, N, *_ids_scales(persp, paral), _ptr(out))
     return out

@@ -159,3 +159,34 @@ def event_inputs(name):
     ev = np.stack([r.integers(0, W, n).astype(np.float64), r.integers(0, H, n).astype(np.float64), t,
                    r.integers(0, 2, n).astype(np.float64)], axis=1)
     return ev, H, W, bins, pol
+
+
+# Section 8(f) blocks pinned at block level: Restormer cross blocks (restormer_arch.py:207-222, 287-302),
+# convex_upsample (utils.py:201-214), resize_flow2d (utils.py:217-224)
+FBLOCK_CASES = {
+    "cross_block2d": dict(B=2, C=24, heads=2, H=20, W=28, seed=701),
+    "cross_block2d_3heads": dict(B=1, C=48, heads=3, H=18, W=30, seed=702),
+    "cross_block3d": dict(B=2, C=32, heads=4, N=300, seed=703),
+    "convex_upsample4": dict(B=2, H=9, W=15, scale=4, seed=704),
+    "convex_upsample8": dict(B=1, H=6, W=10, scale=8, seed=705),
+    "resize_flow2d": dict(B=2, H=64, W=128, th=60, tw=120, seed=706),
+    "resize_flow2d_same": dict(B=1, H=64, W=64, th=64, tw=64, seed=707),
+}
+
+
+def fblock_inputs(name):
+    c = FBLOCK_CASES[name]
+    r = I.rng(c["seed"])
+    if name.startswith("cross_block2d"):
+        return dict(x=I.feature_map(r, c["B"], c["C"], c["H"], c["W"]), y=I.feature_map(r, c["B"], c["C"], c["H"], c["W"]))
+    if name == "cross_block3d":
+        return dict(x=r.standard_normal((c["B"], c["C"], c["N"]), dtype=np.float32), y=r.standard_normal((c["B"], c["C"], c["N"]), dtype=np.float32))
+    if name.startswith("convex_upsample"):
+        s = c["scale"]
+        return dict(flow=I.flow_field(r, c["B"], c["H"], c["W"], std=2.0), mask=r.standard_normal((c["B"], 9 * s * s, c["H"], c["W"]), dtype=np.float32))
+    return dict(flow=I.flow_field(r, c["B"], c["H"], c["W"], std=3.0))
+
+
+# The benched configuration (bench.py, BASELINE config 3): batch 4 of 544x960 frame pairs + 8192 points,
+# samples frame_pair(1000 + i), parameters tests.inputs.model_params
+BENCH_CASE = dict(B=4, H=544, W=960, N=8192, first_seed=1000)

@@ -259,6 +259,46 @@ def gen_model_full():
     save("model_544x960", flow_2d_s8=f2[:, :, ::8, ::8].copy(), flow_3d=f3, epe2d=np.float64(epe2), epe3d=np.float64(epe3), **ids_clouds())
 
 
+@torch.no_grad()
+def gen_fblocks():
+    """Section 8(f) rows at block level: the reference's CrossTransformerBlock2D/3D, convex_upsample, resize_flow2d."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        from models import restormer_arch as ref_ra
+    for name, c in K.FBLOCK_CASES.items():
+        x = K.fblock_inputs(name)
+        if name.startswith("cross_block"):
+            cls = ref_ra.CrossTransformerBlock2D if "2d" in name else ref_ra.CrossTransformerBlock3D
+            m = cls(dim=c["C"], num_heads=c["heads"])
+            load_params(m, c["seed"] + 1000)
+            save(name, out=m(T(x["x"]), T(x["y"])).numpy())
+        elif name.startswith("convex_upsample"):
+            save(name, out=ref_utils.convex_upsample(T(x["flow"]), T(x["mask"]), scale_factor=c["scale"]).numpy())
+        else:
+            save(name, out=ref_utils.resize_flow2d(T(x["flow"]).clone(), c["th"], c["tw"]).numpy())
+
+
+@torch.no_grad()
+def gen_model_bench():
+    """The benched configuration itself (bench.py / BASELINE config 3): a batch of 4 synthetic 544x960 frame pairs
+    (seeds 1000..1003) + 8192 points through the reference on the CPU, seeded parameters.  Stored: flow_2d on a stride-8
+    grid, flow_3d, the batch EPEs against the synthetic targets, the clouds as the reference's host IDS produced them."""
+    c = K.BENCH_CASE
+    m = reference_model()
+    m.load_state_dict({k: T(v) for k, v in model_params(m).items()}, strict=True)
+    m.eval()
+    samples = [I.frame_pair(c["first_seed"] + i, H=c["H"], W=c["W"], N=c["N"]) for i in range(c["B"])]
+    batch = {k: torch.stack([T(s[k]) for s in samples]) for k in samples[0]}
+    out = m(batch, is_Train=False)
+    f2, f3 = out["flow_2d"].numpy(), out["flow_3d"].numpy()
+    assert np.isfinite(f2).all() and np.isfinite(f3).all()
+    t2, t3 = batch["flow_2d"].numpy()[:, :2], batch["flow_3d"].numpy()[:, :3]
+    epe2 = float(np.sqrt(((f2 - t2) ** 2).sum(1)).mean())
+    epe3 = float(np.sqrt(((f3 - t3) ** 2).sum(1)).mean())
+    print("bench flow_2d |max|", np.abs(f2).max(), "flow_3d |max|", np.abs(f3).max(), "EPE", epe2, epe3)
+    save("model_bench_b4_544x960", flow_2d_s8=f2[:, :, ::8, ::8].copy(), flow_3d=f3, epe2d=np.float64(epe2), epe3d=np.float64(epe3),
+         **ids_clouds())
+
+
 def gen_eval():
     """The reference's evaluation loops themselves (eval_withocc.py:45-135, eval_noocc.py:45-116), unmodified, over the
     synthetic frame pairs and the stand-in predictions of tests/test_evaluate.py; stored: the accumulated metric sums.
@@ -322,6 +362,6 @@ def gen_eval():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval"]
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval", "fblocks", "model_bench"]
     for w in which:
         globals()["gen_" + w]()

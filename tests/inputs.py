@@ -45,45 +45,7 @@ def flow_field(r, B, H, W, std=3.0):
     return (r.standard_normal((B, 2, H, W), dtype=np.float32) * np.float32(std)).astype(np.float32)
 
 
-def fill_params(shapes, seed):
-    """Deterministic parameters for a module.  ``shapes``: list of (key, shape).  Every key draws from
-    its own stream, default_rng(seed + crc32(key)), so the values do not depend on the order in which
-    a module registers its parameters.  Weights ~ N(0, 1/fan_in), biases ~ N(0, 0.1), running_var and
-    norm scales in [0.5, 1.5), integer buffers (num_batches_tracked) zero."""
-    import zlib
-    out = {}
-    for key, shape in shapes:
-        shape = tuple(shape)
-        r = rng(seed + zlib.crc32(key.encode()))
-        if key.endswith("num_batches_tracked"):
-            out[key] = np.zeros(shape, np.int64)
-        elif key.endswith("running_var"):
-            out[key] = r.uniform(0.5, 1.5, shape).astype(np.float32)
-        elif key.endswith("running_mean") or key.endswith("bias"):
-            out[key] = (r.standard_normal(shape) * 0.1).astype(np.float32)
-        elif key.endswith("norm_fn.weight") or key.endswith("body.weight") or key.endswith("temperature"):
-            out[key] = r.uniform(0.5, 1.5, shape).astype(np.float32)
-        else:
-            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
-            out[key] = (r.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
-    return out
-
-
-MODEL_SEED = 4242
-# Down-scaling of a few weight groups so that a random-init RPEFlow stays well conditioned: with plain
-# N(0, 1/fan_in) weights the k-sums of PointConv / Correlation3D amplify ~10x per pyramid level and the
-# 3-D decoder features reach 1e8, where fp32 rounding alone moves the 2-D flow by 1e-2 (SURVEY.md H7).
-MODEL_SCALES = [("conv_last_", 0.05), ("linear.", 0.25), ("weight_net1.convs.2", 0.15), ("weight_net2.convs.2", 0.15)]
-
-
-def model_params(shapes):
-    """Seeded parameters for the full model (reference and counterpart alike), keyed by state-dict name."""
-    params = fill_params(shapes, MODEL_SEED)
-    for k in params:
-        for pattern, scale in MODEL_SCALES:
-            if pattern in k and k.endswith("weight") and params[k].ndim > 1:
-                params[k] = (params[k] * np.float32(scale)).astype(np.float32)
-    return params
+from rpeflow_amd.synthetic import MODEL_SCALES, MODEL_SEED, fill_params, model_params  # noqa: E402,F401  (the generators live in the package: bench.py uses them too)
 
 
 def frame_pair(seed, H=544, W=960, N=8192, f=1050.0, dsec=False):

@@ -124,16 +124,18 @@ def test_two_process_gloo_all_reduce_equals_single_process(tmp_path):
     assert accs[0][0] == single[0].item() and accs[0][4] == single[4].item()
 
 
-def test_accumulators_match_the_reference_loops():
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)])
+def test_accumulators_match_the_reference_loops(device):
     """tests/golden/eval_accumulators.npz: the metric sums the reference's own Evaluator.run loops (eval_withocc.py:45-135,
     eval_noocc.py:45-116, run unmodified by tests/golden/make_golden.py) reach on these frame pairs and predictions."""
     golden = np.load(os.path.join(ROOT, "tests", "golden", "eval_accumulators.npz"))
     for dsec, key, n in ((False, "withocc", 12), (True, "noocc", 8)):
         data = SyntheticPairs(5, H=24, W=40, N=512, dsec=dsec)
-        acc = E.new_accumulator("cpu")
+        acc = E.new_accumulator(device)
         for idx in ((0, 1), (2, 3), (4,)):
-            batch = E.collate([data[i] for i in idx])
+            batch = {k: v.to(device) for k, v in E.collate([data[i] for i in idx]).items()}
             E.accumulate(acc, fake_model(batch), batch)
+        acc = acc.cpu()
         got, want = acc.numpy()[:n], golden[key]
         hits = [0, 2, 3, 4, 6, 7, 8, 10, 11][:6 if n == 8 else 9]
         assert np.array_equal(got[hits], want[hits]), (key, got, want)          # counts and threshold hits: exact

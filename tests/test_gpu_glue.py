@@ -270,3 +270,66 @@ def test_resize_frames_matches_the_reference_preparation(B, H, W):
     assert (got_both - want_both).abs().max().item() <= 1e-6 and (got_events - want_events).abs().max().item() <= 2e-6 * events.abs().max().item()
     if size == (H, W):
         assert torch.equal(got_both, want_both) and torch.equal(got_events, want_events)
+
+
+# ---------------------------------------------------------------- IDS transforms and the final flow resize
+@pytest.mark.parametrize("H,W,seeds,dsec", [(544, 960, [1000, 1001, 1002], False), (480, 640, [2000], True), (128, 192, [7], False)])
+def test_ids_forward_bit_exact_against_oracle(H, W, seeds, dsec):
+    """rpe_ids_forward (csrc/ids.hip) against the CPU restatement of perspect2parallel: every coordinate bit for bit --
+    furthest-point sampling behind it is chaotic in these values."""
+    from rpeflow_amd.model import RPEFlow
+    samples = [I.frame_pair(s, H=H, W=W, N=8192, dsec=dsec) for s in seeds]
+    pcs, intr = np.stack([s["pcs"] for s in samples]), np.stack([s["intrinsics"] for s in samples])
+    model = RPEFlow()
+    inputs = {"images": torch.zeros(len(seeds), 6, H, W, dtype=torch.uint8), "pcs": dev(pcs), "intrinsics": dev(intr)}
+    persp, paral = model._cameras(inputs)
+    got = U.ids_forward(inputs["pcs"], inputs["intrinsics"], persp, paral).cpu().numpy()
+    Hp, Wp = paral["sensor_h"], paral["sensor_w"]
+    want = np.concatenate([O.perspect2parallel(pcs[:, :3], intr, H, W, Hp, Wp), O.perspect2parallel(pcs[:, 3:], intr, H, W, Hp, Wp)])
+    assert got.shape == want.shape
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    # strided input (a channel-sliced view) gives the same
+    wide = torch.zeros(len(seeds), 8, 8192, device=DEV)
+    wide[:, 1:7] = inputs["pcs"]
+    assert torch.equal(U.ids_forward(wide[:, 1:7], inputs["intrinsics"], persp, paral), torch.from_numpy(got).to(DEV))
+
+
+def test_ids_forward_against_the_reference_golden(golden_dir):
+    """... and against the clouds the reference itself produced for the benched batch (its CPU log is not correctly rounded
+    on a few values in ten thousand: at most one ulp on those, everything else identical)."""
+    from rpeflow_amd.model import RPEFlow
+    g = G(golden_dir, "model_bench_b4_544x960")
+    samples = [I.frame_pair(1000 + i, H=544, W=960, N=8192) for i in range(4)]
+    inputs = {"images": torch.zeros(4, 6, 544, 960, dtype=torch.uint8), "pcs": dev(np.stack([s["pcs"] for s in samples])),
+              "intrinsics": dev(np.stack([s["intrinsics"] for s in samples]))}
+    model = RPEFlow()
+    got = U.ids_forward(inputs["pcs"], inputs["intrinsics"], *model._cameras(inputs)).cpu().numpy()
+    want = np.concatenate([g["pc1_ids"], g["pc2_ids"]])
+    ulps = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+    assert np.array_equal(got[:, :2].view(np.uint32), want[:, :2].view(np.uint32))
+    assert ulps.max() <= 1 and (ulps != 0).sum() <= 8, (ulps.max(), (ulps != 0).sum())
+
+
+def test_ids_flow_inverse_against_oracle():
+    from rpeflow_amd.model import RPEFlow
+    H, W = 544, 960
+    samples = [I.frame_pair(1000 + i, H=H, W=W, N=8192) for i in range(2)]
+    pcs, intr = np.stack([s["pcs"] for s in samples]), np.stack([s["intrinsics"] for s in samples])
+    xyz = O.perspect2parallel(pcs[:, :3], intr, H, W, 18, 30)
+    flow = (I.rng(5).standard_normal(xyz.shape) * np.array([0.3, 0.3, 1.5])[None, :, None]).astype(np.float32)
+    inputs = {"images": torch.zeros(2, 6, H, W, dtype=torch.uint8), "intrinsics": dev(intr)}
+    persp, paral = RPEFlow()._cameras(inputs)
+    got = U.ids_flow_inverse(dev(xyz), dev(flow), inputs["intrinsics"], persp, paral).cpu().numpy()
+    want = O.parallel2perspect(xyz + flow, intr, H, W, 18, 30) - O.parallel2perspect(xyz, intr, H, W, 18, 30)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))  # same operations, correctly rounded exp on both sides
+
+
+@pytest.mark.parametrize("name", ["resize_flow2d", "resize_flow2d_same"])
+def test_resize_flow2d_against_reference_golden(golden_dir, name):
+    """utils.py:217-224 in one launch against the reference's output (and the identity when the size already matches)."""
+    c, x = K.FBLOCK_CASES[name], K.fblock_inputs(name)
+    flow = dev(x["flow"])
+    got = U.resize_flow2d(flow, c["th"], c["tw"])
+    if name.endswith("same"):
+        assert got is flow
+    close(got, G(golden_dir, name)["out"], atol=3e-6, what=name)

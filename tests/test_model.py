@@ -264,3 +264,47 @@ def test_every_pyramid_level_matches_the_reference(golden_dir):
         d2, d3 = np.abs(got2 - want2).mean(), np.abs(got3 - want3).mean()
         print("level %d: mean |d flow_2d| %.2e (|flow| %.2e), mean |d flow_3d| %.2e (|flow| %.2e)" % (i, d2, np.abs(want2).mean(), d3, np.abs(want3).mean()))
         assert d2 <= 1e-4 * max(1.0, np.abs(want2).mean()) and d3 <= 1e-4 * max(1.0, np.abs(want3).mean())  # measured: 2e-7 relative
+
+
+@pytest.mark.gpu
+@torch.no_grad()
+def test_benched_configuration_matches_reference_golden(golden_dir):
+    """The configuration bench.py times, built the way bench.py builds it -- batch 4 of 544x960 frame pairs + 8192 points
+    (seeds 1000..1003), seeded parameters, IDS transform on the device, furthest-point sampling one batch ahead
+    (forward_ahead) inside ONE HIP graph, MIOpen's default solvers (no environment overrides anywhere in tests/) --
+    against the reference's CPU forward on the same batch: |EPE2D|, |EPE3D| differences < 1e-4 (north_star)."""
+    import bench
+    from rpeflow_amd.model import RPEFlow
+    from rpeflow_amd.synthetic import load_seeded_parameters
+    assert not [k for k in os.environ if k.startswith("MIOPEN_DEBUG_")], "the benched configuration runs MIOpen's defaults"
+    g = np.load(os.path.join(golden_dir, "model_bench_b4_544x960.npz"))
+    dev = torch.device("cuda", 0)
+    model = load_seeded_parameters(RPEFlow()).to(dev).eval()
+    batch = bench.make_batch(4, dev, first_seed=1000)
+    out = model(batch)
+    eager = bench.golden_epe_delta(out, batch, g)
+    order = model.sample_order(batch)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        out = model.forward_ahead(batch, order, batch)
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    replayed = bench.golden_epe_delta(out, batch, g)
+    print("benched configuration: eager", eager, "graph replay", replayed)
+    for d in (eager, replayed):
+        assert d["epe2d"] < GOLDEN_EPE_TOL and d["epe3d"] < GOLDEN_EPE_TOL
+        assert d["mean_abs_flow_2d"] < 1e-3 and d["mean_abs_flow_3d"] < 1e-4
+
+
+def test_config_behaves_like_a_mapping_with_attributes():
+    """hasattr / deepcopy / pickling of the configuration object (the reference's omegaconf.DictConfig allows all three)."""
+    import copy
+    import pickle
+    from rpeflow_amd.model import things_config
+    cfg = things_config()
+    assert not hasattr(cfg, "fusion") and hasattr(cfg, "pwc2d") and cfg.pwc2d.max_displacement == 4
+    assert copy.deepcopy(cfg) == cfg and pickle.loads(pickle.dumps(cfg)) == cfg
+    from rpeflow_amd.model import RPEFlow
+    m = RPEFlow()
+    assert len(copy.deepcopy(m).state_dict()) == len(m.state_dict())

@@ -140,3 +140,30 @@ def test_correlation3d(golden_dir):
 def test_events_to_voxel(golden_dir, name):
     ev, H, W, bins, pol = K.event_inputs(name)
     assert_bits_equal(O.events_to_voxel(ev, bins, H, W, pol), G(golden_dir, name)["voxel"], name)
+
+
+@pytest.mark.parametrize("name,H,W,seeds", [("model_128x192", 128, 192, [1000]), ("model_544x960", 544, 960, [3000]),
+                                            ("model_bench_b4_544x960", 544, 960, [1000, 1001, 1002, 1003]),
+                                            ("model_dsec_480x640", 480, 640, [2000])])
+def test_ids_forward_against_the_clouds_the_reference_produced(golden_dir, name, H, W, seeds):
+    """perspect2parallel (utils.py:320-346): the restatement against the transformed clouds recorded from the reference's
+    forward in the build container.  x and y are bit-identical; z goes through log, where the reference's CPU log (MKL
+    high-accuracy vsLn) and the correctly rounded one differ by one ulp on a few values in ten thousand."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    samples = [I.frame_pair(s, H=H, W=W, N=8192, dsec="dsec" in name) for s in seeds]
+    pcs = np.stack([s["pcs"] for s in samples])
+    intr = np.stack([s["intrinsics"] for s in samples])
+    Hp, Wp = (H + 63) // 64 * 64 // 32, (W + 63) // 64 * 64 // 32
+    for key, sl in (("pc1_ids", slice(0, 3)), ("pc2_ids", slice(3, 6))):
+        got, want = O.perspect2parallel(pcs[:, sl], intr, H, W, Hp, Wp), g[key]
+        assert_bits_equal(got[:, :2], want[:, :2])
+        ulps = np.abs(got[:, 2].view(np.int32).astype(np.int64) - want[:, 2].view(np.int32).astype(np.int64))
+        assert ulps.max() <= 1 and (ulps != 0).mean() < 5e-4, (ulps.max(), (ulps != 0).sum())
+
+
+def test_ids_round_trip():
+    """parallel2perspect(perspect2parallel(p)) = p to fp32 rounding of exp(log z) (utils.py:349-377)."""
+    s = I.frame_pair(1000, H=544, W=960, N=8192)
+    pc, intr = s["pcs"][None, :3], s["intrinsics"][None]
+    back = O.parallel2perspect(O.perspect2parallel(pc, intr, 544, 960, 18, 30), intr, 544, 960, 18, 30)
+    np.testing.assert_allclose(back, pc, rtol=3e-4, atol=1e-4)  # z' = (1050 log z + 1) * 0.03 keeps ~1e-4 relative of z
