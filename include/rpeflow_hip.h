@@ -196,29 +196,60 @@ int rpe_pointconv_group(const float *xyz, int64_t x_sb, int64_t x_sd, int64_t x_
                         const float *w1, const float *b1, const float *w2, const float *b2, float leaky_slope,
                         int B, int M, int Q, int CF, float *out, rpe_stream_t stream);
 
-/* ---- Correlation3D (models/pwc3d_core.py:69-117) ---------------------------------
- * rpe_corr3d_hidden: hidden[b][c][n][j] = leaky(p1[b][c][n] + p2[b][c][knn_j] + wc[c][0..2].rel_j),
- *   rel_j = xyz_s[:,knn_j] - xyz_q[:,n]; p1 [B,C,N] = Wa.feat1 + bias, p2 [B,C,M] = Wb.feat2 are the
- *   per-point halves of cost_mlp's first 1x1 conv (its input is the concatenation
- *   [feat1 | feat2_nbr | rel], pwc3d_core.py:92-94), wc [C,3] its last three input columns.
- *   hidden [B,C,N,16] contiguous feeds cost_mlp's second layer (a GEMM, left to the caller).
- * rpe_corr3d_weighted_sum: out[b][c][n] = sum_{j<16} net(rel_j)[c] * value, with
- *   net = MLP2d(3,[8,8,C],relu) (w1 [8,3], w2 [8,8], w3 [C,8]; weight_net1/2, :66-67) and
- *   value = vals[b][c][n][j] (gather=0, vals [B,C,N,16]: p2n cost, :96-98) or
- *   value = vals[b][c][knn_j] (gather=1, vals [B,C,M]: n2n cost, :106-115).
- * xyz_* channel-first through strides (batch, dim, point); knn [B,N,*] int64, row stride >= 16. */
-int rpe_corr3d_hidden(const float *p1, const float *p2, const float *wc,
-                      const float *xyz_q, int64_t q_sb, int64_t q_sd, int64_t q_sn,
-                      const float *xyz_s, int64_t s_sb, int64_t s_sd, int64_t s_sn,
-                      const int64_t *knn, int64_t knn_row_stride, int B, int C, int N, int M,
-                      float leaky_slope, float *hidden, rpe_stream_t stream);
-int rpe_corr3d_weighted_sum(const float *vals, int gather,
-                            const float *w1, const float *b1, const float *w2, const float *b2,
-                            const float *w3, const float *b3,
-                            const float *xyz_q, int64_t q_sb, int64_t q_sd, int64_t q_sn,
-                            const float *xyz_s, int64_t s_sb, int64_t s_sd, int64_t s_sn,
-                            const int64_t *knn, int64_t knn_row_stride, int B, int C, int N, int M,
-                            float *out, rpe_stream_t stream);
+/* ---- PointConv in one kernel (models/pointconv.py:33-61, 90-122) -----------------
+ * rpe_pointconv_pack_rows: rows[b][m][:] = [xyz[b][:,m] | srcs[0][b][:,m] | ... | zeros] -- cat([xyz, features]) channel-last
+ *   (pointconv.py:43-44) together with the caller's own concatenation of up to four feature tensors in front of it
+ *   (RPEFlow_core.py:382-391).  xyz [B,3,M] and every source [B,C_i,M] through element strides (batch, channel, point;
+ *   src_strides = 3 per source); rows [B,M,CFp] contiguous, CFp a multiple of 16 with 3 + sum C_i <= CFp.
+ *   srcs / src_strides / src_channels are HOST arrays.
+ * rpe_pointconv_fused: from rows, the neighbour table and the query coordinates to the layer's output:
+ *   G[q][w][c] = sum_{j<16} wn_j[w] * rows[b][knn[b][q][j]][c],   wn_j = leaky(W2 leaky(W1 (rows[knn_j][0:3] - q_xyz[:,q]) + b1) + b2)
+ *   out[q][o]  = act(scale[o] * sum_{w,c} L[o][w*CF + c] G[q][w][c] + shift[o])
+ *   with L = nn.Linear's weight (pointconv.py:13, flattened weight-major :57) given PRE-PACKED in MFMA fragment order:
+ *   packed_linear[ci][g][t][kk][n][s] = L[16t + n][(4kk + s)*CF + 16ci + g], zero outside, ci < CFp/16, g < 16,
+ *   t < n_tiles (a multiple of 8 with 16*n_tiles >= Cout), kk < 4, n < 16, s < 4.
+ *   scale / shift [Cout] or NULL fold bias and eval-mode BatchNorm (pointconv.py:58-59); act 0 none, 1 relu, 2 leaky_relu.
+ *   out_mode 0: out [B,Cout,Q] channel-first (what the reference returns); out_mode 1: out [B,Q,out_stride] in the rows
+ *   format above ([q_xyz | y | zeros]), i.e. the next PointConvNoSampling's input on the same points.
+ *   Nothing of size [B,Q,16,CF] or [B,Q,16*CF] is written to memory.  Limits: k = 16, M*CFp < 2^31.                */
+int rpe_pointconv_pack_rows(const float *xyz, int64_t x_sb, int64_t x_sd, int64_t x_sn,
+                            const float *const *srcs, const int64_t *src_strides, const int *src_channels, int n_src,
+                            int B, int M, int CFp, float *rows, rpe_stream_t stream);
+int rpe_pointconv_fused(const float *rows, int CFp, int M, const int64_t *knn, int64_t knn_row_stride,
+                        const float *q_xyz, int64_t q_sb, int64_t q_sd, int64_t q_sn,
+                        const float *w1, const float *b1, const float *w2, const float *b2, float leaky_slope,
+                        const float *packed_linear, int n_tiles, const float *scale, const float *shift,
+                        int act, float act_slope, int B, int Q, int Cout, int out_mode, int out_stride,
+                        float *out, rpe_stream_t stream);
+
+/* ---- Correlation3D (models/pwc3d_core.py:69-117) behind its neighbour search, two launches -----------------------
+ * Channel counts are padded to Cp = 16*T, T in {1,2,4,6,8,12}; every [Cp] / packed array below is zero beyond C.
+ * rpe_corr3d_cost: the point-to-neighbour cost p2n (:84-98) for every point n of cloud 1, neighbours knn[b][n][0..15] in cloud 2:
+ *     hidden[j][c] = leaky(p1_rows[b][n][c] + p2_rows[b][knn_j][c] + wc4[c][0..2] . rel_j),   rel_j = xyz_s[:,knn_j] - xyz_q[:,n]
+ *     cost[j][c']  = leaky(sum_c W2[c'][c] hidden[j][c] + b2[c'])
+ *     p2n[n][c']   = sum_j relu(W3 relu(Wn2 relu(Wn1 rel_j + bn1) + bn2) + b3)[c'] * cost[j][c']
+ *   p1_rows [B,N,Cp] = Wa feat1 + bias and p2_rows [B,M,Cp] = Wb feat2, channel-last, are the per-POINT halves of cost_mlp's
+ *   first 1x1 conv (its input is the concatenation [feat1 | feat2_nbr | rel], :92-94; one small GEMM each, left to the
+ *   caller); wc4 [Cp,4] = that conv's last three input columns (4th float unused).
+ *   w2_packed [T][T][4][16][4]: [g][t][kk][n][s] = W2[16t + n][16g + 4kk + s] (cost_mlp's second conv), b2 [Cp].
+ *   Weight net (weight_net2 here, weight_net1 in rpe_corr3d_n2n; MLP2d(3,[8,8,C],relu), :66-67): n_w1 [8,3], n_b1 [8],
+ *   n_w2 [8,8], n_b2 [8], n_w3_packed [T][4][16][2]: [t][kk][n][s] = W3[16t + n][4s + kk], n_b3 [Cp].
+ *   p2n_rows [B,N,Cp] channel-last (the second hop gathers whole rows).
+ * rpe_corr3d_n2n: out[b][c][n] = sum_j weight_net1(xyz[:,knn_j] - xyz[:,n])[c] * p2n_rows[b][knn_j][c]   (:106-115),
+ *   knn = the neighbours of cloud 1 in itself; out [B,C,N] channel-first (what the reference returns).
+ * xyz_* channel-first through element strides (batch, dim, point); knn [B,N,*] int64, row stride >= 16.               */
+int rpe_corr3d_cost(const float *p1_rows, const float *p2_rows, const float *wc4, const float *w2_packed, const float *b2,
+                    const float *n_w1, const float *n_b1, const float *n_w2, const float *n_b2,
+                    const float *n_w3_packed, const float *n_b3,
+                    const float *xyz_q, int64_t q_sb, int64_t q_sd, int64_t q_sn,
+                    const float *xyz_s, int64_t s_sb, int64_t s_sd, int64_t s_sn,
+                    const int64_t *knn, int64_t knn_row_stride, int B, int Cp, int N, int M,
+                    float leaky_slope, float *p2n_rows, rpe_stream_t stream);
+int rpe_corr3d_n2n(const float *p2n_rows, const float *n_w1, const float *n_b1, const float *n_w2, const float *n_b2,
+                   const float *n_w3_packed, const float *n_b3,
+                   const float *xyz, int64_t x_sb, int64_t x_sd, int64_t x_sn,
+                   const int64_t *knn, int64_t knn_row_stride, int B, int C, int Cp, int N,
+                   float *out, rpe_stream_t stream);
 
 /* ---- Restormer-block pieces (models/restormer_arch.py) -------
  * rpe_dwconv3: depth-wise convolution, stride 1, zero padding 1: kh = 3 -> 3x3 over [B,C,H,W] (weight

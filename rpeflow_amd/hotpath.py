@@ -219,7 +219,9 @@ class HotPathWorkload(torch.nn.Module):
                 grid_sample_wrapper(ef_2d, xy1)
 
             with t.span("flow_estimator_3d"):
-                x_3d = torch.cat([self.aligners[level](corr_3d), self.aligners[level](f1_3d), last_flow_3d, last_flow_feat_3d], 1)
+                x_3d = [self.aligners[level](corr_3d), self.aligners[level](f1_3d), last_flow_3d, last_flow_feat_3d]
+                if not getattr(self.flow_estimator_3d, "concatenates", False):
+                    x_3d = torch.cat(x_3d, 1)
                 flow_feat_3d = self.flow_estimator_3d(xyz1, x_3d, knn_1in1)
             with t.span("project_feat"):  # decoder fusers (:394-395)
                 project_feat_with_nn_corr(xy1, self.flow_feat_2d[level], flow_feat_3d, nn_proj1[..., 0])

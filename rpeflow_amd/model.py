@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from .csrc import correlation2d as native_correlation2d
 from .csrc.wrapper import _correlation2d_algo as correlation2d_fused_leaky
 from .hotpath import native_ops
+from .pwc3d_core import FlowEstimator3D as NativeFlowEstimator3D
 from .utils import Conv1dNormRelu, Conv2dNormRelu, mesh_grid, resize_frames, upsample2x_pair
 from .utils import backwarp_2d as native_backwarp_2d
 
@@ -452,6 +453,17 @@ def _stamp(name):
         TRACE(name)
 
 
+def _tensors(items):
+    """The tensors among ``items`` (nested tuples flattened, None skipped): what crosses a stream boundary."""
+    out = []
+    for t in items:
+        if torch.is_tensor(t):
+            out.append(t)
+        elif isinstance(t, (tuple, list)):
+            out.extend(_tensors(t))
+    return out
+
+
 class _Branches:
     """Two-branch execution for decode(): at every pyramid level the 2-D chain (convolutions over H*W pixels) and the
     3-D chain (small kernels over N points) only meet at the three Bi-CLFM fusers, so the 3-D chain runs on a side HIP
@@ -567,7 +579,10 @@ class RPEFlow_core(nn.Module):
             # the aligners of the estimator inputs (:385-390) read the fused frame-1 features and the event features only
             aligned = (self.feature_aligners_2d[level](fused_2d[:batch_size]), self.efeature_aligners_2d[level](efeats_2d[level]),
                        self.feature_aligners_3d[level](fused_3d[:batch_size]))
-            return xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d, *aligned
+            # the feat1 / feat2 halves of Correlation3D's first layer need the fused features only (pwc3d_core.Correlation3D)
+            corr = self.correlations_3d[level]
+            corr_proj = corr.project_stacked(fused_3d) if hasattr(corr, "project_stacked") else None
+            return xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d, *aligned, corr_proj
 
         fused, ready = {}, {}
         if pre_stream is not None:
@@ -592,7 +607,7 @@ class RPEFlow_core(nn.Module):
             """This level's hoisted tensors, after the main stream has waited for them."""
             if pre_stream is not None:
                 main_stream.wait_event(ready[level])
-                for t in fused[level]:
+                for t in _tensors(fused[level]):
                     t.record_stream(main_stream)
             return fused.pop(level)
 
@@ -601,6 +616,7 @@ class RPEFlow_core(nn.Module):
             hoisted tensors and the side stream's own previous outputs only, so it follows the previous level's stage 3 on
             the side stream without waiting for the main stream's context network."""
             xy_both, _, knn_1in1, _, fused_3d = hoisted[:5]
+            corr_proj = hoisted[8]
             xyz1, xyz2, n_points = xyzs1[level], xyzs2[level], xyzs1[level].shape[-1]
             image_h, image_w = feats_2d_both[level].shape[2:]
             sx, sy = (image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1)
@@ -613,19 +629,23 @@ class RPEFlow_core(nn.Module):
                 last_flow_3d, last_flow_feat_3d = up[:, :3, :], up[:, 3:, :]
                 xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
                 _stamp("side L%d stage1 backwarp done" % level)
-            feat_corr_3d = self.correlations_3d[level](xyz1, fused_3d[:batch_size], xyz2_warp, fused_3d[batch_size:], knn_1in1)
+            if corr_proj is not None:
+                feat_corr_3d = self.correlations_3d[level](xyz1, fused_3d[:batch_size], xyz2_warp, fused_3d[batch_size:], knn_1in1,
+                                                           projected=corr_proj)
+            else:
+                feat_corr_3d = self.correlations_3d[level](xyz1, fused_3d[:batch_size], xyz2_warp, fused_3d[batch_size:], knn_1in1)
             last_flow_3d_to_2d = last_flow_3d[:, :2] * _pair_scale(sx, sy, last_flow_3d)  # (:371-372) one launch, not mul, mul, cat
             _stamp("side L%d stage1 done" % level)
             return last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d
 
         hoisted = take(top)
-        out_s1 = br.fork(lambda: stage1_3d(top, hoisted), list(hoisted) + [xyzs1[top], xyzs2[top]])
+        out_s1 = br.fork(lambda: stage1_3d(top, hoisted), _tensors(hoisted) + [xyzs1[top], xyzs2[top]])
         for level in range(top, 0, -1):
             xyz1 = xyzs1[level]
             efeat_2d = efeats_2d[level]
             image_h, image_w = feats_2d_both[level].shape[2:]
             _stamp("main L%d start" % level)
-            xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d, aligned_2d, aligned_e2d, aligned_3d = hoisted
+            xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d, aligned_2d, aligned_e2d, aligned_3d, _ = hoisted
             xy1, nn_proj1 = xy_both[:batch_size], nn_proj_both[:batch_size]
             feat1_2d, feat2_2d_fused = fused_2d[:batch_size], fused_2d[batch_size:]
 
@@ -653,7 +673,9 @@ class RPEFlow_core(nn.Module):
             def chain_3d():
                 corr_3d_fused = self.corr_feat_fusers_3d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d,
                                                                 last_flow_2d_to_3d)
-                x_3d = torch.cat([self.correlation_aligners_3d[level](corr_3d_fused), aligned_3d, last_flow_3d, last_flow_feat_3d], dim=1)
+                x_3d = [self.correlation_aligners_3d[level](corr_3d_fused), aligned_3d, last_flow_3d, last_flow_feat_3d]
+                if not isinstance(self.flow_estimator_3d, NativeFlowEstimator3D):  # (the native one concatenates while packing)
+                    x_3d = torch.cat(x_3d, dim=1)
                 est = self.flow_estimator_3d(xyz1, x_3d, knn_1in1)
                 _stamp("side L%d stage2 done" % level)
                 return (est,)
@@ -682,7 +704,7 @@ class RPEFlow_core(nn.Module):
                 # last level: the up-sampling of the 3-D flow to the full cloud belongs to this chain too (:430)
                 return (knn_interpolation(xyzs1[1], flow_3d.float(), xyzs1[0]),)
 
-            side_in = [flow_feat_2d_raw] + (list(nxt) + [xyzs1[level - 1], xyzs2[level - 1]] if nxt is not None else [xyzs1[0]])
+            side_in = [flow_feat_2d_raw] + (_tensors(nxt) + [xyzs1[level - 1], xyzs2[level - 1]] if nxt is not None else [xyzs1[0]])
             out_s1 = br.fork(chain_3d, side_in)
             flow_feat_2d = self.estimator_feat_fuser_2d(xy1, flow_feat_2d_raw, flow_feat_3d_raw, nn_proj1)
             flow_2d = last_flow_2d + self.conv_last_2d(flow_feat_2d)

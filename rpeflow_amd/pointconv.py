@@ -2,10 +2,13 @@
 
 Same constructor arguments, forward signatures and state-dict keys
 (``weight_net.convs.{0,1}.conv_fn.*``, ``linear.*``, ``norm_fn.*``), so the
-reference's checkpoints load.  forward() runs the KNN kernel, ONE fused
-grouping kernel (gather + weight net + k-reduction, csrc/pointconv.hip) and
-the nn.Linear on hipBLASLt; the reference's six intermediate tensors
-(pointconv.py:49-57) are never materialised.
+reference's checkpoints load.  forward() is the KNN kernel (unless the caller
+brings the neighbour table), one pass that lays ``cat([xyz, features])`` out
+channel-last (pointconv.py:43-44) and ONE fused kernel for everything else --
+gather, weight net, the 16 x (C+3) weighted sums, nn.Linear, bias, eval-mode
+BatchNorm and the activation (csrc/pointconv_fused.hip).  None of the
+reference's intermediates (pointconv.py:49-57; [B,Q,16,C+3] and [B,Q,16(C+3)]
+are 208 MB each at pyramid level 1) is ever written to memory.
 """
 import ctypes
 
@@ -16,33 +19,54 @@ from . import _lib
 from .csrc import k_nearest_neighbor
 from .utils import MLP2d, _act, _norm, affine_epilogue
 
+_ACT = {None: 0, "relu": 1, "leaky_relu": 2}
+
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def pointconv_group(xyz, features, query_xyz, knn_indices, weight_net, slope=0.1):
-    """[B,3,M], [B,C,M], [B,3,Q], [B,Q,>=16] -> [B,Q,16*(C+3)] (pointconv.py:43-57)."""
-    _lib.require_gpu(xyz, features, query_xyz, knn_indices, op="pointconv_group")
+class PackedRows:
+    """``cat([xyz, features])`` channel-last, [B,M,CFp] with CFp = 16 * ceil((C+3)/16), zero beyond column C+3: what the
+    fused kernel gathers from.  Produced by pack_rows() or by a PointConv layer asked for ``out_rows=True``."""
+
+    def __init__(self, rows, channels):
+        self.rows, self.channels = rows, channels  # channels = C (features only)
+
+
+def pack_rows(xyz, features):
+    """[B,3,M] and [B,C,M] (or a list of up to four such tensors, concatenated along the channels) -> PackedRows."""
+    sources = list(features) if isinstance(features, (list, tuple)) else [features]
+    _lib.require_gpu(xyz, *sources, op="pointconv pack_rows")
+    assert 1 <= len(sources) <= 4
+    xyz = xyz if xyz.dtype == torch.float32 else xyz.float()
+    sources = [s if s.dtype == torch.float32 else s.float() for s in sources]
     B, _, M = xyz.shape
-    Q = query_xyz.shape[2]
-    feats_cl = torch.cat([xyz, features], dim=1).transpose(1, 2).contiguous().float()  # [B,M,C+3]
-    CF = feats_cl.shape[2]
-    c0, c1 = weight_net.convs[0].conv_fn, weight_net.convs[1].conv_fn
-    w1, b1 = c0.weight.detach().reshape(8, 3).contiguous().float(), c0.bias.detach().contiguous().float()
-    w2, b2 = c1.weight.detach().reshape(16, 8).contiguous().float(), c1.bias.detach().contiguous().float()
-    knn_indices = knn_indices.to(torch.int64)
-    if knn_indices.stride(2) != 1 or knn_indices.stride(0) != Q * knn_indices.stride(1):
-        knn_indices = knn_indices.contiguous()
-    xyz, query_xyz = xyz.float(), query_xyz.float()
-    out = torch.empty((B, Q, 16 * CF), dtype=torch.float32, device=xyz.device)
+    C = sum(s.shape[1] for s in sources)
+    CFp = (C + 3 + 15) // 16 * 16
+    rows = torch.empty((B, M, CFp), dtype=torch.float32, device=xyz.device)
+    n = len(sources)
+    ptrs = (ctypes.c_void_p * n)(*[s.data_ptr() for s in sources])
+    strides = (ctypes.c_int64 * (3 * n))(*[v for s in sources for v in s.stride()])
+    chans = (ctypes.c_int * n)(*[s.shape[1] for s in sources])
     with torch.cuda.device(xyz.device):
-        rc = _lib.lib().rpe_pointconv_group(
-            _ptr(xyz), *xyz.stride(), _ptr(query_xyz), *query_xyz.stride(), _ptr(feats_cl),
-            _ptr(knn_indices), knn_indices.stride(1), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), float(slope),
-            B, M, Q, CF, _ptr(out), _lib.stream_of(xyz))
-    _lib.check(rc, "pointconv_group")
-    return out
+        rc = _lib.lib().rpe_pointconv_pack_rows(_ptr(xyz), *xyz.stride(), ptrs, strides, chans, n, B, M, CFp, _ptr(rows),
+                                                _lib.stream_of(xyz))
+    _lib.check(rc, "pointconv pack_rows")
+    return PackedRows(rows, C)
+
+
+def pack_linear(weight, C):
+    """nn.Linear(16*(C+3), Cout).weight -> the fused kernel's B-operand fragments (include/rpeflow_hip.h):
+    packed[ci][g][t][kk][n][s] = W[16t + n][(4kk + s)*(C+3) + 16ci + g], zero-padded; returns (tensor, n_tiles)."""
+    Cout, CF = weight.shape[0], C + 3
+    assert weight.shape[1] == 16 * CF
+    CFp, n_tiles = (CF + 15) // 16 * 16, (Cout + 127) // 128 * 8
+    w = torch.zeros((16 * n_tiles, 16, CFp), dtype=torch.float32, device=weight.device)
+    w[:Cout, :, :CF] = weight.detach().float().reshape(Cout, 16, CF)
+    #     o = (t, n)      w = (kk, s)      c = (ci, g)
+    w = w.reshape(n_tiles, 16, 4, 4, CFp // 16, 16).permute(4, 5, 0, 2, 1, 3).contiguous()
+    return w, n_tiles
 
 
 class _PointConv(nn.Module):
@@ -52,44 +76,83 @@ class _PointConv(nn.Module):
             raise NotImplementedError("rpeflow_amd PointConv is built for k=16 (conf/*/*.yaml pwc3d.k)")
         if activation != "leaky_relu":
             raise NotImplementedError("rpeflow_amd PointConv fuses the weight net's leaky_relu(0.1)")
+        if norm not in (None, "batch_norm"):
+            raise NotImplementedError("rpeflow_amd PointConv fuses eval-mode BatchNorm only (conf/*/*.yaml norms)")
         self.k = k
+        self.in_channels, self.out_channels = in_channels, out_channels
         self.weight_net = MLP2d(3, [8, 16], activation=activation)  # pointconv.py:12
         self.linear = nn.Linear(16 * (in_channels + 3), out_channels)  # pointconv.py:13
         self.norm_fn = _norm(norm, out_channels, 1)
         self.activation_fn = _act(activation)
+        self._packed = None
 
-    def _finish(self, grouped):
-        epi = affine_epilogue(self, self.linear.bias, self.norm_fn, self.activation_fn) if grouped.is_cuda else None
+    def _weights(self):
+        """Kernel-layout copies of the parameters; rebuilt when one changes (load_state_dict, .to(), an optimiser step)."""
+        params = [self.linear.weight] + [t for conv in self.weight_net.convs for t in (conv.conv_fn.weight, conv.conv_fn.bias)]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._packed is None or self._packed[0] != key:
+            c0, c1 = self.weight_net.convs[0].conv_fn, self.weight_net.convs[1].conv_fn
+            lp, n_tiles = pack_linear(self.linear.weight, self.in_channels)
+            self._packed = (key, dict(
+                w1=c0.weight.detach().reshape(8, 3).contiguous().float(), b1=c0.bias.detach().contiguous().float(),
+                w2=c1.weight.detach().reshape(16, 8).contiguous().float(), b2=c1.bias.detach().contiguous().float(),
+                lp=lp, n_tiles=n_tiles))
+        return self._packed[1]
+
+    def _run(self, packed, query_xyz, knn_indices, out_rows):
+        rows = packed.rows
+        _lib.require_gpu(rows, query_xyz, knn_indices, op="PointConv")
+        if packed.channels != self.in_channels:
+            raise RuntimeError("PointConv: %d feature channels given, layer built for %d" % (packed.channels, self.in_channels))
+        epi = affine_epilogue(self, self.linear.bias, self.norm_fn, self.activation_fn)
         if epi is None:
-            out = self.linear(grouped).float()  # [B,Q,Cout]
-            return self.activation_fn(self.norm_fn(out.transpose(1, 2)))
-        # W [Cout,K] x grouped^T [B,K,Q] lands channel-first with no transpose pass; bias + eval BatchNorm + activation
-        # follow as one in-place kernel
-        from .restormer_ops import channel_affine_act_
+            raise NotImplementedError("rpeflow_amd PointConv is inference-only: BatchNorm must be in eval mode")
         scale, shift, kind = epi
-        out = torch.matmul(self.linear.weight, grouped.transpose(1, 2))  # [B,Cout,Q]
-        return channel_affine_act_(out, scale, shift, kind, 0.1)
+        w = self._weights()
+        B, M, CFp = rows.shape
+        Q = query_xyz.shape[2]
+        knn_indices = knn_indices.to(torch.int64)
+        if knn_indices.stride(2) != 1 or knn_indices.stride(0) != Q * knn_indices.stride(1):
+            knn_indices = knn_indices.contiguous()
+        query_xyz = query_xyz if query_xyz.dtype == torch.float32 else query_xyz.float()
+        Cout = self.out_channels
+        if out_rows:
+            stride = (Cout + 3 + 15) // 16 * 16
+            out = torch.empty((B, Q, stride), dtype=torch.float32, device=rows.device)
+        else:
+            stride = 0
+            out = torch.empty((B, Cout, Q), dtype=torch.float32, device=rows.device)
+        with torch.cuda.device(rows.device):
+            rc = _lib.lib().rpe_pointconv_fused(
+                _ptr(rows), CFp, M, _ptr(knn_indices), knn_indices.stride(1), _ptr(query_xyz), *query_xyz.stride(),
+                _ptr(w["w1"]), _ptr(w["b1"]), _ptr(w["w2"]), _ptr(w["b2"]), 0.1, _ptr(w["lp"]), w["n_tiles"],
+                _ptr(scale), _ptr(shift), _ACT[kind], 0.1, B, Q, Cout, int(out_rows), stride, _ptr(out), _lib.stream_of(rows))
+        _lib.check(rc, "PointConv")
+        return PackedRows(out, Cout) if out_rows else out
 
 
 class PointConvDownSampling(_PointConv):
     """pointconv.py:7-61."""
 
-    def forward(self, xyz, features, sampled_xyz, knn_indices=None):
-        """``knn_indices`` [B,Q,k]: neighbours of sampled_xyz in xyz if the caller already has them (the reference
-        always searches here, pointconv.py:46)."""
+    def forward(self, xyz, features, sampled_xyz, knn_indices=None, out_rows=False):
+        """``features``: [B,C,M], a list of such tensors (concatenated), or PackedRows.  ``knn_indices`` [B,Q,>=k]: the
+        neighbours of sampled_xyz in xyz if the caller already has them (the reference always searches here,
+        pointconv.py:46).  ``out_rows``: return PackedRows over the SAMPLED points instead of [B,Cout,Q]."""
         if knn_indices is None:
             knn_indices = k_nearest_neighbor(xyz, sampled_xyz, self.k)  # [B,Q,k]
-        return self._finish(pointconv_group(xyz, features, sampled_xyz, knn_indices, self.weight_net))
+        packed = features if isinstance(features, PackedRows) else pack_rows(xyz, features)
+        return self._run(packed, sampled_xyz, knn_indices, out_rows)
 
 
 class PointConvNoSampling(_PointConv):
     """pointconv.py:64-122."""
 
-    def forward(self, xyz, features, knn_indices=None):
+    def forward(self, xyz, features, knn_indices=None, out_rows=False):
         batch_size, n_points = xyz.shape[0], xyz.shape[2]
         if knn_indices is not None:
             assert knn_indices.shape[:2] == torch.Size([batch_size, n_points])
             assert knn_indices.shape[2] >= self.k
         else:
             knn_indices = k_nearest_neighbor(xyz, xyz, self.k)
-        return self._finish(pointconv_group(xyz, features, xyz, knn_indices, self.weight_net))
+        packed = features if isinstance(features, PackedRows) else pack_rows(xyz, features)
+        return self._run(packed, xyz, knn_indices, out_rows)

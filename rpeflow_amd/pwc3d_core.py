@@ -58,17 +58,25 @@ class FeaturePyramid3D(nn.Module):
         return feats
 
 
+def _pad_channels(c):
+    """Channel counts the Correlation3D kernels are instantiated for (16 * T, T in 1, 2, 4, 6, 8, 12)."""
+    for cp in (16, 32, 64, 96, 128, 192):
+        if c <= cp:
+            return cp
+    raise NotImplementedError("rpeflow_amd Correlation3D: out_channels <= 192 (got %d)" % c)
+
+
 class Correlation3D(nn.Module):
     """pwc3d_core.py:60-117.
 
     The first cost_mlp layer is linear in the concatenation [feat1 | feat2_nbr | rel]
-    (pwc3d_core.py:92-94), so it is applied per POINT before the gather --
-    W_a feat1 + gather(W_b feat2) + W_c rel -- instead of per (point, neighbour) pair:
-    k = 16 times fewer multiply-adds in that layer, and the [B, 2C+3, N, k] tensor is
-    never built.  The gather + sum + leaky_relu, both weight nets and both k-sums run
-    in three launches of two HIP kernels (csrc/corr3d.hip); the only dense work left is
-    three GEMMs on hipBLASLt.  Results differ from the reference by fp32 re-association
-    only."""
+    (pwc3d_core.py:92-94), so its feat1 / feat2 blocks are applied per POINT before the
+    gather -- ``project()``: one batched GEMM, which depends on the features only and can
+    be issued long before the warped cloud exists -- instead of per (point, neighbour)
+    pair, and the [B, 2C+3, N, k] tensor is never built.  Behind the neighbour search the
+    rest is two kernels (csrc/corr3d_fused.hip): gather + rel block + second layer on MFMA +
+    weight_net2 + k-sum, then the second hop.  Results differ from the reference by fp32
+    re-association only."""
 
     def __init__(self, in_channels, out_channels, k=16):
         super().__init__()
@@ -80,73 +88,100 @@ class Correlation3D(nn.Module):
         self.weight_net2 = MLP2d(3, [8, 8, out_channels], activation="relu")
         self._cache = None
 
-    def _weights(self, in_channels):
-        """Contiguous fp32 views of the parameters in the layout the kernels read; rebuilt when a
+    def _weights(self):
+        """fp32 copies of the parameters in the layouts the kernels read (include/rpeflow_hip.h); rebuilt when a
         parameter changes (load_state_dict, .to(), an optimiser step)."""
         params = list(self.parameters())
         key = tuple((p.data_ptr(), p._version) for p in params)
         if self._cache is None or self._cache[0] != key:
             first, second = self.cost_mlp.convs[0].conv_fn, self.cost_mlp.convs[1].conv_fn
             w = first.weight.detach()[:, :, 0, 0].float()
-            c = in_channels
-            net = lambda m: [t.detach().float().reshape(t.shape[0], -1).contiguous() if t.dim() > 1 else t.detach().float().contiguous()
-                             for conv in m.convs for t in (conv.conv_fn.weight, conv.conv_fn.bias)]
+            c_out, c_in = w.shape[0], (w.shape[1] - 3) // 2
+            cp, dev = _pad_channels(c_out), w.device
+            t = cp // 16
+
+            def pad(x, *shape):
+                out = torch.zeros(shape, dtype=torch.float32, device=dev)
+                out[tuple(slice(0, n) for n in x.shape)] = x
+                return out
+
+            def net(m):
+                c0, c1, c2 = (conv.conv_fn for conv in m.convs)
+                w3 = pad(c2.weight.detach().float().reshape(c_out, 8), cp, 8)
+                return [c0.weight.detach().float().reshape(8, 3).contiguous(), c0.bias.detach().float().contiguous(),
+                        c1.weight.detach().float().reshape(8, 8).contiguous(), c1.bias.detach().float().contiguous(),
+                        w3.reshape(t, 16, 2, 4).permute(0, 3, 1, 2).contiguous(),  # [t][n][s][kk] -> [t][kk][n][s]
+                        pad(c2.bias.detach().float(), cp)]
+
+            w2 = pad(second.weight.detach()[:, :, 0, 0].float(), cp, cp)
             self._cache = (key, dict(
-                w_a=w[:, :c].contiguous(), w_b=w[:, c:2 * c].contiguous(), w_c=w[:, 2 * c:].contiguous(),
-                b_first=first.bias.detach().float().contiguous(),
-                w_second=second.weight.detach()[:, :, 0, 0].float().contiguous(),
-                b_second=second.bias.detach().float().contiguous(),
+                c_out=c_out, c_in=c_in, cp=cp,
+                # per-point halves of the first layer for the stacked [feat1; feat2] batch: columns padded to cp
+                w_ab_t=torch.stack([pad(w[:, :c_in].t(), c_in, cp), pad(w[:, c_in:2 * c_in].t(), c_in, cp)]),
+                bias_ab=torch.stack([pad(first.bias.detach().float(), cp), torch.zeros(cp, device=dev)]),
+                wc4=pad(w[:, 2 * c_in:], cp, 4),
+                w2p=w2.reshape(t, 16, t, 4, 4).permute(2, 0, 3, 1, 4).contiguous(),  # [t][n][g][kk][s] -> [g][t][kk][n][s]
+                b2=pad(second.bias.detach().float(), cp),
                 net1=net(self.weight_net1), net2=net(self.weight_net2)))
         return self._cache[1]
 
-    def forward(self, xyz1, feat1, xyz2, feat2, knn_indices_1in1=None):
+    def project_stacked(self, feat_both):
+        """project() for the two clouds' features stacked on the batch axis ([2B,C,N], cloud 1 first): ONE batched GEMM."""
+        w = self._weights()
+        batch_size = feat_both.shape[0] // 2
+        wt = w["w_ab_t"].repeat_interleave(batch_size, dim=0)
+        bias = w["bias_ab"].repeat_interleave(batch_size, dim=0)[:, None, :]
+        rows = torch.baddbmm(bias, feat_both.float().transpose(1, 2), wt)
+        return rows[:batch_size], rows[batch_size:]
+
+    def project(self, feat1, feat2):
+        """(p1_rows [B,N,Cp], p2_rows [B,M,Cp]): the feat1 / feat2 blocks of cost_mlp's first layer per point, channel-last.
+        Depends on the features only; callers that know them early pass the result to forward(projected=...)."""
+        if feat1.shape[2] == feat2.shape[2]:
+            return self.project_stacked(torch.cat([feat1, feat2], dim=0))
+        w = self._weights()
+        batch_size = feat1.shape[0]
+        p1 = torch.baddbmm(w["bias_ab"][0][None, None, :], feat1.float().transpose(1, 2), w["w_ab_t"][0][None].expand(batch_size, -1, -1))
+        p2 = torch.matmul(feat2.float().transpose(1, 2), w["w_ab_t"][1])
+        return p1, p2
+
+    def forward(self, xyz1, feat1, xyz2, feat2, knn_indices_1in1=None, projected=None):
         from . import _lib
         from .utils import _ptr
         _lib.require_gpu(xyz1, feat1, xyz2, feat2, op="Correlation3D")
-        batch_size, in_channels, n_points = feat1.shape
+        batch_size, _, n_points = feat1.shape
         m_points = xyz2.shape[2]
-        w = self._weights(in_channels)
-        c_out = w["w_a"].shape[0]
+        w = self._weights()
         xyz1, xyz2 = xyz1.float(), xyz2.float()
         lib, stream = _lib.lib(), _lib.stream_of(xyz1)
 
         knn_indices_1in2 = k_nearest_neighbor(input_xyz=xyz2, query_xyz=xyz1, k=self.k)
-        part1 = torch.baddbmm(w["b_first"][None, :, None], w["w_a"][None].expand(batch_size, -1, -1), feat1.float())
-        part2 = torch.matmul(w["w_b"], feat2.float())
-        hidden = torch.empty((batch_size, c_out, n_points, self.k), dtype=torch.float32, device=xyz1.device)
+        p1_rows, p2_rows = projected if projected is not None else self.project(feat1, feat2)
+        p2n_rows = torch.empty((batch_size, n_points, w["cp"]), dtype=torch.float32, device=xyz1.device)
         with torch.cuda.device(xyz1.device):
-            rc = lib.rpe_corr3d_hidden(_ptr(part1), _ptr(part2), _ptr(w["w_c"]), _ptr(xyz1), *xyz1.stride(),
-                                       _ptr(xyz2), *xyz2.stride(), _ptr(knn_indices_1in2), knn_indices_1in2.stride(1),
-                                       batch_size, c_out, n_points, m_points, 0.1, _ptr(hidden), stream)
-        _lib.check(rc, "Correlation3D (hidden)")
-        # second cost_mlp layer: one GEMM over all (point, neighbour) pairs, then leaky_relu(0.1)
-        from .restormer_ops import channel_affine_act_
-        p2p_cost = torch.matmul(w["w_second"], hidden.view(batch_size, c_out, -1))
-        p2p_cost = channel_affine_act_(p2p_cost, None, w["b_second"], "leaky_relu", 0.1)  # bias + leaky_relu in one in-place pass
-
-        p2n_cost = torch.empty((batch_size, c_out, n_points), dtype=torch.float32, device=xyz1.device)
-        with torch.cuda.device(xyz1.device):
-            rc = lib.rpe_corr3d_weighted_sum(_ptr(p2p_cost), 0, *[_ptr(t) for t in w["net2"]], _ptr(xyz1), *xyz1.stride(),
-                                             _ptr(xyz2), *xyz2.stride(), _ptr(knn_indices_1in2), knn_indices_1in2.stride(1),
-                                             batch_size, c_out, n_points, m_points, _ptr(p2n_cost), stream)
-        _lib.check(rc, "Correlation3D (p2n)")
+            rc = lib.rpe_corr3d_cost(_ptr(p1_rows), _ptr(p2_rows), _ptr(w["wc4"]), _ptr(w["w2p"]), _ptr(w["b2"]),
+                                     *[_ptr(t) for t in w["net2"]], _ptr(xyz1), *xyz1.stride(), _ptr(xyz2), *xyz2.stride(),
+                                     _ptr(knn_indices_1in2), knn_indices_1in2.stride(1), batch_size, w["cp"], n_points, m_points,
+                                     0.1, _ptr(p2n_rows), stream)
+        _lib.check(rc, "Correlation3D (point-to-neighbour cost)")
 
         if knn_indices_1in1 is not None:
             assert knn_indices_1in1.shape == torch.Size([batch_size, n_points, self.k])
             knn_indices_1in1 = knn_indices_1in1.to(torch.int64).contiguous()
         else:
             knn_indices_1in1 = k_nearest_neighbor(input_xyz=xyz1, query_xyz=xyz1, k=self.k)
-        n2n_cost = torch.empty_like(p2n_cost)
+        n2n_cost = torch.empty((batch_size, w["c_out"], n_points), dtype=torch.float32, device=xyz1.device)
         with torch.cuda.device(xyz1.device):
-            rc = lib.rpe_corr3d_weighted_sum(_ptr(p2n_cost), 1, *[_ptr(t) for t in w["net1"]], _ptr(xyz1), *xyz1.stride(),
-                                             _ptr(xyz1), *xyz1.stride(), _ptr(knn_indices_1in1), knn_indices_1in1.stride(1),
-                                             batch_size, c_out, n_points, n_points, _ptr(n2n_cost), stream)
-        _lib.check(rc, "Correlation3D (n2n)")
+            rc = lib.rpe_corr3d_n2n(_ptr(p2n_rows), *[_ptr(t) for t in w["net1"]], _ptr(xyz1), *xyz1.stride(),
+                                    _ptr(knn_indices_1in1), knn_indices_1in1.stride(1), batch_size, w["c_out"], w["cp"], n_points,
+                                    _ptr(n2n_cost), stream)
+        _lib.check(rc, "Correlation3D (neighbour-to-neighbour cost)")
         return n2n_cost
 
 
 class FlowEstimator3D(nn.Module):
     """pwc3d_core.py:120-148."""
+    concatenates = True  # forward() accepts the list of tensors a caller would torch.cat
 
     def __init__(self, n_channels, norm=None, conv_last=True, k=16):
         super().__init__()
@@ -156,8 +191,10 @@ class FlowEstimator3D(nn.Module):
         self.conv_last = nn.Conv1d(n_channels[3], 3, kernel_size=1) if conv_last else None
 
     def forward(self, xyz, feat, knn_indices):
-        feat = self.point_conv1.forward(xyz, feat, knn_indices)
-        feat = self.point_conv2.forward(xyz, feat, knn_indices)
+        """``feat``: [B,C,N], or the list of tensors the caller would concatenate along the channels
+        (RPEFlow_core.py:382-391): the first layer's packing pass does that concatenation."""
+        rows = self.point_conv1.forward(xyz, feat, knn_indices, out_rows=True)  # channel-last, the second layer's gather source
+        feat = self.point_conv2.forward(xyz, rows, knn_indices)
         feat = self.mlp(feat)
         if self.conv_last is not None:
             return feat, self.conv_last(feat)
