@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 1
+#define RPE_ABI_VERSION 2
 
 #define RPE_EINVAL (-1)       /* bad size / null pointer */
 #define RPE_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
@@ -46,15 +46,25 @@ const char *rpe_error_string(int code);
  * (k_nearest_neighbor.cpp:3-4, kernels k_nearest_neighbor_kernel.cu:8-112) with
  * the arithmetic of the CPU fallback (wrapper.py:40-52,115-117):
  *   d = fl(fl(-2*dot + |q|^2) + |p|^2), dot = fma(q2,p2,fma(q1,p1,q0*p0)),
- * k smallest, ascending, equal distances ordered by input index.
+ * k smallest, ascending.  tie_mode says what happens to EQUAL distances (the reference is matmul + torch.topk on the
+ * CPU, i.e. libstdc++'s partial_sort / nth_element + sort, restated in knn.hip; k <= 63):
+ *   RPE_KNN_TIES_TORCH  any tie among the k+1 best makes the query redo its selection exactly as torch.topk does it:
+ *                       indices equal the reference's position for position (the few waves that redo run much longer:
+ *                       +45 % on a 8192 -> 4096, k = 16 search, 1 % on the whole forward);
+ *   RPE_KNN_TIES_SET    only a tie between the k-th and the (k+1)-th distance triggers the redo: the returned neighbour
+ *                       SET still always equals the reference's, equal distances inside the top k stay in index order;
+ *   RPE_KNN_TIES_INDEX  lowest index first everywhere (no redo).
  * Either point layout is accepted through strides (elements, not bytes):
  *   input[b][m][d] = input[b*in_sb + m*in_sn + d*in_sd], same for query,
  * so channel-first callers need no transpose (wrapper.py:119-122 does one).
  * idx  [B,Q,k] int64 contiguous; dist [B,Q,k] fp32 contiguous or NULL.
- * Limits: 1 <= D <= 3, 1 <= k <= 64, k <= M.                                  */
+ * Limits: 1 <= D <= 3, 1 <= k <= 64, k <= M (k = 64: index order whatever the mode).            */
+#define RPE_KNN_TIES_INDEX 0
+#define RPE_KNN_TIES_SET 1
+#define RPE_KNN_TIES_TORCH 3
 int rpe_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd,
             const float *query, int64_t q_sb, int64_t q_sn, int64_t q_sd,
-            int B, int M, int Q, int D, int k,
+            int B, int M, int Q, int D, int k, int tie_mode,
             int64_t *idx, float *dist, rpe_stream_t stream);
 
 /* Several searches with the same (B, D, k) in ONE launch: job i is rpe_knn(jobs[i]...) exactly.  The PointConv pyramid's
@@ -69,7 +79,7 @@ typedef struct rpe_knn_job {
     int64_t *idx;                   /* [B,Q,k] */
     float *dist;                    /* [B,Q,k] or NULL */
 } rpe_knn_job;
-int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, rpe_stream_t stream);
+int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, int tie_mode, rpe_stream_t stream);
 
 /* ---- squared_distance (wrapper.py:40-52) ------------------------------------
  * out[b][i][j] = distance above between xyz1[b][i] and xyz2[b][j]; out contiguous. */
@@ -312,15 +322,6 @@ int rpe_probe_mfma4x4(float *out256, rpe_stream_t stream);
  * in front of the barrier, 1/2/4 clusters a wave (2, 4-7: 1024 < N <= 16384, else 3).  All give identical indices;
  * kept for A/B timing and cross-checks. */
 int rpe_debug_set_fps_variant(int variant);
-/* How k_nearest_neighbor treats EQUAL distances (k <= 17; the reference is matmul + torch.topk on the CPU, i.e.
- * libstdc++'s partial_sort / nth_element, restated in knn.hip):
- *   3 (default) any tie among the k+1 best makes the query redo its selection exactly as torch.topk does it: indices
- *               equal the reference's position for position (the few waves that redo run much longer: +45 % on a
- *               8192 -> 4096, k = 16 search, 1 % on the whole forward);
- *   1           only a tie between the k-th and the (k+1)-th distance triggers the redo: the returned neighbour SET
- *               still always equals the reference's, equal distances inside the top k stay in index order;
- *   0           lowest index first everywhere (no redo).                                                         */
-int rpe_debug_set_knn_exact_ties(int on);
 /* Writes the GPU's constant-rate clock (100 MHz wall_clock64) to *slot when the stream reaches this point: a
  * one-thread kernel, usable inside a captured HIP graph, for timelines of multi-stream replays that rocprofv3
  * serialises.                                                                                               */

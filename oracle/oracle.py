@@ -74,7 +74,7 @@ def squared_distance(xyz1, xyz2):
 def k_nearest_neighbor(input_xyz, query_xyz, k, return_dists=False, ties="torch"):
     """models/csrc/wrapper.py:106-127 (CPU branch :115-117), including the
     ``shape[1] <= 3`` channel-first sniff (:119-122).  ties="torch": equal distances selected and ordered as
-    torch.topk does on the CPU (libstdc++ partial_sort / nth_element restated in rpe_oracle.c; k <= 17);
+    torch.topk does on the CPU (libstdc++ partial_sort / nth_element / sort restated in rpe_oracle.c);
     ties="index": lower index first."""
     input_xyz, query_xyz = np.asarray(input_xyz), np.asarray(query_xyz)
     if input_xyz.shape[1] <= 3:
@@ -88,7 +88,7 @@ def k_nearest_neighbor(input_xyz, query_xyz, k, return_dists=False, ties="torch"
         raise RuntimeError("selected index k out of range")  # what torch.topk raises
     idx = np.empty((B, Q, k), np.int64)
     dist = np.empty((B, Q, k), np.float32)
-    fn = lib().orc_knn_torch_ties if (ties == "torch" and k <= 17) else lib().orc_knn
+    fn = lib().orc_knn_torch_ties if ties == "torch" else lib().orc_knn
     rc = fn(_p(input_xyz), _p(query_xyz), B, M, Q, D, k, idx.ctypes.data_as(_i64p), _p(dist))
     assert rc == 0
     return (idx, dist) if return_dists else idx

@@ -126,7 +126,7 @@ ORC_API int orc_knn(const float *input, const float *query, int B, int M, int Q,
  * only (NaN last), so which of several equal values survives, and in which order, is whatever libstdc++'s heap /
  * introselect code does with them.  Restated here from libstdc++ (bits/stl_heap.h, bits/stl_algo.h: __adjust_heap,
  * __push_heap, __make_heap, __pop_heap, __heap_select, __sort_heap, __introselect, __move_median_to_first,
- * __unguarded_partition, __insertion_sort), for k - 1 <= 16 (std::sort is then a plain insertion sort). */
+ * __unguarded_partition, __insertion_sort, __introsort_loop, __final_insertion_sort). */
 typedef struct { float v; int64_t i; } orc_pair;
 
 static int pair_less(const orc_pair *x, const orc_pair *y) {
@@ -232,17 +232,44 @@ static void introselect(orc_pair *first, orc_pair *nth, orc_pair *last, long dep
     insertion_sort(first, last);
 }
 static long floor_log2(long n) { long l = 0; while (n > 1) { n >>= 1; ++l; } return l; }
+static void introsort_loop(orc_pair *first, orc_pair *last, long depth_limit) { /* std::__introsort_loop, _S_threshold = 16 */
+    while (last - first > 16) {
+        if (depth_limit == 0) { /* std::__partial_sort(first, last, last) */
+            heap_select(first, last, last);
+            heap_sort(first, last);
+            return;
+        }
+        --depth_limit;
+        orc_pair *cut = partition_pivot(first, last);
+        introsort_loop(cut, last, depth_limit);
+        last = cut;
+    }
+}
+static void std_sort(orc_pair *first, orc_pair *last) { /* std::sort: introsort loop + __final_insertion_sort */
+    if (first == last) return;
+    introsort_loop(first, last, floor_log2(last - first) * 2);
+    if (last - first > 16) {
+        insertion_sort(first, first + 16);
+        for (orc_pair *i = first + 16; i != last; ++i) { /* __unguarded_insertion_sort */
+            orc_pair val = *i, *pos = i, *next = i - 1;
+            while (pair_less(&val, next)) { *pos = *next; pos = next; --next; }
+            *pos = val;
+        }
+    } else {
+        insertion_sort(first, last);
+    }
+}
 
 /* queue: n scratch pairs; returns 1 if k is outside what this restatement covers */
 static int topk_smallest_like_torch(const float *vals, long n, long k, orc_pair *queue, int64_t *out_idx, float *out_val) {
-    if (k < 1 || k > n || k > 17) return 1;
+    if (k < 1 || k > n) return 1;
     for (long j = 0; j < n; ++j) { queue[j].v = vals[j]; queue[j].i = j; }
     if (k * 64 <= n) { /* std::partial_sort(begin, begin + k, end) */
         heap_select(queue, queue + k, queue + n);
         heap_sort(queue, queue + k);
     } else { /* std::nth_element(begin, begin + k - 1, end); std::sort(begin, begin + k - 1) */
         introselect(queue, queue + (k - 1), queue + n, floor_log2(n) * 2);
-        insertion_sort(queue, queue + (k - 1)); /* std::sort of <= 16 elements == __insertion_sort */
+        std_sort(queue, queue + (k - 1)); /* (a plain __insertion_sort while k - 1 <= 16) */
     }
     for (long j = 0; j < k; ++j) { out_idx[j] = queue[j].i; if (out_val) out_val[j] = queue[j].v; }
     return 0;

@@ -21,7 +21,7 @@ _c_ptr = ctypes.c_void_p
 _PROTOTYPES = {
     "rpe_abi_version": [],
     "rpe_knn": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
-                _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
+                _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_squared_distance": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                              _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_fps": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
@@ -44,10 +44,9 @@ _PROTOTYPES = {
                                         _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
     "rpe_corr3d_n2n": [_c_ptr] * 7 + [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_correlation2d_backward": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
-    "rpe_knn_multi": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr],
+    "rpe_knn_multi": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr],
     "rpe_debug_set_fps_variant": [_c_int],
     "rpe_debug_stamp": [_c_ptr, _c_ptr],
-    "rpe_debug_set_knn_exact_ties": [_c_int],
     "rpe_gather_channel_first": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_gather_channel_last": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_knn_interpolate": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
@@ -72,6 +71,8 @@ _PROTOTYPES = {
 }
 
 _lib = None
+ABI_VERSION = 2  # RPE_ABI_VERSION of include/rpeflow_hip.h
+KNN_TIES = {"torch": 3, "set": 1, "index": 0}  # RPE_KNN_TIES_* (how equal distances are resolved)
 
 
 class KnnJob(ctypes.Structure):
@@ -100,7 +101,7 @@ def lib():
         handle.rpe_channel_attention_workspace_floats.restype = _c_i64
         handle.rpe_error_string.argtypes = [_c_int]
         handle.rpe_error_string.restype = ctypes.c_char_p
-        if handle.rpe_abi_version() != 1:
+        if handle.rpe_abi_version() != ABI_VERSION:
             raise RuntimeError("librpeflow_hip.so: ABI version mismatch")
         _lib = handle
     return _lib

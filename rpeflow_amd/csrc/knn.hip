@@ -55,8 +55,8 @@ struct Queries {
 // code does (aten/src/ATen/native/TopKImpl.h; bits/stl_heap.h, bits/stl_algo.h).  The sweep below keeps one entry more
 // than k: any two equal neighbours among the k + 1 best mean the result could depend on that code, and only then the
 // query is redone by a literal restatement of it -- heap_* on a lane-distributed heap for the partial_sort case,
-// seq_* by one lane on an LDS copy of the row for the (small M) nth_element case.  k <= 17; NaN distances are not
-// modelled (the sweep never selects them).
+// seq_* by one lane on an LDS copy of the row for the (small M) nth_element case.  k <= 63 (the reference's extension caps
+// k at 32, k_nearest_neighbor_kernel.cu:24,68); NaN distances are not modelled (the sweep never selects them).
 struct LaneHeap {  // element r of the heap lives in lane r
     float v;
     int i;
@@ -175,6 +175,53 @@ struct SeqPairs {
                 adjust_heap(first, 0, len, pv, pi);
             }
     }
+    __device__ void sort_heap(int first, int last) {  // std::__sort_heap
+        while (last - first > 1) {
+            --last;
+            const float lv = v[last];
+            const int li = i[last];
+            v[last] = v[first]; i[last] = i[first];
+            adjust_heap(first, 0, last - first, lv, li);
+        }
+    }
+    // std::sort(first, last) for at most 63 elements: __introsort_loop (threshold 16; its recursion on the right part as
+    // an explicit stack) then __final_insertion_sort.  k - 1 <= 16 never leaves the plain insertion sort.
+    __device__ void sort(int first, int last) {
+        if (first == last) return;
+        int lg = 0;
+        for (int t = last - first; t > 1; t >>= 1) ++lg;
+        int stack_first[12], stack_last[12], stack_depth[12], sp = 0;
+        stack_first[0] = first, stack_last[0] = last, stack_depth[0] = 2 * lg, sp = 1;
+        while (sp > 0) {
+            --sp;
+            int f = stack_first[sp], l = stack_last[sp], depth = stack_depth[sp];
+            while (l - f > 16) {
+                if (depth == 0) {  // std::__partial_sort(f, l, l)
+                    heap_select(f, l, l);
+                    sort_heap(f, l);
+                    break;
+                }
+                --depth;
+                const int cut = partition_pivot(f, l);
+                // the reference recurses into [cut, l) first and then loops on [f, cut); the two ranges are disjoint, so
+                // the order in which they are finished does not change the result
+                stack_first[sp] = cut, stack_last[sp] = l, stack_depth[sp] = depth, ++sp;
+                l = cut;
+            }
+        }
+        if (last - first > 16) {
+            insertion_sort(first, first + 16);
+            for (int p = first + 16; p != last; ++p) {  // __unguarded_insertion_sort
+                const float pv = v[p];
+                const int pi = i[p];
+                int pos = p, next = p - 1;
+                while (pv < v[next]) { v[pos] = v[next]; i[pos] = i[next]; pos = next; --next; }
+                v[pos] = pv; i[pos] = pi;
+            }
+        } else {
+            insertion_sort(first, last);
+        }
+    }
     __device__ void introselect(int first, int nth, int last, int depth_limit) {  // std::__introselect
         while (last - first > 3) {
             if (depth_limit == 0) {
@@ -267,14 +314,14 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
     for (int j = 0; j < QW; ++j) {
         const int qi = qbase + j;
         if (qi >= Q) continue;  // wave-uniform
-        if (exact_ties && k <= 17) {
+        if (exact_ties && k < RPE_WAVE) {
             // equal neighbours among the kk best (lane r against lane r + 1)?  Then redo this query as libstdc++ would.
             const float nxt = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Ld[j]), __float_as_int(Ld[j]), 0x130, 0xf, 0xf, false));  // wave_shl:1
             // exact_ties 1: only a tie ACROSS the boundary (k-th against (k+1)-th distance) can change WHICH neighbours are
             // returned; ties inside the top k change their order only and keep the sweep's index order.  3: any tie.
             unsigned long long dup = __ballot(lane + 1 < kk && Ld[j] == nxt);
             if (exact_ties == 1) dup &= 1ull << (k - 1);
-            if (dup && exact_ties != 2) {
+            if (dup) {
                 if (!SMALL || k * 64 <= M) {  // std::partial_sort: __heap_select over the row in index order, then __sort_heap
                     LaneHeap h;
                     h.v = INFINITY;
@@ -336,7 +383,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
                         int lg = 0;
                         for (int t = M; t > 1; t >>= 1) ++lg;
                         sp.introselect(0, k - 1, M, 2 * lg);
-                        sp.insertion_sort(0, k - 1);
+                        sp.sort(0, k - 1);
                     }
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
@@ -444,39 +491,44 @@ int pick_qw(int B, int Q) {
     return 1;
 }
 
-int g_knn_exact_ties = 3;  // indices equal the reference's position for position; 1: neighbour sets only (cheaper), 0: lowest index
-
 template <int D, int QW>
-void launch_knn(const KnnJobs &jobs, int njobs, int max_q, int min_m, int max_m, int B, int k, hipStream_t st) {
+int launch_knn(const KnnJobs &jobs, int njobs, int max_q, int min_m, int max_m, int B, int k, int ties, hipStream_t st) {
     const int per_block = kWavesPerBlock * QW;
     dim3 grid((max_q + per_block - 1) / per_block, B, njobs), block(kWavesPerBlock * RPE_WAVE);
     // k == 1 with M >= 64 is std::partial_sort with a one-element heap: the first minimum, which the lane-local kernel keeps
-    if (k == 1 && (min_m >= 64 || !g_knn_exact_ties)) {
+    if (k == 1 && (min_m >= 64 || !ties)) {
         hipLaunchKernelGGL((knn_nearest_kernel<D, QW>), grid, block, 0, st, jobs);
-    } else if (g_knn_exact_ties && min_m < 64 * k) {
+    } else if (ties && k < RPE_WAVE && min_m < 64 * k) {
         // some job is in topk's nth_element regime: every wave gets LDS room for one such row (values + indices)
         const int row = max_m < 64 * k ? max_m : 64 * k;  // only rows shorter than 64 k are ever copied
         const size_t lds = (size_t)kWavesPerBlock * 2 * row * sizeof(float);
-        hipLaunchKernelGGL((knn_select_kernel<D, QW, true>), grid, block, lds, st, jobs, k, g_knn_exact_ties, row);
+        if (lds > 160 * 1024) return RPE_EUNSUPPORTED;
+        if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit (k > 32 with a few thousand points)
+            hipError_t e = hipFuncSetAttribute((const void *)knn_select_kernel<D, QW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL((knn_select_kernel<D, QW, true>), grid, block, lds, st, jobs, k, ties, row);
     } else {
-        hipLaunchKernelGGL((knn_select_kernel<D, QW, false>), grid, block, 0, st, jobs, k, g_knn_exact_ties, 0);
+        hipLaunchKernelGGL((knn_select_kernel<D, QW, false>), grid, block, 0, st, jobs, k, ties, 0);
     }
+    return rpe_launch_status();
 }
 
 template <int D>
-void launch_knn_d(int qw, const KnnJobs &jobs, int njobs, int max_q, int min_m, int max_m, int B, int k, hipStream_t st) {
+int launch_knn_d(int qw, const KnnJobs &jobs, int njobs, int max_q, int min_m, int max_m, int B, int k, int ties, hipStream_t st) {
     switch (qw) {
-        case 1: launch_knn<D, 1>(jobs, njobs, max_q, min_m, max_m, B, k, st); break;
-        case 2: launch_knn<D, 2>(jobs, njobs, max_q, min_m, max_m, B, k, st); break;
-        case 4: launch_knn<D, 4>(jobs, njobs, max_q, min_m, max_m, B, k, st); break;
-        default: launch_knn<D, 8>(jobs, njobs, max_q, min_m, max_m, B, k, st); break;
+        case 1: return launch_knn<D, 1>(jobs, njobs, max_q, min_m, max_m, B, k, ties, st);
+        case 2: return launch_knn<D, 2>(jobs, njobs, max_q, min_m, max_m, B, k, ties, st);
+        case 4: return launch_knn<D, 4>(jobs, njobs, max_q, min_m, max_m, B, k, ties, st);
+        default: return launch_knn<D, 8>(jobs, njobs, max_q, min_m, max_m, B, k, ties, st);
     }
 }
 
 }  // namespace
 
-RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, rpe_stream_t stream) {
+RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, int tie_mode, rpe_stream_t stream) {
     if (!jobs || njobs < 1 || njobs > RPE_KNN_MAX_JOBS || B < 0 || D < 1 || D > 3 || k < 1) return RPE_EINVAL;
+    if (tie_mode != RPE_KNN_TIES_TORCH && tie_mode != RPE_KNN_TIES_SET && tie_mode != RPE_KNN_TIES_INDEX) return RPE_EINVAL;
     if (k > RPE_WAVE) return RPE_EUNSUPPORTED;
     if (B > 65535) return RPE_EUNSUPPORTED;
     KnnJobs packed;
@@ -494,24 +546,18 @@ RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int 
     if (B == 0 || max_q == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int qw = pick_qw(B, (int)total_q);
-    if (D == 3) launch_knn_d<3>(qw, packed, njobs, max_q, min_m, max_m, B, k, st);
-    else if (D == 2) launch_knn_d<2>(qw, packed, njobs, max_q, min_m, max_m, B, k, st);
-    else launch_knn_d<1>(qw, packed, njobs, max_q, min_m, max_m, B, k, st);
-    return rpe_launch_status();
-}
-
-RPE_API int rpe_debug_set_knn_exact_ties(int on) {
-    g_knn_exact_ties = on;  // 3: also reproduce the ORDER of equal distances inside the top k; 2 (timing): detect only
-    return 0;
+    if (D == 3) return launch_knn_d<3>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
+    if (D == 2) return launch_knn_d<2>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
+    return launch_knn_d<1>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
 }
 
 RPE_API int rpe_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,
-                    int64_t q_sn, int64_t q_sd, int B, int M, int Q, int D, int k, int64_t *idx, float *dist,
+                    int64_t q_sn, int64_t q_sd, int B, int M, int Q, int D, int k, int tie_mode, int64_t *idx, float *dist,
                     rpe_stream_t stream) {
     if (!input || !query || !idx || B < 0 || M <= 0 || Q < 0 || D < 1 || D > 3) return RPE_EINVAL;
     if (k < 1 || k > M) return RPE_EINVAL;
     const rpe_knn_job job{input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, M, Q, idx, dist};
-    return rpe_knn_multi(&job, 1, B, D, k, stream);
+    return rpe_knn_multi(&job, 1, B, D, k, tie_mode, stream);
 }
 
 RPE_API int rpe_squared_distance(const float *xyz1, int64_t a_sb, int64_t a_sn, int64_t a_sd, const float *xyz2,

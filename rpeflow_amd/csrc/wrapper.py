@@ -123,7 +123,15 @@ def furthest_point_sampling(xyz: torch.Tensor, n_samples: int, cpp_impl=True):
 
 
 def k_nearest_neighbor(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cpp_impl=True):
-    """models/csrc/wrapper.py:106-127.  Points as [B,N,D] or [B,D,N] (D<=3) -> int64 [B,Q,k]."""
+    """models/csrc/wrapper.py:106-127.  Points as [B,N,D] or [B,D,N] (D<=3) -> int64 [B,Q,k]; equal distances selected
+    and ordered exactly as the reference's matmul + torch.topk does on the CPU."""
+    return k_nearest_neighbor_ties(input_xyz, query_xyz, k, cpp_impl=cpp_impl, ties="torch")
+
+
+def k_nearest_neighbor_ties(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cpp_impl=True, ties="torch"):
+    """k_nearest_neighbor with the treatment of EQUAL distances chosen per call (no global state): "torch" -- as above;
+    "set" -- the reference's neighbour SET, equal distances inside it in index order (cheaper); "index" -- lowest index
+    first (RPE_KNN_TIES_* of include/rpeflow_hip.h)."""
     _as_points(input_xyz, "k_nearest_neighbor", "input_xyz")
     _as_points(query_xyz, "k_nearest_neighbor", "query_xyz")
     if input_xyz.shape[1] <= 3:  # channel_first to channel_last (a view; the kernel takes strides)
@@ -142,12 +150,12 @@ def k_nearest_neighbor(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int,
     idx = torch.empty((B, Q, k), dtype=torch.int64, device=input_xyz.device)
     with torch.cuda.device(input_xyz.device):
         rc = _lib.lib().rpe_knn(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(),
-                                B, M, Q, D, int(k), _ptr(idx), _NULL, _lib.stream_of(input_xyz))
+                                B, M, Q, D, int(k), _lib.KNN_TIES[ties], _ptr(idx), _NULL, _lib.stream_of(input_xyz))
     _lib.check(rc, "k_nearest_neighbor")
     return idx
 
 
-def k_nearest_neighbor_multi(pairs, k: int):
+def k_nearest_neighbor_multi(pairs, k: int, ties="torch"):
     """[(input_xyz, query_xyz), ...] with one batch size, dimension and k -> [idx, ...], each exactly
     k_nearest_neighbor(input_xyz, query_xyz, k), from ONE launch (at most 8 pairs)."""
     jobs, outs, keep = (_lib.KnnJob * len(pairs))(), [], []
@@ -170,12 +178,12 @@ def k_nearest_neighbor_multi(pairs, k: int):
         outs.append(idx)
         keep += [inp, qry]
     with torch.cuda.device(outs[0].device):
-        rc = _lib.lib().rpe_knn_multi(ctypes.byref(jobs), len(pairs), B, D, int(k), _lib.stream_of(outs[0]))
+        rc = _lib.lib().rpe_knn_multi(ctypes.byref(jobs), len(pairs), B, D, int(k), _lib.KNN_TIES[ties], _lib.stream_of(outs[0]))
     _lib.check(rc, "k_nearest_neighbor_multi")
     return outs
 
 
-def k_nearest_neighbor_with_distances(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int):
+def k_nearest_neighbor_with_distances(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, ties="torch"):
     """k_nearest_neighbor plus the sorted squared distances the kernel selected on
     (what ``squared_distance(query, input).topk(k, largest=False).values`` holds)."""
     if input_xyz.shape[1] <= 3:
@@ -187,7 +195,7 @@ def k_nearest_neighbor_with_distances(input_xyz: torch.Tensor, query_xyz: torch.
     dist = torch.empty((B, Q, k), dtype=torch.float32, device=input_xyz.device)
     with torch.cuda.device(input_xyz.device):
         rc = _lib.lib().rpe_knn(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(),
-                                B, M, Q, D, int(k), _ptr(idx), _ptr(dist), _lib.stream_of(input_xyz))
+                                B, M, Q, D, int(k), _lib.KNN_TIES[ties], _ptr(idx), _ptr(dist), _lib.stream_of(input_xyz))
     _lib.check(rc, "k_nearest_neighbor")
     return idx, dist
 

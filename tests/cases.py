@@ -16,6 +16,11 @@ KNN_CASES = {
     "knn2d_k1_pix_1x4096x240x144": ("pix", 1, 4096, (144, 240), 2, 1, 107),
     "knn3d_k32_unit_1x300x200": ("unit", 1, 300, 200, 3, 32, 108),
     "knn3d_k1_ids_1x70x130": ("ids", 1, 70, 130, 3, 1, 109),
+    # integer-lattice clouds: most distances tie; k = 32 is the reference extension's cap (k_nearest_neighbor_kernel.cu:24,68),
+    # where torch.topk's std::sort of the first k - 1 is an introsort; both topk regimes (k * 64 <= M or not)
+    "knn3d_k32_lattice_1x1500x160": ("lattice", 1, 1500, 160, 3, 32, 110),
+    "knn3d_k32_lattice_2x2500x120": ("lattice", 2, 2500, 120, 3, 32, 111),
+    "knn3d_k20_lattice_1x900x200": ("lattice", 1, 900, 200, 3, 20, 112),
 }
 
 
@@ -29,6 +34,9 @@ def knn_inputs(name):
     elif kind == "ids":
         inp = I.ids_cloud(r, B, M, D)
         qry = I.ids_cloud(r, B, Q, D)
+    elif kind == "lattice":
+        inp = r.integers(0, 7, (B, M, D)).astype(np.float32)
+        qry = r.integers(0, 7, (B, Q, D)).astype(np.float32)
     else:
         inp = I.unit_cloud(r, B, M, D)
         qry = I.unit_cloud(r, B, Q, D)

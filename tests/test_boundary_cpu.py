@@ -31,7 +31,7 @@ def test_library_builds_and_exports_header_symbols():
 
 def test_ctypes_prototypes_cover_the_header():
     assert set(_lib._PROTOTYPES) | {"rpe_error_string"} == set(declared_symbols())
-    assert _lib.lib().rpe_abi_version() == 1
+    assert _lib.lib().rpe_abi_version() == _lib.ABI_VERSION
     assert _lib.lib().rpe_error_string(-1).decode().startswith("rpeflow_hip")
 
 

@@ -21,15 +21,6 @@ from rpeflow_amd.csrc import wrapper as W  # noqa: E402
 DEV = "cuda:0"
 
 
-@pytest.fixture(autouse=True)
-def _knn_default_mode():
-    """Every test starts and ends in the library's default tie mode (3: the reference's indices position for position);
-    the tests that exercise the cheaper modes 1 (sets only) and 0 (lowest index) switch explicitly."""
-    _lib.lib().rpe_debug_set_knn_exact_ties(3)
-    yield
-    _lib.lib().rpe_debug_set_knn_exact_ties(3)
-
-
 def G(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
@@ -40,7 +31,7 @@ def dev(a):
 
 def test_library_is_loaded_from_tree():
     assert os.path.exists(_lib.LIB_PATH)
-    assert _lib.lib().rpe_abi_version() == 1
+    assert _lib.lib().rpe_abi_version() == _lib.ABI_VERSION
 
 
 def test_mfma_4x4x1_layout_probe():
@@ -71,9 +62,7 @@ def test_knn_golden_cases(golden_dir, name):
     idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
     default_idx = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
     assert np.array_equal(default_idx, idx)
-    _lib.lib().rpe_debug_set_knn_exact_ties(1)
-    sets_only = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
-    _lib.lib().rpe_debug_set_knn_exact_ties(3)
+    sets_only = W.k_nearest_neighbor_ties(dev(inp), dev(qry), k, ties="set").cpu().numpy()
     assert np.array_equal(np.sort(sets_only, -1), np.sort(idx, -1)), name + ": mode 1 returns another neighbour set"
     oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True)
     assert np.array_equal(idx, oi), f"{name}: {(idx != oi).sum()} indices differ from the oracle"
@@ -309,7 +298,11 @@ def test_knn_multi_equals_separate_calls():
 
 @pytest.mark.parametrize("B,M,Q,D,k", [(2, 700, 300, 3, 16), (1, 2048, 1024, 3, 16), (2, 130, 64, 3, 3), (1, 500, 777, 2, 3), (3, 40, 33, 3, 1),
                                        (1, 1500, 200, 3, 17), (2, 1023, 128, 3, 16), (2, 1024, 128, 3, 16), (1, 64, 64, 2, 1), (1, 63, 40, 2, 1),
-                                       (2, 300, 300, 3, 2), (1, 5000, 96, 3, 5)])
+                                       (2, 300, 300, 3, 2), (1, 5000, 96, 3, 5),
+                                       # k - 1 > 16: topk's std::sort is an introsort there; 32 is the reference extension's cap
+                                       # (k_nearest_neighbor_kernel.cu:24,68); both regimes (k * 64 <= M or not)
+                                       (2, 700, 200, 3, 32), (1, 2048, 300, 3, 32), (1, 3000, 100, 3, 24), (1, 1500, 64, 2, 20),
+                                       (1, 4000, 50, 3, 63), (1, 5000, 40, 3, 40), (1, 40, 40, 3, 40)])
 def test_knn_equal_distances_follow_torch_topk(B, M, Q, D, k):
     """Points on a coarse integer lattice: most distances tie.  Indices AND their order must be what the reference's
     matmul + torch.topk gives on the CPU, in both of topk's regimes (k * 64 <= M: partial_sort; else nth_element + sort)."""
@@ -324,14 +317,9 @@ def test_knn_equal_distances_follow_torch_topk(B, M, Q, D, k):
     assert np.array_equal(O.k_nearest_neighbor(inp, qry, k), ref_idx)      # the oracle's restatement of it
     got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()  # default: position for position, order of equal distances included
     assert np.array_equal(got, ref_idx), f"{(got != ref_idx).sum()} of {got.size} indices differ"
-    try:
-        _lib.lib().rpe_debug_set_knn_exact_ties(1)  # cheaper: the reference's neighbour SET, always
-        got = ops.k_nearest_neighbor(dev(inp), dev(qry), k).cpu().numpy()
-        assert np.array_equal(np.sort(got, -1), np.sort(ref_idx, -1)), "mode 1 returns another neighbour set"
-        # the plain lowest-index rule is still available and still a valid neighbour set
-        _lib.lib().rpe_debug_set_knn_exact_ties(0)
-        low, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k)
-        oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True, ties="index")
-        assert np.array_equal(low.cpu().numpy(), oi)
-    finally:
-        _lib.lib().rpe_debug_set_knn_exact_ties(3)
+    got = W.k_nearest_neighbor_ties(dev(inp), dev(qry), k, ties="set").cpu().numpy()  # cheaper: the reference's neighbour SET, always
+    assert np.array_equal(np.sort(got, -1), np.sort(ref_idx, -1)), "ties='set' returns another neighbour set"
+    # the plain lowest-index rule is still available and still a valid neighbour set
+    low, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k, ties="index")
+    oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True, ties="index")
+    assert np.array_equal(low.cpu().numpy(), oi)
