@@ -96,6 +96,14 @@ int rpe_squared_distance(const float *xyz1, int64_t a_sb, int64_t a_sn, int64_t 
  * No scratch buffer: running distances live in registers.  Limits: N <= 32768. */
 int rpe_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
             int B, int N, int S, int64_t *idx, rpe_stream_t stream);
+/* The same with the kernel chosen by the caller (identical indices either way; tests cross-check them):
+ * RPE_FPS_PLAIN recomputes every point per sample, RPE_FPS_PRUNED skips Morton clusters the new sample cannot reach
+ * (1024 < N <= 16384), RPE_FPS_AUTO = rpe_fps's choice (pruned for >= 2048 samples of >= 8192 points).        */
+#define RPE_FPS_AUTO 0
+#define RPE_FPS_PLAIN 1
+#define RPE_FPS_PRUNED 2
+int rpe_fps_algo(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
+                 int B, int N, int S, int64_t *idx, int algo, rpe_stream_t stream);
 
 /* ---- correlation2d forward ---------------------------------------------------
  * Replaces correlation_forward_kernel_wrapper(out, in1, in2, B, C, H, W, md)
@@ -315,13 +323,6 @@ int rpe_channel_affine_act(float *y, const float *scale, const float *shift, int
  * Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation
  * kernel relies on: out[64*4] = D for A[lane]=lane, B[lane]=100*lane (one K).   */
 int rpe_probe_mfma4x4(float *out256, rpe_stream_t stream);
-/* Selects the FPS kernel: -1 (default) = automatic: 7 for >= 2048 samples of >= 8192 points, else 3;
- * 3 = integer-pipe running distances + fused DPP reductions; 7 = Morton-sorted clusters skipped per wave, the skip test
- * folded into the post-barrier reduction, candidate coordinates published with the partials; 1 = DPP reductions +
- * packed fp32; 0 = shuffle-based first version; 2 = per-thread box skipping; 4/5/6 = wave-level skipping with the test
- * in front of the barrier, 1/2/4 clusters a wave (2, 4-7: 1024 < N <= 16384, else 3).  All give identical indices;
- * kept for A/B timing and cross-checks. */
-int rpe_debug_set_fps_variant(int variant);
 /* Writes the GPU's constant-rate clock (100 MHz wall_clock64) to *slot when the stream reaches this point: a
  * one-thread kernel, usable inside a captured HIP graph, for timelines of multi-stream replays that rocprofv3
  * serialises.                                                                                               */

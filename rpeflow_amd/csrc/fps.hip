@@ -3,9 +3,12 @@
 // Replaces furthest_point_sampling_kernel<1024> (furthest_point_sampling_kernel.cu:34-85:
 // running distances in a global scratch buffer, ~11 barriers per sample) with one
 // 1024-thread workgroup per cloud that keeps its points AND their running minimum
-// distances in registers (PPT points per thread), a copy of the coordinates in LDS
-// for the "look up the winner" step, wave butterflies for the argmax and ONE barrier
-// per sample (the per-wave partials are double-buffered by sample parity).
+// distances in registers (PPT points per thread) and needs ONE barrier per sample
+// (the per-wave partials are double-buffered by sample parity).  Two kernels:
+//   fps_kernel_int      every point recomputed per sample; integer-pipe running distances, fused DPP reductions
+//   fps_pruned2_kernel  Morton-sorted clusters, a wave whose box the new sample cannot reach skips its recompute
+//                       (exact: a skipped point provably keeps its distance); the default for long runs on big clouds
+// Both give identical indices (the GPU tests cross-check them against each other and the CPU restatement).
 //
 // Rules are the CPU fallback's (wrapper.py:83-96), not the CUDA kernel's: start at
 // index 0, nd = fl(fl(dx*dx + dy*dy) + dz*dz) with every square rounded, running
@@ -24,79 +27,6 @@ __device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi)
     v = take ? ov : v;
     i = take ? oi : i;
 }
-
-template <int PPT, bool LDS_XYZ>
-__global__ __launch_bounds__(kThreads) void fps_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
-                                                       int N, int S, int64_t *__restrict__ idx) {
-    extern __shared__ float lds[];
-    // layout: [2][kWaves] partial values | [2][kWaves] partial indices | x[N] y[N] z[N]
-    float *part_v = lds;
-    int *part_i = reinterpret_cast<int *>(lds + 2 * kWaves);
-    float *lx = lds + 4 * kWaves, *ly = lx + N, *lz = ly + N;
-
-    const int tid = threadIdx.x, lane = rpe_lane(), wave = tid >> 6;
-    const int b = blockIdx.x;
-    xyz += (int64_t)b * sb;
-    idx += (int64_t)b * S;
-
-    float px[PPT], py[PPT], pz[PPT], md[PPT];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int i = tid + j * kThreads;
-        const bool valid = i < N;
-        const float *a = xyz + (int64_t)(valid ? i : 0) * sn;
-        px[j] = a[0];
-        py[j] = a[sd];
-        pz[j] = a[2 * sd];
-        md[j] = valid ? 1e10f : -INFINITY;  // -inf: can never win the argmax, min() keeps it
-        if (LDS_XYZ && valid) {
-            lx[i] = px[j];
-            ly[i] = py[j];
-            lz[i] = pz[j];
-        }
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (int s = 0; s < S; ++s) {
-        if (tid == 0) idx[s] = (int64_t)cur;
-        if (s == S - 1) break;
-        float cx, cy, cz;
-        if (LDS_XYZ) {
-            cx = lx[cur]; cy = ly[cur]; cz = lz[cur];
-        } else {
-            const float *a = xyz + (int64_t)cur * sn;
-            cx = a[0]; cy = a[sd]; cz = a[2 * sd];
-        }
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
-            const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-            float nd = xx + yy;
-            nd = nd + zz;
-            md[j] = nd < md[j] ? nd : md[j];
-            const bool take = md[j] > bv;  // strict: first index wins inside a thread
-            bv = take ? md[j] : bv;
-            bi = take ? tid + j * kThreads : bi;
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) argmax_merge(bv, bi, __shfl_xor(bv, off), __shfl_xor(bi, off));
-        const int par = (s & 1) * kWaves;
-        if (lane == 0) {
-            part_v[par + wave] = bv;
-            part_i[par + wave] = bi;
-        }
-        __syncthreads();
-        float wv = part_v[par + (lane & (kWaves - 1))];
-        int wi = part_i[par + (lane & (kWaves - 1))];
-#pragma unroll
-        for (int off = kWaves / 2; off > 0; off >>= 1) argmax_merge(wv, wi, __shfl_xor(wv, off), __shfl_xor(wi, off));
-        cur = rpe_uniform(wi);
-    }
-}
-
 
 // ---- DPP reductions (gfx9 row_shr / row_bcast controls): ~8 cycles a step instead of a
 // ds_bpermute round trip per __shfl_xor.  After the six steps lane 63 holds the result;
@@ -139,90 +69,6 @@ __device__ __forceinline__ int wave_min(int v) {
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Same algorithm as fps_kernel; differences: packed fp32 arithmetic for the distance
-// (v_pk_add/v_pk_mul, each component rounded exactly as the scalar form), a two-phase
-// argmax (max of the values, then min of the indices holding it) on DPP, first-max rule
-// unchanged.
-template <int PPT, bool LDS_XYZ>
-__global__ __launch_bounds__(kThreads) void fps_kernel_dpp(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
-                                                           int N, int S, int64_t *__restrict__ idx) {
-    static_assert(PPT % 2 == 0, "packed path needs an even number of points per thread");
-    constexpr int H = PPT / 2;
-    extern __shared__ float lds[];
-    float *part_v = lds;
-    int *part_i = reinterpret_cast<int *>(lds + 2 * kWaves);
-    float *lx = lds + 4 * kWaves, *ly = lx + N, *lz = ly + N;
-
-    const int tid = threadIdx.x, lane = rpe_lane();
-    const int wave = rpe_uniform(tid >> 6);
-    const int b = blockIdx.x;
-    xyz += (int64_t)b * sb;
-    idx += (int64_t)b * S;
-
-    f32x2 px[H], py[H], pz[H], md[H];
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const int i = tid + j * kThreads;
-        const bool valid = i < N;
-        const float *a = xyz + (int64_t)(valid ? i : 0) * sn;
-        const float x = a[0], y = a[sd], z = a[2 * sd];
-        px[j >> 1][j & 1] = x;
-        py[j >> 1][j & 1] = y;
-        pz[j >> 1][j & 1] = z;
-        md[j >> 1][j & 1] = valid ? 1e10f : -INFINITY;
-        if (LDS_XYZ && valid) {
-            lx[i] = x;
-            ly[i] = y;
-            lz[i] = z;
-        }
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (int s = 0; s < S; ++s) {
-        if (tid == 0) idx[s] = (int64_t)cur;
-        if (s == S - 1) break;
-        float cx, cy, cz;
-        if (LDS_XYZ) {
-            cx = lx[cur]; cy = ly[cur]; cz = lz[cur];
-        } else {
-            const float *a = xyz + (int64_t)cur * sn;
-            cx = a[0]; cy = a[sd]; cz = a[2 * sd];
-        }
-        const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
-            const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
-            f32x2 nd = xx + yy;
-            nd = nd + zz;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float m = fminf(md[h][e], nd[e]);
-                md[h][e] = m;
-                const bool take = m > bv;  // strict: first index wins inside a thread
-                bv = take ? m : bv;
-                bi = take ? tid + (2 * h + e) * kThreads : bi;
-            }
-        }
-        const float wmax = wave_max(bv);
-        const int widx = wave_min(bv == wmax ? bi : 0x7fffffff);
-        const int par = (s & 1) * kWaves;
-        if (lane == 0) {
-            part_v[par + wave] = wmax;
-            part_i[par + wave] = widx;
-        }
-        __syncthreads();
-        const float pv = part_v[par + (lane & (kWaves - 1))];
-        const int pi = part_i[par + (lane & (kWaves - 1))];
-        const float bmax = rpe_readlane(row_max16(pv), 15);
-        cur = rpe_readlane(row_min16(pv == bmax ? pi : 0x7fffffff), 15);
-    }
-}
-
 
 // ---- variant 3: the same algorithm on the integer pipe, reductions as fused DPP instructions ----------------
 // Running distances are non-negative floats (sums of squares, 1e10 at the start), so their bit patterns order like
@@ -374,166 +220,6 @@ __device__ __forceinline__ float wave_minf(float v) {
     return rpe_readlane(v, 63);
 }
 
-template <int PPT>
-__global__ __launch_bounds__(kThreads) void fps_sorted_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
-                                                              int N, int S, int64_t *__restrict__ idx) {
-    constexpr int NP = PPT * kThreads;  // padded (power of two) element count
-    extern __shared__ unsigned long long sortbuf[];  // [NP] (key << 32 | index); reused for the slots afterwards
-    __shared__ float red[6][kWaves];
-    const int tid = threadIdx.x, lane = rpe_lane();
-    const int wave = rpe_uniform(tid >> 6);
-    const int b = blockIdx.x;
-    xyz += (int64_t)b * sb;
-    idx += (int64_t)b * S;
-
-    // ---- 1. bounding box of the cloud
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < N; i += kThreads) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float v = xyz[(int64_t)i * sn + d * sd];
-            lo[d] = fminf(lo[d], v);
-            hi[d] = fmaxf(hi[d], v);
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float l = wave_minf(lo[d]), h = wave_max(hi[d]);
-        if (lane == 0) { red[d][wave] = l; red[3 + d][wave] = h; }
-    }
-    __syncthreads();
-    float clo[3], scale;
-    {
-        float span = 0.f;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            float l = red[d][0], h = red[3 + d][0];
-            for (int w = 1; w < kWaves; ++w) { l = fminf(l, red[d][w]); h = fmaxf(h, red[3 + d][w]); }
-            clo[d] = l;
-            span = fmaxf(span, h - l);
-        }
-        scale = span > 0.f ? 1023.0f / span : 0.f;
-    }
-
-    // ---- 2. Morton keys + bitonic sort (ascending; padding sorts last)
-    for (int i = tid; i < NP; i += kThreads) {
-        unsigned long long e = ~0ull;
-        if (i < N) {
-            unsigned key = 0;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float v = xyz[(int64_t)i * sn + d * sd];
-                int q = (int)((v - clo[d]) * scale);
-                q = q < 0 ? 0 : (q > 1023 ? 1023 : q);  // NaN -> 0
-                key |= spread10((unsigned)q) << d;
-            }
-            e = ((unsigned long long)key << 32) | (unsigned)i;
-        }
-        sortbuf[i] = e;
-    }
-    __syncthreads();
-    for (int k = 2; k <= NP; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int p = tid; p < NP / 2; p += kThreads) {
-                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
-                const unsigned long long a = sortbuf[i], c = sortbuf[l];
-                const bool up = (i & k) == 0;
-                if ((a > c) == up) { sortbuf[i] = c; sortbuf[l] = a; }
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- 3. this thread's points: PPT consecutive sorted positions
-    float px[PPT], py[PPT], pz[PPT], md[PPT];
-    int oi[PPT];
-    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const unsigned o = (unsigned)(sortbuf[tid * PPT + j] & 0xffffffffu);
-        const bool valid = o != 0xffffffffu;
-        oi[j] = valid ? (int)o : 0x7fffffff;
-        const float *a = xyz + (int64_t)(valid ? o : 0) * sn;
-        px[j] = a[0]; py[j] = a[sd]; pz[j] = a[2 * sd];
-        md[j] = valid ? 1e10f : -INFINITY;
-        if (valid) {
-            blo[0] = fminf(blo[0], px[j]); bhi[0] = fmaxf(bhi[0], px[j]);
-            blo[1] = fminf(blo[1], py[j]); bhi[1] = fmaxf(bhi[1], py[j]);
-            blo[2] = fminf(blo[2], pz[j]); bhi[2] = fmaxf(bhi[2], pz[j]);
-        }
-    }
-    __syncthreads();  // everyone has read its sorted entries: the buffer is free for the slots
-    float *slot = reinterpret_cast<float *>(sortbuf);  // [2 parities][5 fields][kWaves]
-
-    // thread candidate: (largest running distance, lowest original index among equals, its coordinates)
-    float tv = -INFINITY, tx = 0.f, ty = 0.f, tz = 0.f;
-    int ti = 0x7fffffff;
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const bool better = (md[j] > tv) || (md[j] == tv && oi[j] < ti);
-        tv = better ? md[j] : tv; ti = better ? oi[j] : ti;
-        tx = better ? px[j] : tx; ty = better ? py[j] : ty; tz = better ? pz[j] : tz;
-    }
-    // wave candidate, wave-uniform (SGPRs)
-    float wv = -INFINITY, wx = 0.f, wy = 0.f, wz = 0.f;
-    int wi = 0x7fffffff;
-    bool wave_dirty = true;
-
-    int cur = 0;
-    float cx = rpe_uniform(xyz[0]), cy = rpe_uniform(xyz[sd]), cz = rpe_uniform(xyz[2 * sd]);
-    for (int s = 0; s < S; ++s) {
-        if (tid == 0) idx[s] = (int64_t)cur;
-        if (s == S - 1) break;
-        // lower bound of the squared distance from the sample to this thread's box
-        const float ex = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.f);
-        const float ey = fmaxf(fmaxf(blo[1] - cy, cy - bhi[1]), 0.f);
-        const float ez = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.f);
-        const float bound = (ex * ex + ey * ey + ez * ez) * 0.9999f;
-        const bool need = bound < tv;  // false for empty threads (tv = -inf) and NaN bounds
-        if (need) {
-            tv = -INFINITY; ti = 0x7fffffff;
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
-                const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-                float nd = xx + yy;
-                nd = nd + zz;
-                const float m = fminf(md[j], nd);
-                md[j] = m;
-                const bool better = (m > tv) || (m == tv && oi[j] < ti);
-                tv = better ? m : tv; ti = better ? oi[j] : ti;
-                tx = better ? px[j] : tx; ty = better ? py[j] : ty; tz = better ? pz[j] : tz;
-            }
-        }
-        if (wave_dirty || __ballot(need) != 0ull) {  // wave-uniform
-            wv = wave_max(tv);
-            wi = wave_min(tv == wv ? ti : 0x7fffffff);
-            const unsigned long long owner = __ballot(tv == wv && ti == wi);
-            const int ol = owner ? __builtin_ctzll(owner) : 0;
-            wx = rpe_readlane(tx, ol); wy = rpe_readlane(ty, ol); wz = rpe_readlane(tz, ol);
-            wave_dirty = false;
-        }
-        float *sl = slot + (s & 1) * (5 * kWaves);
-        if (lane == 0) {
-            sl[0 * kWaves + wave] = wv;
-            sl[1 * kWaves + wave] = __int_as_float(wi);
-            sl[2 * kWaves + wave] = wx;
-            sl[3 * kWaves + wave] = wy;
-            sl[4 * kWaves + wave] = wz;
-        }
-        __syncthreads();
-        const int l16 = lane & (kWaves - 1);
-        const float pv = sl[0 * kWaves + l16];
-        const int pi = __float_as_int(sl[1 * kWaves + l16]);
-        const float qx = sl[2 * kWaves + l16], qy = sl[3 * kWaves + l16], qz = sl[4 * kWaves + l16];
-        const float bmax = rpe_readlane(row_max16(pv), 15);
-        cur = rpe_readlane(row_min16(pv == bmax ? pi : 0x7fffffff), 15);
-        const unsigned long long win = __ballot(pv == bmax && pi == cur);
-        const int wl = win ? __builtin_ctzll(win) : 0;
-        cx = rpe_readlane(qx, wl); cy = rpe_readlane(qy, wl); cz = rpe_readlane(qz, wl);
-    }
-}
-
 // 0: shuffle-based fps_kernel, 1: DPP + packed math, 2: sorted + exact skipping (1024 < N <= 16384).
 // Measured on MI355X (8192 -> 4096): 1.68 / 1.19 / 1.32 us per sample.  Variant 2 removes ~95 % of the
 // distance arithmetic but not the per-sample latency chain (candidate update -> wave reduce -> LDS ->
@@ -561,210 +247,6 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 #ifdef RPE_FPS_STATS
 __device__ unsigned long long g_fps_stats[4];
 #endif
-template <int PPT, int NCL>
-__global__ __launch_bounds__(kThreads) void fps_pruned_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
-                                                              int N, int S, int64_t *__restrict__ idx) {
-    static_assert(PPT % NCL == 0 && (PPT / NCL) % 2 == 0, "a cluster is a whole number of packed row pairs");
-    constexpr int NP = PPT * kThreads;  // padded (power of two) element count
-    constexpr int RPC = PPT / NCL;      // rows per cluster
-    constexpr int H = PPT / 2;
-    // LDS: the sort buffer [NP] u64 first; afterwards the same bytes hold x[N] y[N] z[N] by original index
-    extern __shared__ unsigned long long sortbuf[];
-    __shared__ float red[6][kWaves];
-    __shared__ int part_v[2 * kWaves], part_i[2 * kWaves];
-    const int tid = threadIdx.x, lane = rpe_lane();
-    const int wave = rpe_uniform(tid >> 6);
-    const int b = blockIdx.x;
-    xyz += (int64_t)b * sb;
-    idx += (int64_t)b * S;
-
-    // ---- 1. bounding box of the cloud
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < N; i += kThreads) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float v = xyz[(int64_t)i * sn + d * sd];
-            lo[d] = fminf(lo[d], v);
-            hi[d] = fmaxf(hi[d], v);
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float l = wave_minf(lo[d]), h = wave_max(hi[d]);
-        if (lane == 0) { red[d][wave] = l; red[3 + d][wave] = h; }
-    }
-    __syncthreads();
-    float clo[3], scale[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        float l = red[d][0], h = red[3 + d][0];
-        for (int w = 1; w < kWaves; ++w) { l = fminf(l, red[d][w]); h = fmaxf(h, red[3 + d][w]); }
-        clo[d] = l;
-        scale[d] = h > l ? 1023.0f / (h - l) : 0.f;  // per-axis: clusters come out as boxes of similar proportions as the cloud
-    }
-
-    // ---- 2. Morton keys + bitonic sort (ascending; padding sorts last)
-    for (int i = tid; i < NP; i += kThreads) {
-        unsigned long long e = ~0ull;
-        if (i < N) {
-            unsigned key = 0;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float v = xyz[(int64_t)i * sn + d * sd];
-                int q = (int)((v - clo[d]) * scale[d]);
-                q = q < 0 ? 0 : (q > 1023 ? 1023 : q);  // NaN -> 0
-                key |= spread10((unsigned)q) << d;
-            }
-            e = ((unsigned long long)key << 32) | (unsigned)i;
-        }
-        sortbuf[i] = e;
-    }
-    __syncthreads();
-    for (int k = 2; k <= NP; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int p = tid; p < NP / 2; p += kThreads) {
-                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
-                const unsigned long long a = sortbuf[i], c = sortbuf[l];
-                const bool up = (i & k) == 0;
-                if ((a > c) == up) { sortbuf[i] = c; sortbuf[l] = a; }
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- 3. this thread's points: row j of wave w = sorted positions w*64*PPT + j*64 + lane
-    f32x2 px[H], py[H], pz[H];
-    int md[PPT], oi[PPT];
-    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};  // lane c < NCL: box of cluster c
-#pragma unroll
-    for (int c = 0; c < NCL; ++c) {
-        float l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-        for (int r = 0; r < RPC; ++r) {
-            const int j = c * RPC + r;
-            const unsigned o = (unsigned)(sortbuf[wave * (RPE_WAVE * PPT) + j * RPE_WAVE + lane] & 0xffffffffu);
-            const bool valid = o != 0xffffffffu;
-            oi[j] = valid ? (int)o : 0x7fffffff;
-            const float *a = xyz + (int64_t)(valid ? o : 0) * sn;
-            const float x = a[0], y = a[sd], z = a[2 * sd];
-            px[j >> 1][j & 1] = x;
-            py[j >> 1][j & 1] = y;
-            pz[j >> 1][j & 1] = z;
-            md[j] = valid ? __float_as_int(1e10f) : -1;
-            if (valid) {
-                l3[0] = fminf(l3[0], x); h3[0] = fmaxf(h3[0], x);
-                l3[1] = fminf(l3[1], y); h3[1] = fmaxf(h3[1], y);
-                l3[2] = fminf(l3[2], z); h3[2] = fmaxf(h3[2], z);
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float l = wave_minf(l3[d]), h = wave_max(h3[d]);
-            if (lane == c) { blo[d] = l; bhi[d] = h; }
-        }
-    }
-    __syncthreads();  // everyone has read its sorted entries: the buffer becomes the coordinate table
-    float *lx = reinterpret_cast<float *>(sortbuf), *ly = lx + N, *lz = ly + N;
-    for (int i = tid; i < N; i += kThreads) {
-        lx[i] = xyz[(int64_t)i * sn];
-        ly[i] = xyz[(int64_t)i * sn + sd];
-        lz[i] = xyz[(int64_t)i * sn + 2 * sd];
-    }
-    __syncthreads();
-
-    int cmax[NCL];      // wave-uniform: largest running distance (bits) per cluster; -1 for an empty cluster
-    int cmaxv = -1;     // lane c < NCL: cmax[c] (for the lane-parallel skip test)
-#pragma unroll
-    for (int c = 0; c < NCL; ++c) {
-        int t = -1;
-#pragma unroll
-        for (int r = 0; r < RPC; ++r) t = max(t, md[c * RPC + r]);
-        cmax[c] = wave_max_i32(t);
-        cmaxv = lane == c ? cmax[c] : cmaxv;
-    }
-    int wmax = -1, widx = 0x7fffffff;  // the wave's candidate: value bits, lowest original index holding it
-    bool fresh = true;                 // candidate must be (re)derived
-
-    int cur = 0;
-    for (int s = 0; s < S; ++s) {
-        if (tid == 0) idx[s] = (int64_t)cur;
-        if (s == S - 1) break;
-        const float cx = lx[cur], cy = ly[cur], cz = lz[cur];
-        // lane c: lower bound of the squared distance from the sample to box c, shrunk by 1e-5
-        const float ex = fmaxf(fmaxf(blo[0] - cx, cx - bhi[0]), 0.f), ey = fmaxf(fmaxf(blo[1] - cy, cy - bhi[1]), 0.f),
-                    ez = fmaxf(fmaxf(blo[2] - cz, cz - bhi[2]), 0.f);
-        const float lb = ((ex * ex + ey * ey) + ez * ez) * 0.99999f;
-        const unsigned need = (unsigned)__builtin_amdgcn_ballot_w64(__float_as_int(lb) <= cmaxv) & ((1u << NCL) - 1u);
-        if (need) {
-            const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
-#pragma unroll
-            for (int c = 0; c < NCL; ++c) {
-                if (!((need >> c) & 1u)) continue;  // wave-uniform
-#ifdef RPE_FPS_STATS
-                if (lane == 0) atomicAdd(&g_fps_stats[0], 1ull);
-#endif
-                int t = -1;
-#pragma unroll
-                for (int h = c * RPC / 2; h < (c + 1) * RPC / 2; ++h) {
-                    const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
-                    const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
-                    f32x2 nd = xx + yy;
-                    nd = nd + zz;
-                    md[2 * h] = min(md[2 * h], __float_as_int(nd[0]));
-                    md[2 * h + 1] = min(md[2 * h + 1], __float_as_int(nd[1]));
-                    t = max(t, max(md[2 * h], md[2 * h + 1]));
-                }
-                cmax[c] = wave_max_i32(t);
-                cmaxv = lane == c ? cmax[c] : cmaxv;
-            }
-            fresh = true;
-        }
-        if (fresh) {  // wave-uniform: derive (wmax, widx) from the clusters' maxima
-            fresh = false;
-            wmax = cmax[0];
-#pragma unroll
-            for (int c = 1; c < NCL; ++c) wmax = max(wmax, cmax[c]);
-            unsigned long long m[PPT];
-            int holders = 0;
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) {
-                m[j] = __builtin_amdgcn_ballot_w64(md[j] == wmax);
-                holders += (int)__builtin_popcountll(m[j]);
-            }
-            if (holders == 1) {
-                widx = 0x7fffffff;
-#pragma unroll
-                for (int j = 0; j < PPT; ++j)
-                    if (m[j]) widx = __builtin_amdgcn_readlane(oi[j], (int)__builtin_ctzll(m[j]));
-            } else {  // several points share the maximum (the start, duplicates): lowest original index
-                int v = 0x7fffffff;
-#pragma unroll
-                for (int j = 0; j < PPT; ++j) v = md[j] == wmax ? min(v, oi[j]) : v;
-                widx = wave_min_i32(v);
-            }
-        }
-        const int par = (s & 1) * kWaves;
-        if (lane == 0) {
-            part_v[par + wave] = wmax;
-            part_i[par + wave] = widx;
-        }
-        __syncthreads();
-        const int pv = part_v[par + (lane & (kWaves - 1))];
-        const int pi = part_i[par + (lane & (kWaves - 1))];
-        int bmax;
-        {
-            int r = row_max16_i32(pv);
-            asm volatile("s_nop 1\n\tv_readlane_b32 %0, %1, 15" : "=s"(bmax) : "v"(r));
-        }
-        unsigned long long tied = __builtin_amdgcn_ballot_w64(pv == bmax) & 0xffffull;
-        cur = 0x7fffffff;
-        do {
-            cur = min(cur, __builtin_amdgcn_readlane(pi, (int)__builtin_ctzll(tied)));
-            tied &= tied - 1;
-        } while (tied);
-    }
-}
-
 // ---- variant 7: wave-level skipping with the skip test folded into the post-barrier reduction ----------------
 // As variant 4 (one Morton cluster per wave), but (a) every wave publishes its candidate's COORDINATES with its
 // partial, so the winner's coordinates are three v_readlane away instead of an LDS lookup, and (b) the skip test is
@@ -969,32 +451,13 @@ int launch_fps_pruned2(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int
     return rpe_launch_status();
 }
 
-template <int PPT, int NCL>
-int launch_fps_pruned(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, hipStream_t st) {
-    const size_t sort_bytes = sizeof(unsigned long long) * (size_t)PPT * kThreads, table_bytes = sizeof(float) * 3 * (size_t)N;
-    const size_t shmem = sort_bytes > table_bytes ? sort_bytes : table_bytes;
-    auto kern = fps_pruned_kernel<PPT, NCL>;
-    if (shmem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), shmem, st, xyz, sb, sn, sd, N, S, idx);
-    return rpe_launch_status();
-}
-
-int g_fps_variant = -1;  // -1 auto (7 for long runs on big clouds, else 3); 0 shuffle, 1 DPP + packed math, 2 Morton-sorted per-thread skipping, 3 integer pipe + fused DPP, 4-6 wave-level cluster skipping, 7 skip test folded into the reduction
-
 template <int PPT>
-int launch_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, hipStream_t st) {
+int launch_fps_plain(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, hipStream_t st) {
     const size_t small = sizeof(float) * 4 * kWaves;
     const size_t full = small + sizeof(float) * 3 * (size_t)N;
     const bool use_lds = full <= 150 * 1024;
     const size_t shmem = use_lds ? full : small;
-    auto kern = use_lds ? fps_kernel<PPT, true> : fps_kernel<PPT, false>;
-    if constexpr (PPT % 2 == 0) {
-        if (g_fps_variant >= 1 || g_fps_variant == -1) kern = use_lds ? fps_kernel_dpp<PPT, true> : fps_kernel_dpp<PPT, false>;
-        if (g_fps_variant >= 3 || g_fps_variant == -1) kern = use_lds ? fps_kernel_int<PPT, true> : fps_kernel_int<PPT, false>;
-    }
+    auto kern = use_lds ? fps_kernel_int<PPT, true> : fps_kernel_int<PPT, false>;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return (int)e;
@@ -1005,69 +468,30 @@ int launch_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int 
 
 }  // namespace
 
-template <int PPT>
-int launch_fps_sorted(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, hipStream_t st) {
-    const size_t shmem = sizeof(unsigned long long) * (size_t)PPT * kThreads;
-    auto kern = fps_sorted_kernel<PPT>;
-    if (shmem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(kern, dim3(B), dim3(kThreads), shmem, st, xyz, sb, sn, sd, N, S, idx);
-    return rpe_launch_status();
-}
-
-#ifdef RPE_FPS_STATS
-extern "C" __attribute__((visibility("default"))) unsigned long long rpe_debug_fps_stats(int reset) {
-    unsigned long long h[4] = {0, 0, 0, 0};
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fps_stats), sizeof(h));
-    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_fps_stats), z, sizeof(z)); }
-    return h[0];
-}
-#endif
-RPE_API int rpe_debug_set_fps_variant(int variant) {
-    if (variant < -1 || variant > 7) return RPE_EINVAL;
-    g_fps_variant = variant;
-    return 0;
-}
-
-RPE_API int rpe_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx,
-                    rpe_stream_t stream) {
+RPE_API int rpe_fps_algo(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, int algo,
+                         rpe_stream_t stream) {
     if (!xyz || !idx || B < 0 || N <= 0 || S < 0 || S > N) return RPE_EINVAL;
+    if (algo != RPE_FPS_AUTO && algo != RPE_FPS_PLAIN && algo != RPE_FPS_PRUNED) return RPE_EINVAL;
     if (B == 0 || S == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int ppt = (N + kThreads - 1) / kThreads;
-    if (g_fps_variant == 2 && N > kThreads && N <= 16 * kThreads) {
-        if (ppt <= 2) return launch_fps_sorted<2>(xyz, sb, sn, sd, B, N, S, idx, st);
-        if (ppt <= 4) return launch_fps_sorted<4>(xyz, sb, sn, sd, B, N, S, idx, st);
-        if (ppt <= 8) return launch_fps_sorted<8>(xyz, sb, sn, sd, B, N, S, idx, st);
-        return launch_fps_sorted<16>(xyz, sb, sn, sd, B, N, S, idx, st);
-    }
-    // auto: the Morton sort of variant 7 costs ~100 us per launch; it pays from a few thousand samples on
-    const bool auto7 = g_fps_variant == -1 && N >= 8 * kThreads && S >= 2048;
-    if ((g_fps_variant == 7 || auto7) && N > kThreads && N <= 16 * kThreads) {
+    const bool can_prune = N > kThreads && N <= 16 * kThreads;
+    if (algo == RPE_FPS_PRUNED && !can_prune) return RPE_EUNSUPPORTED;
+    // auto: the Morton sort of the pruned kernel costs ~100 us per launch; it pays from a few thousand samples on
+    if (algo == RPE_FPS_PRUNED || (algo == RPE_FPS_AUTO && can_prune && N >= 8 * kThreads && S >= 2048)) {
         if (ppt <= 2) return launch_fps_pruned2<2>(xyz, sb, sn, sd, B, N, S, idx, st);
         if (ppt <= 4) return launch_fps_pruned2<4>(xyz, sb, sn, sd, B, N, S, idx, st);
         if (ppt <= 8) return launch_fps_pruned2<8>(xyz, sb, sn, sd, B, N, S, idx, st);
         return launch_fps_pruned2<16>(xyz, sb, sn, sd, B, N, S, idx, st);
     }
-    if (g_fps_variant >= 4 && N > kThreads && N <= 16 * kThreads) {  // 4/5/6: pruned, 1/2/4 clusters per wave
-#define RPE_PRUNED(P)                                                                                          \
-    return g_fps_variant == 4   ? launch_fps_pruned<P, 1>(xyz, sb, sn, sd, B, N, S, idx, st)                   \
-           : g_fps_variant == 5 ? launch_fps_pruned<P, (P >= 4 ? 2 : 1)>(xyz, sb, sn, sd, B, N, S, idx, st)    \
-                                : launch_fps_pruned<P, (P >= 8 ? 4 : P >= 4 ? 2 : 1)>(xyz, sb, sn, sd, B, N, S, idx, st)
-        if (ppt <= 2) RPE_PRUNED(2);
-        if (ppt <= 4) RPE_PRUNED(4);
-        if (ppt <= 8) RPE_PRUNED(8);
-        RPE_PRUNED(16);
-#undef RPE_PRUNED
-    }
-    if (ppt <= 1) return launch_fps<1>(xyz, sb, sn, sd, B, N, S, idx, st);
-    if (ppt <= 2) return launch_fps<2>(xyz, sb, sn, sd, B, N, S, idx, st);
-    if (ppt <= 4) return launch_fps<4>(xyz, sb, sn, sd, B, N, S, idx, st);
-    if (ppt <= 8) return launch_fps<8>(xyz, sb, sn, sd, B, N, S, idx, st);
-    if (ppt <= 16) return launch_fps<16>(xyz, sb, sn, sd, B, N, S, idx, st);
-    if (ppt <= 32) return launch_fps<32>(xyz, sb, sn, sd, B, N, S, idx, st);
+    if (ppt <= 2) return launch_fps_plain<2>(xyz, sb, sn, sd, B, N, S, idx, st);
+    if (ppt <= 4) return launch_fps_plain<4>(xyz, sb, sn, sd, B, N, S, idx, st);
+    if (ppt <= 8) return launch_fps_plain<8>(xyz, sb, sn, sd, B, N, S, idx, st);
+    if (ppt <= 16) return launch_fps_plain<16>(xyz, sb, sn, sd, B, N, S, idx, st);
+    if (ppt <= 32) return launch_fps_plain<32>(xyz, sb, sn, sd, B, N, S, idx, st);
     return RPE_EUNSUPPORTED;
+}
+
+RPE_API int rpe_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, rpe_stream_t stream) {
+    return rpe_fps_algo(xyz, sb, sn, sd, B, N, S, idx, RPE_FPS_AUTO, stream);
 }

@@ -141,20 +141,31 @@ def test_fps_golden_cases(golden_dir, name):
     assert np.array_equal(got, G(golden_dir, name)["idx"]), name + " vs reference golden"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
-def test_fps_both_kernel_variants_agree(golden_dir, variant):
-    """The first (shuffle) kernel and the DPP/packed-math kernel give identical samples."""
-    try:
-        _lib.check(_lib.lib().rpe_debug_set_fps_variant(variant), "set variant")
-        for name in K.FPS_CASES:
-            xyz, S = K.fps_inputs(name)
-            got = ops.furthest_point_sampling(dev(xyz), S).cpu().numpy()
-            assert np.array_equal(got, G(golden_dir, name)["idx"]), (name, variant)
-        xyz = I.ids_cloud(I.rng(8300), 2, 5000)  # N not a multiple of 1024: padded lanes must never win
-        got = ops.furthest_point_sampling(dev(xyz), 4999).cpu().numpy()
-        assert np.array_equal(got, O.furthest_point_sampling(xyz, 4999))
-    finally:
-        _lib.lib().rpe_debug_set_fps_variant(-1)
+def _fps_algo(xyz, S, algo):
+    """rpe_fps_algo with the kernel chosen explicitly (1 plain, 2 pruned)."""
+    t = dev(xyz)
+    idx = torch.empty((t.shape[0], S), dtype=torch.int64, device=DEV)
+    rc = _lib.lib().rpe_fps_algo(t.data_ptr(), *t.stride(), t.shape[0], t.shape[1], S, idx.data_ptr(), algo, None)
+    if rc == -2:
+        return None  # RPE_EUNSUPPORTED: the pruned kernel needs 1024 < N <= 16384
+    _lib.check(rc, "rpe_fps_algo")
+    torch.cuda.synchronize()
+    return idx.cpu().numpy()
+
+
+@pytest.mark.parametrize("algo", [1, 2])
+def test_fps_both_kernels_agree(golden_dir, algo):
+    """The plain kernel and the cluster-skipping kernel give identical samples, whichever one rpe_fps would pick."""
+    for name in K.FPS_CASES:
+        xyz, S = K.fps_inputs(name)
+        got = _fps_algo(xyz, S, algo)
+        if got is not None:
+            assert np.array_equal(got, G(golden_dir, name)["idx"]), (name, algo)
+    xyz = I.ids_cloud(I.rng(8300), 2, 5000)  # N not a multiple of 1024: padded lanes must never win
+    assert np.array_equal(_fps_algo(xyz, 4999, algo), O.furthest_point_sampling(xyz, 4999))
+    xyz = I.ids_cloud(I.rng(8301), 1, 700)   # N <= 1024: plain only
+    got = _fps_algo(xyz, 300, algo)
+    assert (got is None) if algo == 2 else np.array_equal(got, O.furthest_point_sampling(xyz, 300))
 
 
 @pytest.mark.parametrize("B,N,S", [(1, 2, 1), (2, 65, 64), (3, 1023, 100), (1, 1025, 1024), (2, 3000, 700), (1, 9000, 50), (1, 20000, 40)])

@@ -52,11 +52,11 @@ def main():
         for (B, N, S) in [(8, 8192, 4096), (2, 8192, 4096), (8, 4096, 1024)]:
             p = (torch.rand(B, 3, N, device=dev) * 30).transpose(1, 2)
             from rpeflow_amd import _lib
-            for variant in (3, 4, 7):
-                _lib.lib().rpe_debug_set_fps_variant(variant)
-                us = timeit(lambda: ops.furthest_point_sampling(p, S), warmup=1, iters=3)
-                print(f"fps variant={variant} B={B} N={N} S={S}: {us:9.1f} us  {us / S:6.3f} us/sample")
-            _lib.lib().rpe_debug_set_fps_variant(-1)
+            idx = torch.empty((B, S), dtype=torch.int64, device=dev)
+            for algo, name in ((1, "plain"), (2, "pruned")):
+                us = timeit(lambda: _lib.check(_lib.lib().rpe_fps_algo(p.data_ptr(), *p.stride(), B, N, S, idx.data_ptr(), algo, None), "fps"),
+                            warmup=1, iters=3)
+                print(f"fps {name} B={B} N={N} S={S}: {us:9.1f} us  {us / S:6.3f} us/sample")
     if "restormer" in which:
         from rpeflow_amd.restormer_ops import channel_layernorm, dwconv3
         for (B, C, H, Wd) in [(4, 96, 144, 240), (4, 81, 144, 240), (4, 32, 144, 240), (4, 96, 72, 120), (4, 64, 1, 4096)]:
