@@ -29,6 +29,32 @@ __device__ __forceinline__ void load_point(const float *base, int64_t sn, int64_
     p[2] = D > 2 ? a[2 * sd] : 0.f;
 }
 
+// The sweeps read the cloud 64 points at a time; the loads of tile t + 2 are issued before tile t is used, so the L2
+// round trip (~700 cycles) hides behind two tiles of arithmetic instead of stalling every iteration (a wave has only
+// one or two partners on its SIMD at these grid sizes).
+template <int D>
+struct TileStream {
+    const float *inp;
+    int64_t sn, sd;
+    int M, lane;
+    float a[3], b[3];  // tiles t + 1 and t + 2
+    __device__ __forceinline__ void fetch(int base, float (&p)[3]) const {
+        const int pi = base + lane;
+        p[0] = p[1] = p[2] = 0.f;
+        if (pi < M) load_point<D>(inp, sn, sd, pi, p);
+    }
+    __device__ __forceinline__ void start() {
+        fetch(0, a);
+        fetch(RPE_WAVE, b);
+    }
+    // the points of tile `base` (zeros past the end), and the request for tile base + 128
+    __device__ __forceinline__ void next(int base, float (&p)[3]) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { p[d] = a[d]; a[d] = b[d]; }
+        fetch(base + 2 * RPE_WAVE, b);
+    }
+};
+
 template <int D, int QW>
 struct Queries {
     float qm2[QW][3];
@@ -278,11 +304,51 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
     // keep one entry more than asked for: it shows whether anything outside the top k ties with the k-th distance
     const int kk = (exact_ties && k < M && k < RPE_WAVE) ? k + 1 : k;
 
+    // ---- pass 1: an upper bound for the kk-th smallest distance, so that the sweep below inserts ~kk candidates instead of
+    // ~kk (1 + ln(M / kk)).  Every lane keeps the minimum over the points IT sees (one per tile): 64 distances of 64
+    // distinct points, whose kk-th smallest therefore bounds the kk-th smallest of all M from above -- and, the best
+    // few points mostly falling into different lanes, is about the (1.2 kk)-th smallest overall.  Points beyond the bound
+    // cannot be among the kk best and never enter the serial insertion; equal to the bound they still compete (index order).
+    if (M > 2 * RPE_WAVE) {
+        float lm[QW];
+#pragma unroll
+        for (int j = 0; j < QW; ++j) lm[j] = INFINITY;
+        TileStream<D> ts{inp, in_sn, in_sd, M, lane};
+        ts.start();
+        for (int base = 0; base < M; base += RPE_WAVE) {
+            const bool valid = base + lane < M;
+            float p[3];
+            ts.next(base, p);
+            const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;
+#pragma unroll
+            for (int j = 0; j < QW; ++j) {
+                const float d = rpe_pair_dist<D>(qs.qm2[j], qs.qq[j], p, pp);
+                lm[j] = d < lm[j] ? d : lm[j];  // (a NaN distance never lowers the minimum: the bound stays valid)
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+            int below = 0;  // how many of the 64 lane minima are strictly smaller than this lane's
+#pragma unroll 16
+            for (int l = 0; l < RPE_WAVE; ++l) below += rpe_readlane(lm[j], l) < lm[j] ? 1 : 0;
+            float bound = below < kk ? lm[j] : -INFINITY;  // the kk-th smallest = the largest value with fewer than kk below it
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) bound = fmaxf(bound, __shfl_xor(bound, off));
+            // strict comparisons below: step to the next float up so that d == bound still passes
+            const int bits = __float_as_int(bound);
+            tau[j] = !(bound < INFINITY) ? INFINITY : bound == 0.f ? __int_as_float(1) : bound > 0.f ? __int_as_float(bits + 1) : __int_as_float(bits - 1);
+        }
+    }
+    float tau_cap[QW];
+#pragma unroll
+    for (int j = 0; j < QW; ++j) tau_cap[j] = tau[j];
+
+    TileStream<D> sweep{inp, in_sn, in_sd, M, lane};
+    sweep.start();
     for (int base = 0; base < M; base += RPE_WAVE) {
-        const int pi = base + lane;
-        const bool valid = pi < M;
-        float p[3] = {0.f, 0.f, 0.f};
-        if (valid) load_point<D>(inp, in_sn, in_sd, pi, p);
+        const bool valid = base + lane < M;
+        float p[3];
+        sweep.next(base, p);
         const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;  // a lane past the end: p = 0, |p|^2 = +inf -> d = +inf for every query
 #pragma unroll
         for (int j = 0; j < QW; ++j) {
@@ -304,7 +370,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
                     const bool gtp = (lane > 0) && (nd < upd);
                     Ld[j] = gt ? (gtp ? upd : nd) : Ld[j];
                     Li[j] = gt ? (gtp ? upi : ni) : Li[j];
-                    tau[j] = rpe_readlane(Ld[j], kk - 1);
+                    tau[j] = fminf(rpe_readlane(Ld[j], kk - 1), tau_cap[j]);
                 }
             }
         }
@@ -432,11 +498,13 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_nearest_kernel(
         bi[j] = 0x7fffffff;
     }
 
+    TileStream<D> sweep{inp, in_sn, in_sd, M, lane};
+    sweep.start();
     for (int base = 0; base < M; base += RPE_WAVE) {
         const int pi = base + lane;
         const bool valid = pi < M;
-        float p[3] = {0.f, 0.f, 0.f};
-        if (valid) load_point<D>(inp, in_sn, in_sd, pi, p);
+        float p[3];
+        sweep.next(base, p);
         const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;  // past the end: d = +inf, never taken
 #pragma unroll
         for (int j = 0; j < QW; ++j) {
