@@ -240,6 +240,23 @@ int rpe_pointconv_fused(const float *rows, int CFp, int M, const int64_t *knn, i
                         int act, float act_slope, int B, int Q, int Cout, int out_mode, int out_stride,
                         float *out, rpe_stream_t stream);
 
+/* ---- point-wise MLP: one or two Conv1dNormRelu layers (models/utils.py:7-98) in one launch -------------------------
+ * y = act2(s2 * (W2 act1(s1 * (W1 x) + t1)) + t2) per point; x [B,C0,N] through element strides (batch, channel, point).
+ * Layer widths are padded to 16 * T1 / 16 * T2 (T2 = 0: one layer).  Packed operands (built once per module):
+ *   w1_packed [ceil(C0/16)][T1][4][16][4]: [g][t][kk][o][s] = W1[16t + o][16g + 4kk + s]   (zero beyond C1 x C0)
+ *   w2_packed [T1][T2][4][16][4]:          [t1][t2][kk][o][s] = W2[16t2 + o][16t1 + 4kk + s]
+ *   scale_shift{1,2} [2][16 T]: the per-channel scale then shift that bias and eval-mode BatchNorm fold into
+ *   act 0 none, 1 relu, 2 leaky_relu(slope).
+ * out_mode 0: out [B,Cout,N] channel-first; out_mode 1: out [B,N,out_stride] = [xyz | y | zeros], the PointConv
+ * kernel's gather source (xyz [B,3,N] through strides).  Supported (T1,T2): (1,1) (1,2) (2,4) (4,6) (6,8) (8,12) (8,4)
+ * and (T,0) for T in 1, 2, 4, 6, 8, 12; anything else returns RPE_EUNSUPPORTED.                                     */
+int rpe_mlp1d_fused(const float *x, int64_t x_sb, int64_t x_sc, int64_t x_sn, int B, int C0, int N,
+                    const float *w1_packed, const float *scale_shift1, int act1, int T1,
+                    const float *w2_packed, const float *scale_shift2, int act2, int T2,
+                    float slope, int Cout, int out_mode, int out_stride,
+                    const float *xyz, int64_t z_sb, int64_t z_sd, int64_t z_sn,
+                    float *out, rpe_stream_t stream);
+
 /* ---- Correlation3D (models/pwc3d_core.py:69-117) behind its neighbour search, two launches -----------------------
  * Channel counts are padded to Cp = 16*T, T in {1,2,4,6,8,12}; every [Cp] / packed array below is zero beyond C.
  * rpe_corr3d_cost: the point-to-neighbour cost p2n (:84-98) for every point n of cloud 1, neighbours knn[b][n][0..15] in cloud 2:

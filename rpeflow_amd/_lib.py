@@ -62,6 +62,8 @@ _PROTOTYPES = {
     "rpe_pointconv_fused": [_c_ptr, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                             _c_float, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int,
                             _c_ptr, _c_ptr],
+    "rpe_mlp1d_fused": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_int, _c_int,
+                        _c_float, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr],
     "rpe_ids_forward": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int, _c_int,
                         _c_float, _c_float, _c_float, _c_float, _c_float, _c_ptr, _c_ptr],
     "rpe_ids_flow_inverse": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int,

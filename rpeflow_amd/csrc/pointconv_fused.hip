@@ -46,18 +46,20 @@ __device__ __forceinline__ float leaky(float x, float slope) { return x >= 0.f ?
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// 4 waves: WM x WN of them over (queries, outputs); a wave owns MT x NT tiles of 16 x 16.
-template <int MT, int WM, int NT, int WN>
-__global__ __launch_bounds__(256, 2) void pointconv_fused_kernel(PcArgs a) {
-    static_assert(WM * WN == 4, "four waves");
+// KS groups of 4 waves: in a group WM x WN waves over (queries, outputs), a wave owns MT x NT tiles of 16 x 16.  KS = 2
+// (the smallest levels, where a workgroup per 16 queries still leaves half the SIMDs idle): the two groups take alternate
+// channel chunks with a tile each, and their partial sums meet in LDS at the end -- twice the waves on the same K loop.
+template <int MT, int WM, int NT, int WN, int KS>
+__global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void pointconv_fused_kernel(PcArgs a) {
+    static_assert(WM * WN == 4, "four waves a group");
     constexpr int BM = 16 * MT * WM, QW = BM / 4;
-    constexpr int PD = MT * NT >= 8 ? 2 : MT * NT >= 4 ? 3 : MT * NT >= 2 ? 5 : 9;  // B-fragment groups in flight + 1
+    constexpr int PD = MT * NT >= 8 ? 2 : MT * NT >= 4 ? 4 : MT * NT >= 2 ? 8 : 16;  // B-fragment ring (divides the 16 groups of a chunk): PD - 1 groups in flight
     extern __shared__ __align__(16) float smem[];
-    float *atile = smem;                  // [BM][256] floats, 16-byte blocks XOR-swizzled by (row & 15)
-    int *rowoff = (int *)(smem + BM * 256);  // [BM][16] element offsets of the gathered rows
-
     const int lane = rpe_lane();
-    const int wave = rpe_uniform((int)(threadIdx.x >> 6));
+    const int kg = rpe_uniform((int)(threadIdx.x >> 8));         // wave group
+    const int wave = rpe_uniform((int)(threadIdx.x >> 6)) & 3;  // wave inside its group
+    float *atile = smem + kg * (BM * 256);        // [BM][256] floats per group, 16-byte blocks XOR-swizzled by (row & 15)
+    int *rowoff = (int *)(smem + KS * BM * 256);  // [BM][16] element offsets of the gathered rows (every group writes the same)
     const int kk = lane >> 4, n16 = lane & 15;
     const int b = blockIdx.y, q0 = blockIdx.x * BM;
     const float *rows_b = a.rows + (int64_t)b * a.M * a.CFp;
@@ -67,33 +69,51 @@ __global__ __launch_bounds__(256, 2) void pointconv_fused_kernel(PcArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) w2r[i] = a.w2[n16 * 8 + i];
     const float b2r = a.b2[n16];
-    // (rolled loop, values parked in this wave's own rows of the LDS tile: unrolled over 16 queries the compiler keeps
-    // hundreds of uniform temporaries alive and spills)
+    // Queries in batches of QB: all neighbour indices of a batch are requested first, then all neighbour coordinates, then
+    // the arithmetic -- two memory round trips a batch instead of two per query.  The batch loop stays rolled and the
+    // values are parked in this wave's own rows of the LDS tile (unrolled over 16 queries the compiler keeps hundreds
+    // of uniform temporaries alive and spills).
+    constexpr int QB = QW < 4 ? QW : 4;
 #pragma unroll 1
-    for (int iq = 0; iq < QW; ++iq) {
-        const int ql = wave * QW + iq;
-        const int q = min(q0 + ql, a.Q - 1);
-        const float *qp = a.q_xyz + (int64_t)b * a.q_sb + (int64_t)q * a.q_sn;
-        const float qx = qp[0], qy = qp[a.q_sd], qz = qp[2 * a.q_sd];
+    for (int ib = 0; ib < QW; ib += QB) {
+        int off[QB][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int j = 4 * s + kk;
-            const int off = (int)a.knn[((int64_t)b * a.Q + q) * a.knn_sq + j] * a.CFp;
-            if (n16 == 0) rowoff[ql * 16 + j] = off;
-            const float *r = rows_b + off;
-            const float rel[3] = {r[0] - qx, r[1] - qy, r[2] - qz};
-            float h[8];
+        for (int u = 0; u < QB; ++u) {
+            const int q = min(q0 + wave * QW + ib + u, a.Q - 1);
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                float v = a.b1[o];
+            for (int s = 0; s < 4; ++s) off[u][s] = (int)a.knn[((int64_t)b * a.Q + q) * a.knn_sq + 4 * s + kk] * a.CFp;
+        }
+        float nx[QB][4][3];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) v = __fmaf_rn(a.w1[o * 3 + d], rel[d], v);
-                h[o] = leaky(v, a.slope);
+        for (int u = 0; u < QB; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float *r = rows_b + off[u][s];
+                nx[u][s][0] = r[0], nx[u][s][1] = r[1], nx[u][s][2] = r[2];
             }
-            float v = b2r;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v = __fmaf_rn(w2r[i], h[i], v);
-            atile[ql * 256 + s * 64 + lane] = leaky(v, a.slope);
+        for (int u = 0; u < QB; ++u) {
+            const int ql = wave * QW + ib + u;
+            const int q = min(q0 + ql, a.Q - 1);
+            const float *qp = a.q_xyz + (int64_t)b * a.q_sb + (int64_t)q * a.q_sn;
+            const float qx = qp[0], qy = qp[a.q_sd], qz = qp[2 * a.q_sd];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (n16 == 0) rowoff[ql * 16 + 4 * s + kk] = off[u][s];
+                const float rel[3] = {nx[u][s][0] - qx, nx[u][s][1] - qy, nx[u][s][2] - qz};
+                float h[8];
+#pragma unroll
+                for (int o = 0; o < 8; ++o) {
+                    float v = a.b1[o];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) v = __fmaf_rn(a.w1[o * 3 + d], rel[d], v);
+                    h[o] = leaky(v, a.slope);
+                }
+                float v = b2r;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v = __fmaf_rn(w2r[i], h[i], v);
+                atile[ql * 256 + s * 64 + lane] = leaky(v, a.slope);
+            }
         }
     }
     __syncthreads();
@@ -121,9 +141,18 @@ __global__ __launch_bounds__(256, 2) void pointconv_fused_kernel(PcArgs a) {
 #pragma unroll
     for (int u = 0; u < QW; ++u)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bv[u][s] = rows_b[rowoff[(wave * QW + u) * 16 + 4 * s + kk] + n16];
+        for (int s = 0; s < 4; ++s) bv[u][s] = rows_b[rowoff[(wave * QW + u) * 16 + 4 * s + kk] + 16 * min(kg, a.nchunks - 1) + n16];
 
-    for (int ci = 0; ci < a.nchunks; ++ci) {
+    f32x4 bf[PD][NT];
+    if (kg < a.nchunks) {
+#pragma unroll
+        for (int d = 0; d < PD - 1; ++d)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[d][nt] = a.Lp[(((int64_t)kg * 16 + d) * a.NTT + tbase + nt) * 64 + lane];
+    }
+    for (int c0 = 0; c0 < a.nchunks; c0 += KS) {
+        const int ci = c0 + kg;
+        const bool live = KS == 1 || ci < a.nchunks;  // (group-uniform; every wave still meets both barriers)
         // ---- stage 1: G for this chunk's 16 channels -> LDS tile
 #pragma unroll
         for (int u = 0; u < QW; ++u) {
@@ -134,13 +163,17 @@ __global__ __launch_bounds__(256, 2) void pointconv_fused_kernel(PcArgs a) {
             const int blk = (4 * n16 + kk) ^ (ql & 15);
             *(f32x4 *)(atile + ql * 256 + 4 * blk) = g;
         }
-        if (ci + 1 < a.nchunks) {
+        if (ci + KS < a.nchunks) {
 #pragma unroll
             for (int u = 0; u < QW; ++u)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) bv[u][s] = rows_b[rowoff[(wave * QW + u) * 16 + 4 * s + kk] + 16 * (ci + 1) + n16];
+                for (int s = 0; s < 4; ++s) bv[u][s] = rows_b[rowoff[(wave * QW + u) * 16 + 4 * s + kk] + 16 * (ci + KS) + n16];
         }
         __syncthreads();
+        if (!live) {  // past the last chunk: nothing to add, but the partner group still needs this round's second barrier
+            __syncthreads();
+            continue;
+        }
 
         // ---- stage 2: total += A[BM x 256] * Lp chunk
         f32x4 acc[MT][NT];
@@ -149,17 +182,17 @@ __global__ __launch_bounds__(256, 2) void pointconv_fused_kernel(PcArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};  // MT*NT == 1: a second chain hides the 40-cycle dependent latency
-        const f32x4 *Lc = a.Lp + ((int64_t)ci * 16 * a.NTT + tbase) * 64 + lane;
-        f32x4 bf[PD][NT];
-#pragma unroll
-        for (int d = 0; d < PD - 1; ++d)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bf[d][nt] = Lc[((int64_t)d * a.NTT + nt) * 64];
+        // B fragments: a ring that runs on across the chunk boundaries (group g + PD - 1 of this chunk, or the first groups of
+        // this wave group's next chunk), so only the very first groups of the kernel wait for their L2 round trip
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            if (g + PD - 1 < 16) {
+            {
+                const int gg = g + PD - 1;  // compile-time after unrolling
+                const int cn = ci + KS * (gg / 16);
+                if (cn < a.nchunks) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bf[(g + PD - 1) % PD][nt] = Lc[((int64_t)(g + PD - 1) * a.NTT + nt) * 64];
+                    for (int nt = 0; nt < NT; ++nt) bf[gg % PD][nt] = a.Lp[(((int64_t)cn * 16 + (gg % 16)) * a.NTT + tbase + nt) * 64 + lane];
+                }
             }
             f32x4 af[MT];
 #pragma unroll
@@ -185,6 +218,22 @@ __global__ __launch_bounds__(256, 2) void pointconv_fused_kernel(PcArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) total[mt][nt] += acc[mt][nt];
         __syncthreads();
+    }
+
+    if constexpr (KS == 2) {  // group 1 hands its partial sums over through LDS (the tiles are dead: the last round's barrier is behind)
+        float *xchg = smem;
+        if (kg == 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) *(f32x4 *)(xchg + ((wave * MT * NT + mt * NT + nt) * 64 + lane) * 4) = total[mt][nt];
+        }
+        __syncthreads();
+        if (kg == 1) return;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) total[mt][nt] += *(const f32x4 *)(xchg + ((wave * MT * NT + mt * NT + nt) * 64 + lane) * 4);
     }
 
     // ---- epilogue: lane holds out[q = tile row 4*kk + r][o = 16*t + n16]
@@ -225,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void pointconv_fused_kernel(PcArgs a) {
     if (a.out_mode == 1 && blockIdx.z == 0) {
         // the rows' xyz columns and the zero tail beyond the last output tile
         const int covered = 3 + 16 * (int)gridDim.z * WN * NT;
-        for (int i = threadIdx.x; i < BM * 16; i += 256) {
+        for (int i = threadIdx.x; i < BM * 16; i += 256) {  // (KS == 2: group 0 only is left, threadIdx.x < 256)
             const int ql = i >> 4, c = i & 15, q = q0 + ql;
             if (q >= a.Q) continue;
             float *row = a.out + ((int64_t)b * a.Q + q) * a.out_stride;
@@ -272,18 +321,18 @@ __global__ __launch_bounds__(256) void pointconv_pack_kernel(PackSrc s, int M, i
     }
 }
 
-template <int MT, int WM, int NT, int WN>
+template <int MT, int WM, int NT, int WN, int KS = 1>
 int launch_fused(const PcArgs &a, int B, int nsplit, hipStream_t st) {
     constexpr int BM = 16 * MT * WM;
-    constexpr int smem = BM * 256 * 4 + BM * 16 * 4;
+    constexpr int smem = KS * BM * 256 * 4 + BM * 16 * 4;
     static bool configured = false;  // idempotent attribute: a race only repeats the call
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)pointconv_fused_kernel<MT, WM, NT, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute((const void *)pointconv_fused_kernel<MT, WM, NT, WN, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
     dim3 grid((a.Q + BM - 1) / BM, B, nsplit);
-    hipLaunchKernelGGL((pointconv_fused_kernel<MT, WM, NT, WN>), grid, dim3(256), smem, st, a);
+    hipLaunchKernelGGL((pointconv_fused_kernel<MT, WM, NT, WN, KS>), grid, dim3(256 * KS), smem, st, a);
     return rpe_launch_status();
 }
 
@@ -338,10 +387,12 @@ RPE_API int rpe_pointconv_fused(const float *rows, int CFp, int M, const int64_t
     if (Cout <= 64) {
         if (work >= 64 * want) return launch_fused<2, 2, 2, 2>(a, B, 1, st);
         if (work >= 32 * want) return launch_fused<1, 2, 2, 2>(a, B, 1, st);
-        return launch_fused<1, 1, 1, 4>(a, B, 1, st);
+        if (work >= 16 * want) return launch_fused<1, 1, 1, 4>(a, B, 1, st);
+        return launch_fused<1, 1, 1, 4, 2>(a, B, 1, st);
     }
     if (work * n128 >= 64 * want) return launch_fused<2, 2, 4, 2>(a, B, n128, st);
     if (work * n128 >= 32 * want) return launch_fused<1, 2, 4, 2>(a, B, n128, st);
     if (work * n128 >= 16 * want) return launch_fused<1, 1, 2, 4>(a, B, n128, st);
-    return launch_fused<1, 1, 1, 4>(a, B, n64, st);
+    if (work * n64 >= 16 * want) return launch_fused<1, 1, 1, 4>(a, B, n64, st);
+    return launch_fused<1, 1, 1, 4, 2>(a, B, n64, st);  // fewer than two workgroups a CU even so: split the channel chunks over two wave groups
 }

@@ -54,7 +54,8 @@ class FeaturePyramid3D(nn.Module):
         knns = k_nearest_neighbor_multi([(xyzs[i], xyzs[i + 1]) for i in range(len(xyzs) - 1)], self.pyramid_convs[0].k)
         feats = [self.level0_mlp(torch.zeros_like(xyzs[0]))]
         for i in range(len(xyzs) - 1):
-            feats.append(self.pyramid_convs[i](xyzs[i], self.pyramid_mlps[i](feats[-1]), xyzs[i + 1], knn_indices=knns[i]))
+            # the MLP writes the PointConv layer's gather rows [xyz | features] directly: no packing pass
+            feats.append(self.pyramid_convs[i](xyzs[i], self.pyramid_mlps[i](feats[-1], rows_xyz=xyzs[i]), xyzs[i + 1], knn_indices=knns[i]))
         return feats
 
 

@@ -115,6 +115,13 @@ class _ConvNormRelu(nn.Module):
 class Conv1dNormRelu(_ConvNormRelu):
     dims = 1
 
+    def forward(self, x):
+        if x.is_cuda and x.dim() == 3:
+            y = fused_mlp1d(x, [self])  # one launch instead of GEMM + epilogue (None: a shape the kernel is not built for)
+            if y is not None:
+                return y
+        return super().forward(x)
+
 
 class Conv2dNormRelu(_ConvNormRelu):
     dims = 2
@@ -138,6 +145,18 @@ class _MLP(nn.Module):
 
 class MLP1d(_MLP):
     block = Conv1dNormRelu
+
+    def forward(self, x, rows_xyz=None):
+        """``rows_xyz`` [B,3,N]: return the result as PointConv rows [xyz | y | 0] (rpeflow_amd.pointconv.PackedRows)."""
+        if x.is_cuda and x.dim() == 3 and len(self.convs) == 2:
+            y = fused_mlp1d(x, list(self.convs), rows_xyz=rows_xyz)  # both layers in one launch
+            if y is not None:
+                return y
+        y = super().forward(x)
+        if rows_xyz is not None:
+            from .pointconv import pack_rows
+            return pack_rows(rows_xyz, y)
+        return y
 
 
 class MLP2d(_MLP):
@@ -350,4 +369,85 @@ def ids_flow_inverse(xyz, flow, intrinsics, persp, paral):
     out = torch.empty((B, 3, N), dtype=torch.float32, device=xyz.device)
     _launch(xyz, "ids_flow_inverse", _lib.lib().rpe_ids_flow_inverse, _ptr(xyz), *xyz.stride(), _ptr(flow), *flow.stride(),
             _ptr(intrinsics), intrinsics.stride(0), B, N, *_ids_scales(persp, paral), _ptr(out))
+    return out
+
+
+# ------------------------------------------------------------------ fused point-wise MLP (csrc/mlp_fused.hip)
+_MLP_PAIRS = [(1, 1), (1, 2), (2, 4), (4, 6), (6, 8), (8, 12), (8, 4)]
+_MLP_SINGLE = [1, 2, 4, 6, 8, 12]
+_ACT_CODE = {None: 0, "relu": 1, "leaky_relu": 2}
+
+
+def _mlp_pack(blocks):
+    """Kernel-layout copies of one or two Conv1dNormRelu blocks (include/rpeflow_hip.h), or None when their shapes
+    are not among the instantiated ones; cached on the first block until a parameter or buffer changes."""
+    first = blocks[0]
+    tensors = [t for blk in blocks for t in (*blk.parameters(), *blk.buffers())]
+    key = (len(blocks),) + tuple((t.data_ptr(), t._version) for t in tensors)
+    cache = getattr(first, "_mlp_cache", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    packed = None
+    convs = [blk.conv_fn for blk in blocks]
+    plain = all(c.kernel_size == (1,) and c.stride == (1,) and c.padding == (0,) and c.groups == 1 for c in convs)
+    epis = [blk._epilogue() for blk in blocks]
+    if plain and all(e is not None for e in epis):
+        need = [(c.out_channels + 15) // 16 for c in convs]
+        if len(blocks) == 2:
+            fits = [p for p in _MLP_PAIRS if p[0] >= need[0] and p[1] >= need[1]]
+            tiles = min(fits, key=lambda p: p[0] * p[1]) if fits else None
+        else:
+            fits = [t for t in _MLP_SINGLE if t >= need[0]]
+            tiles = (fits[0], 0) if fits else None
+        if tiles is not None:
+            dev = convs[0].weight.device
+
+            def pack_w(conv, t_out, k_groups):
+                w = torch.zeros((16 * t_out, 16 * k_groups), dtype=torch.float32, device=dev)
+                w[:conv.out_channels, :conv.in_channels] = conv.weight.detach()[:, :, 0].float()
+                return w.reshape(t_out, 16, k_groups, 4, 4).permute(2, 0, 3, 1, 4).contiguous()  # [g][t][kk][o][s]
+
+            def pack_ss(epi, t_out, c_out):
+                scale, shift, _ = epi
+                ss = torch.zeros((2, 16 * t_out), dtype=torch.float32, device=dev)
+                ss[0, :c_out] = 1.0 if scale is None else scale
+                if shift is not None:
+                    ss[1, :c_out] = shift
+                return ss
+
+            c0 = convs[0].in_channels
+            packed = dict(tiles=tiles, c0=c0, cout=convs[-1].out_channels,
+                          w1=pack_w(convs[0], tiles[0], (c0 + 15) // 16), ss1=pack_ss(epis[0], tiles[0], convs[0].out_channels),
+                          act1=_ACT_CODE[epis[0][2]], w2=None, ss2=None, act2=0)
+            if len(blocks) == 2:
+                packed.update(w2=pack_w(convs[1], tiles[1], tiles[0]), ss2=pack_ss(epis[1], tiles[1], convs[1].out_channels),
+                              act2=_ACT_CODE[epis[1][2]])
+    first._mlp_cache = (key, packed)
+    return packed
+
+
+def fused_mlp1d(x, blocks, rows_xyz=None):
+    """One or two Conv1dNormRelu blocks applied to x [B,C0,N] in ONE launch; None when the kernel has no instantiation
+    for these widths (the caller then runs the library path).  ``rows_xyz``: see MLP1d.forward."""
+    w = _mlp_pack(blocks)
+    if w is None or x.shape[1] != w["c0"]:
+        return None
+    _lib.require_gpu(x, op="fused_mlp1d")
+    x = _f32(x)
+    B, _, N = x.shape
+    if rows_xyz is not None:
+        rows_xyz = _f32(rows_xyz)
+        stride = (w["cout"] + 3 + 15) // 16 * 16
+        out = torch.empty((B, N, stride), dtype=torch.float32, device=x.device)
+        xyz_args = (_ptr(rows_xyz), *rows_xyz.stride())
+    else:
+        stride = 0
+        out = torch.empty((B, w["cout"], N), dtype=torch.float32, device=x.device)
+        xyz_args = (_NULL, 0, 0, 0)
+    _launch(x, "fused_mlp1d", _lib.lib().rpe_mlp1d_fused, _ptr(x), *x.stride(), B, w["c0"], N, _ptr(w["w1"]), _ptr(w["ss1"]), w["act1"],
+            w["tiles"][0], _ptr(w["w2"]) if w["w2"] is not None else _NULL, _ptr(w["ss2"]) if w["ss2"] is not None else _NULL, w["act2"],
+            w["tiles"][1], 0.1, w["cout"], int(rows_xyz is not None), stride, *xyz_args, _ptr(out))
+    if rows_xyz is not None:
+        from .pointconv import PackedRows
+        return PackedRows(out, w["cout"])
     return out

@@ -12,8 +12,8 @@ from rpeflow_amd.model import RPEFlow
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device("cuda", 0)
-torch.manual_seed(0)
-model = RPEFlow().to(dev).eval()
+from rpeflow_amd.synthetic import load_seeded_parameters
+model = load_seeded_parameters(RPEFlow()).to(dev).eval()
 batch = bench.make_batch(4, dev)
 for _ in range(3):
     model(batch)
