@@ -112,7 +112,9 @@ int rpe_fps_algo(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
  *   out[b][(dy+md)*(2md+1)+(dx+md)][y][x] = (1/C) sum_c in1[b][c][y][x]*in2[b][c][y+dy][x+dx]
  * zero outside the image.  in1,in2 [B,C,H,W] contiguous; out [B,(2md+1)^2,H,W].
  * leaky_slope != 0 fuses the caller's leaky_relu (RPEFlow_core.py:362); pass 0
- * for the plain operator.  algo: 0 = pick, 1 = direct (any md), 2 = MFMA tiles (md==4). */
+ * for the plain operator.  algo: 0 = pick; 1 = direct (any md); 2 = MFMA tiles, register-staged (md == 4);
+ * 4 / 7 = MFMA tiles behind an LDS-DMA ring, 4 / 8 waves a workgroup (md == 4, W % 4 == 0, C % 4 / C % 2 == 0, 16-byte
+ * aligned inputs).  All give the same values to fp32 re-association; tests cross-check them.                        */
 int rpe_correlation2d_forward(const float *in1, const float *in2, int B, int C, int H, int W, int md,
                               float leaky_slope, int algo, float *out, rpe_stream_t stream);
 
@@ -201,18 +203,6 @@ int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int6
                              const float *feat_2d, int C2, int H, int W,
                              const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
                              const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream);
-
-/* ---- PointConv grouping (models/pointconv.py:48-57 and 107-118) ------------------
- * out[b][q][w*CF+c] = sum_{j<16} wn_j[w] * feats_cl[b][knn[b][q][j]][c],
- * wn_j = leaky(W2 leaky(W1 (xyz[:,knn_j]-q_xyz[:,q]) + b1) + b2), W1 [8,3], W2 [16,8]
- * (weight_net = MLP2d(3,[8,16]), pointconv.py:12).  feats_cl [B,M,CF] contiguous is
- * cat([xyz, features]) channel-last (pointconv.py:43-44), CF = C+3 <= 256.
- * The nn.Linear / norm / activation that follow stay with the caller.               */
-int rpe_pointconv_group(const float *xyz, int64_t x_sb, int64_t x_sd, int64_t x_sn,
-                        const float *q_xyz, int64_t q_sb, int64_t q_sd, int64_t q_sn,
-                        const float *feats_cl, const int64_t *knn, int64_t knn_row_stride,
-                        const float *w1, const float *b1, const float *w2, const float *b2, float leaky_slope,
-                        int B, int M, int Q, int CF, float *out, rpe_stream_t stream);
 
 /* ---- PointConv in one kernel (models/pointconv.py:33-61, 90-122) -----------------
  * rpe_pointconv_pack_rows: rows[b][m][:] = [xyz[b][:,m] | srcs[0][b][:,m] | ... | zeros] -- cat([xyz, features]) channel-last

@@ -68,8 +68,6 @@ _PROTOTYPES = {
                         _c_float, _c_float, _c_float, _c_float, _c_float, _c_ptr, _c_ptr],
     "rpe_ids_flow_inverse": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int,
                              _c_float, _c_float, _c_float, _c_float, _c_float, _c_ptr, _c_ptr],
-    "rpe_pointconv_group": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_i64,
-                            _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_float, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
 }
 
 _lib = None

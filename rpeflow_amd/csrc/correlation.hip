@@ -330,28 +330,8 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
         const int slot_id = ch % NSLOT;
         const float *l1 = lds + slot_id * G::SLOT + (wave * RY) * TX + lane;
         const float *l2 = lds + slot_id * G::SLOT + G::OFF2 + (wave * RY) * PX2 + lane;
-        if constexpr (PD == 0) {
-#pragma unroll 1
-            for (int c = 0; c < CK; ++c) {
-                float a[RY];
-#pragma unroll
-                for (int ry = 0; ry < RY; ++ry) a[ry] = l1[(c * G::TY + ry) * TX];
-#pragma unroll
-                for (int r = 0; r < RY + 2 * MD; ++r) {
-                    const float *row = l2 + (c * G::TY2 + r) * PX2;
-#pragma unroll
-                    for (int s = 0; s < 3; ++s) {
-                        const float bv = row[4 * s];
-#pragma unroll
-                        for (int ry = 0; ry < RY; ++ry) {
-                            const int dy = r - ry;  // in2 row (y + dy - MD) sits at local row ry + dy
-                            if (dy >= 0 && dy < ND)
-                                acc[ry][dy][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[ry], bv, acc[ry][dy][s], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        } else {
+        static_assert(PD > 0, "the operand reads run PD steps ahead of the MFMAs");
+        {
             constexpr int ROWS = RY + 2 * MD, STEPS = CK * ROWS;
             constexpr int DMA_EVERY = STEPS / G::PPW;
             static_assert(DMA_EVERY >= 1, "more DMA pieces than steps");
@@ -486,13 +466,10 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
         if (md != MD) return RPE_EUNSUPPORTED;
         if (B > 65535) return RPE_EUNSUPPORTED;
         launch_mfma<2, 4, 4>(in1, in2, B, C, H, W, leaky_slope, out, st);
-    } else if (algo >= 4 && algo <= 8) {
+    } else if (algo == 4 || algo == 7) {
         if (md != MD || B > 65535 || W % 4 != 0 || !aligned) return RPE_EUNSUPPORTED;
         int rc = algo == 4 ? launch_mfma_dma<2, 4, 4, 3, 4, true>(in1, in2, B, C, H, W, leaky_slope, out, st)
-               : algo == 5 ? launch_mfma_dma<2, 4, 2, 4, 0, false>(in1, in2, B, C, H, W, leaky_slope, out, st)
-               : algo == 6 ? launch_mfma_dma<2, 8, 2, 3, 0, false>(in1, in2, B, C, H, W, leaky_slope, out, st)
-               : algo == 7 ? launch_mfma_dma<2, 8, 2, 3, 3, true>(in1, in2, B, C, H, W, leaky_slope, out, st)
-                           : launch_mfma_dma<2, 8, 4, 3, 3, false>(in1, in2, B, C, H, W, leaky_slope, out, st);
+                           : launch_mfma_dma<2, 8, 2, 3, 3, true>(in1, in2, B, C, H, W, leaky_slope, out, st);
         if (rc) return rc;
     } else if (algo == 1) {
         if ((int64_t)B * n * n > 65535 || H > 65535) return RPE_EUNSUPPORTED;

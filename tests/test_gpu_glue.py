@@ -120,8 +120,8 @@ def test_pointconv_modules(golden_dir, name):
 
 @torch.no_grad()
 @pytest.mark.parametrize("C,M,Q", [(2, 64, 64), (61, 500, 77), (125, 300, 300), (195, 256, 256), (253, 100, 40)])
-def test_pointconv_group_channel_rounds(C, M, Q):
-    """Every channel-round instantiation (C+3 <= 64, 128, 192, 256) against the oracle."""
+def test_pointconv_channel_counts(C, M, Q):
+    """Channel counts around the 16-channel chunk boundaries (C + 3 = 5 ... 256) against the oracle."""
     r = I.rng(6100 + C)
     xyz = np.ascontiguousarray(I.ids_cloud(r, 2, M).transpose(0, 2, 1))
     feat = r.standard_normal((2, C, M), dtype=np.float32)

@@ -1,0 +1,40 @@
+"""Single hot-path operators at the forward's level-1 shapes, for rocprofv3 --pmc / --kernel-trace runs.
+Usage: python3 tools/prof_ops.py <pointconv|knn16|knn3|corr3d> [iters]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from rpeflow_amd import pointconv as PC
+from rpeflow_amd.csrc import k_nearest_neighbor
+
+which = sys.argv[1]
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = "cuda:0"
+torch.manual_seed(0)
+with torch.no_grad():
+    if which == "pointconv":  # FlowEstimator3D.point_conv1 at level 1: B=4, N=4096, 195 -> 128 (pwc3d_core.py:123)
+        xyz = torch.randn(4, 3, 4096, device=dev)
+        knn = k_nearest_neighbor(xyz, xyz, 16)
+        m = PC.PointConvNoSampling(195, 128).to(dev).eval()
+        packed = PC.pack_rows(xyz, torch.randn(4, 195, 4096, device=dev))
+        step = lambda: m(xyz, packed, knn)
+    elif which in ("knn16", "knn3"):  # the forward's largest 3-D searches
+        k = 16 if which == "knn16" else 3
+        p = torch.rand(4, 3, 8192 if k == 16 else 4096, device=dev) * 30
+        q = torch.rand(4, 3, 4096, device=dev) * 30
+        step = lambda: k_nearest_neighbor(p, q, k)
+    elif which == "corr3d":  # Correlation3D at level 1: B=4, N=4096, C=32
+        from rpeflow_amd.pwc3d_core import Correlation3D
+        m = Correlation3D(32, 32).to(dev).eval()
+        xyz1 = torch.randn(4, 3, 4096, device=dev)
+        xyz2 = xyz1 + 0.05 * torch.randn_like(xyz1)
+        f1, f2 = torch.randn(4, 32, 4096, device=dev), torch.randn(4, 32, 4096, device=dev)
+        step = lambda: m(xyz1, f1, xyz2, f2)
+    else:
+        raise SystemExit("unknown operator " + which)
+    for _ in range(iters):
+        step()
+torch.cuda.synchronize()
+print("done", which, iters)
