@@ -29,30 +29,45 @@ __device__ __forceinline__ void load_point(const float *base, int64_t sn, int64_
     p[2] = D > 2 ? a[2 * sd] : 0.f;
 }
 
-// The sweeps read the cloud 64 points at a time; the loads of tile t + 2 are issued before tile t is used, so the L2
-// round trip (~700 cycles) hides behind two tiles of arithmetic instead of stalling every iteration (a wave has only
-// one or two partners on its SIMD at these grid sizes).
+// The sweeps read the cloud 64 points at a time through a small wave-private LDS ring filled by LDS-DMA
+// (global_load_lds_dword: no staging registers, so nothing of a tile in flight is loop-carried and hipcc has no reason to
+// drain the memory queue at the loop head, which it does -- s_waitcnt vmcnt(0) -- for register prefetches carried
+// around the back edge: that wait exposed one L2 round trip per tile, 46 % of the wave cycles of the k = 16 search).
+// Tile t + 2 is requested before tile t is used; every request issues exactly D DMAs (lanes past the end re-read the
+// last point), so the counted wait below is exact.  Nothing else in the sweeps touches vector memory.
+typedef __attribute__((address_space(3))) void knn_lds_void_t;
+typedef __attribute__((address_space(1))) const void knn_glb_void_t;
+constexpr int kRingSlots = 4;
+
 template <int D>
 struct TileStream {
     const float *inp;
     int64_t sn, sd;
     int M, lane;
-    float a[3], b[3];  // tiles t + 1 and t + 2
-    __device__ __forceinline__ void fetch(int base, float (&p)[3]) const {
-        const int pi = base + lane;
-        p[0] = p[1] = p[2] = 0.f;
-        if (pi < M) load_point<D>(inp, sn, sd, pi, p);
-    }
-    __device__ __forceinline__ void start() {
-        fetch(0, a);
-        fetch(RPE_WAVE, b);
-    }
-    // the points of tile `base` (zeros past the end), and the request for tile base + 128
-    __device__ __forceinline__ void next(int base, float (&p)[3]) {
+    float *ring;  // this wave's [kRingSlots][3][64] floats of LDS
+    __device__ __forceinline__ void request(int base) const {
+        const int pi = min(base + lane, M - 1);
+        const float *src = inp + (int64_t)pi * sn;
+        float *dst = ring + ((base >> 6) & (kRingSlots - 1)) * (3 * RPE_WAVE);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { p[d] = a[d]; a[d] = b[d]; }
-        fetch(base + 2 * RPE_WAVE, b);
+        for (int d = 0; d < D; ++d)
+            __builtin_amdgcn_global_load_lds((knn_glb_void_t *)(src + d * sd), (knn_lds_void_t *)(dst + d * RPE_WAVE), 4, 0, 0);
     }
+    __device__ __forceinline__ void start() const {
+        request(0);
+        request(RPE_WAVE);
+    }
+    // the points of tile `base` (lanes past the end hold the last point: callers mask them), and the request for tile base + 128
+    __device__ __forceinline__ void next(int base, float (&p)[3]) const {
+        request(base + 2 * RPE_WAVE);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * D) : "memory");  // tile `base` has landed (two younger requests may be pending)
+        const float *src = ring + ((base >> 6) & (kRingSlots - 1)) * (3 * RPE_WAVE) + lane;
+        p[0] = src[0];
+        p[1] = D > 1 ? src[RPE_WAVE] : 0.f;
+        p[2] = D > 2 ? src[2 * RPE_WAVE] : 0.f;
+    }
+    // after the last tile: the two trailing requests must land before the ring is reused or the kernel ends
+    __device__ __forceinline__ void finish() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
 template <int D, int QW>
@@ -275,6 +290,7 @@ struct KnnJobs {
 template <int D, int QW, bool SMALL>  // SMALL: some job has M < 64 k (topk's nth_element form): LDS room for one row per wave
 __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(KnnJobs jobs, int k, int exact_ties, int row_stride) {
     extern __shared__ float seq_lds[];  // SMALL: per wave row_stride values then row_stride indices
+    __shared__ float tile_ring[kWavesPerBlock][kRingSlots * 3 * RPE_WAVE];
     const rpe_knn_job &J = jobs.job[blockIdx.z];
     const float *__restrict__ inp = J.input;
     const float *__restrict__ qry = J.query;
@@ -313,7 +329,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
         float lm[QW];
 #pragma unroll
         for (int j = 0; j < QW; ++j) lm[j] = INFINITY;
-        TileStream<D> ts{inp, in_sn, in_sd, M, lane};
+        TileStream<D> ts{inp, in_sn, in_sd, M, lane, tile_ring[wave]};
         ts.start();
         for (int base = 0; base < M; base += RPE_WAVE) {
             const bool valid = base + lane < M;
@@ -326,6 +342,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
                 lm[j] = d < lm[j] ? d : lm[j];  // (a NaN distance never lowers the minimum: the bound stays valid)
             }
         }
+        ts.finish();
 #pragma unroll
         for (int j = 0; j < QW; ++j) {
             int below = 0;  // how many of the 64 lane minima are strictly smaller than this lane's
@@ -343,13 +360,13 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
 #pragma unroll
     for (int j = 0; j < QW; ++j) tau_cap[j] = tau[j];
 
-    TileStream<D> sweep{inp, in_sn, in_sd, M, lane};
+    TileStream<D> sweep{inp, in_sn, in_sd, M, lane, tile_ring[wave]};
     sweep.start();
     for (int base = 0; base < M; base += RPE_WAVE) {
         const bool valid = base + lane < M;
         float p[3];
         sweep.next(base, p);
-        const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;  // a lane past the end: p = 0, |p|^2 = +inf -> d = +inf for every query
+        const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;  // a lane past the end: |p|^2 = +inf -> d = +inf for every query
 #pragma unroll
         for (int j = 0; j < QW; ++j) {
             const float d = rpe_pair_dist<D>(qs.qm2[j], qs.qq[j], p, pp);
@@ -375,6 +392,8 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
             }
         }
     }
+
+    sweep.finish();
 
 #pragma unroll
     for (int j = 0; j < QW; ++j) {
@@ -498,7 +517,8 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_nearest_kernel(
         bi[j] = 0x7fffffff;
     }
 
-    TileStream<D> sweep{inp, in_sn, in_sd, M, lane};
+    __shared__ float tile_ring[kWavesPerBlock][kRingSlots * 3 * RPE_WAVE];
+    TileStream<D> sweep{inp, in_sn, in_sd, M, lane, tile_ring[wave]};
     sweep.start();
     for (int base = 0; base < M; base += RPE_WAVE) {
         const int pi = base + lane;
@@ -515,6 +535,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_nearest_kernel(
         }
     }
 
+    sweep.finish();
 #pragma unroll
     for (int j = 0; j < QW; ++j) {
 #pragma unroll
