@@ -333,3 +333,98 @@ def test_resize_flow2d_against_reference_golden(golden_dir, name):
     if name.endswith("same"):
         assert got is flow
     close(got, G(golden_dir, name)["out"], atol=3e-6, what=name)
+
+
+# ---------------------------------------------------------------- round-2 fused kernels, unit level
+@torch.no_grad()
+@pytest.mark.parametrize("C0,C1,C2,N,norm,act", [(3, 16, 16, 100, "batch_norm", "leaky_relu"), (16, 16, 32, 777, "batch_norm", "leaky_relu"),
+                                                 (13, 9, 21, 50, None, "relu"), (128, 128, 64, 1030, None, "leaky_relu"),
+                                                 (96, 96, 128, 513, "batch_norm", None), (24, 24, 16, 16, None, "leaky_relu")])
+def test_fused_mlp1d_two_layers(C0, C1, C2, N, norm, act):
+    """MLP1d (two Conv1dNormRelu, utils.py:65-98) in one launch against the same module on the CPU: odd channel counts,
+    N not a multiple of 16, channel-first and PointConv-rows output."""
+    torch.manual_seed(C0 + N)
+    m = U.MLP1d(C0, [C1, C2], norm=norm, activation=act).eval()
+    for blk in m.convs:
+        if norm:
+            blk.norm_fn.running_mean.normal_(); blk.norm_fn.running_var.uniform_(0.5, 2.0)
+            blk.norm_fn.weight.data.uniform_(0.5, 1.5); blk.norm_fn.bias.data.normal_()
+    x = torch.randn(2, C0, N)
+    ref = m(x)
+    mg = m.to(DEV)
+    assert U._mlp_pack(list(mg.convs)) is not None, "shape expected to take the fused kernel"
+    got = mg(x.to(DEV)).cpu()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    # a strided (channel-sliced) input
+    wide = torch.randn(2, C0 + 5, N, device=DEV)
+    torch.testing.assert_close(mg(wide[:, 2:2 + C0]).cpu(), m.cpu()(wide[:, 2:2 + C0].cpu()), rtol=1e-4, atol=1e-4)
+    mg = m.to(DEV)
+    xyz = torch.randn(2, 3, N, device=DEV)
+    rows = mg(x.to(DEV), rows_xyz=xyz)
+    assert rows.channels == C2 and rows.rows.shape == (2, N, (C2 + 3 + 15) // 16 * 16)
+    r = rows.rows.cpu()
+    assert torch.equal(r[:, :, :3], xyz.cpu().transpose(1, 2))
+    torch.testing.assert_close(r[:, :, 3:3 + C2], ref.transpose(1, 2), rtol=1e-4, atol=1e-4)
+    assert (r[:, :, 3 + C2:] == 0).all()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("C0,C1,N", [(64, 64, 300), (5, 17, 33), (128, 64, 4096), (192, 64, 257)])
+def test_fused_conv1d_single_layer(C0, C1, N):
+    """Conv1dNormRelu (1x1) in one launch; a layer too wide for the kernel takes the library path and still agrees."""
+    torch.manual_seed(C0 * 3 + N)
+    m = U.Conv1dNormRelu(C0, C1, norm="batch_norm").eval()
+    m.norm_fn.running_mean.normal_(); m.norm_fn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(3, C0, N)
+    ref = m(x)
+    torch.testing.assert_close(m.to(DEV)(x.to(DEV)).cpu(), ref, rtol=1e-4, atol=1e-4)
+    wide = U.Conv1dNormRelu(300, 280).eval()  # beyond 12 output tiles: fused_mlp1d returns None, library path
+    xw = torch.randn(1, 300, 40)
+    refw = wide(xw)
+    assert U._mlp_pack([wide.to(DEV)]) is None
+    torch.testing.assert_close(wide(xw.to(DEV)).cpu(), refw, rtol=1e-4, atol=1e-4)
+
+
+@torch.no_grad()
+def test_pack_rows_concatenates_and_pads():
+    """rpe_pointconv_pack_rows: cat([xyz, a, b, c]) channel-last, zero-padded to a multiple of 16, strided sources."""
+    torch.manual_seed(11)
+    xyz = torch.randn(2, 3, 333, device=DEV)
+    a, b, c = torch.randn(2, 64, 333, device=DEV), torch.randn(2, 9, 333, device=DEV)[:, 2:5], torch.randn(2, 1, 333, device=DEV)
+    packed = PC.pack_rows(xyz, [a, b, c])
+    assert packed.channels == 68 and packed.rows.shape == (2, 333, 80)
+    want = torch.cat([xyz, a, b, c], dim=1).transpose(1, 2)
+    assert torch.equal(packed.rows[:, :, :71], want) and (packed.rows[:, :, 71:] == 0).all()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("B,N,C,Cmid,Cout", [(2, 200, 20, 24, 24), (4, 1024, 195, 128, 128), (1, 50, 7, 130, 20), (3, 4096, 35, 32, 32)])
+def test_pointconv_rows_output_feeds_the_next_layer(B, N, C, Cmid, Cout):
+    """out_rows=True (the fused kernel writes the next layer's gather rows) equals channel-first output + packing pass,
+    bit for bit, and the chained second layer equals the two-step form -- every tile configuration the launcher picks."""
+    r = I.rng(7000 + N)
+    xyz = dev(np.ascontiguousarray(I.ids_cloud(r, B, N).transpose(0, 2, 1)))
+    feat = dev(r.standard_normal((B, C, N), dtype=np.float32))
+    from rpeflow_amd.csrc import k_nearest_neighbor
+    knn = k_nearest_neighbor(xyz, xyz, 16)
+    torch.manual_seed(N)
+    c1, c2 = PC.PointConvNoSampling(C, Cmid).to(DEV).eval(), PC.PointConvNoSampling(Cmid, Cout).to(DEV).eval()
+    y = c1(xyz, feat, knn)
+    rows = c1(xyz, feat, knn, out_rows=True)
+    again = PC.pack_rows(xyz, y)
+    assert torch.equal(rows.rows, again.rows)
+    assert torch.equal(c2(xyz, rows, knn), c2(xyz, y, knn))
+    ref = O.pointconv({k: v.detach().cpu().numpy() for k, v in c1.state_dict().items()}, xyz.cpu().numpy(), feat.cpu().numpy(),
+                      knn_indices=knn.cpu().numpy(), k=16, norm=None)
+    close_sum(y, ref, what="first layer vs oracle")
+
+
+@torch.no_grad()
+def test_correlation3d_projection_is_hoistable():
+    """Correlation3D.forward(projected=project_stacked(...)) equals the plain call (the model issues the projection early)."""
+    c, x = K.BLOCK_CASES["correlation3d"], K.block_inputs("correlation3d")
+    m, _ = _load(P3.Correlation3D(c["C"], c["C"], k=c["k"]), _shapes_corr3d(c["C"]), c["seed"] + 1000)
+    a = m(dev(x["xyz1"]), dev(x["feat1"]), dev(x["xyz2"]), dev(x["feat2"]))
+    proj = m.project_stacked(torch.cat([dev(x["feat1"]), dev(x["feat2"])], 0))
+    b = m(dev(x["xyz1"]), dev(x["feat1"]), dev(x["xyz2"]), dev(x["feat2"]), projected=proj)
+    assert torch.equal(a, b)
