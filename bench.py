@@ -43,7 +43,14 @@ RUNTIME = runtime.configure()  # before anything initialises the HIP runtime (gr
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-H, W, NPTS = 544, 960, 8192
+H, W, NPTS = 544, 960, 8192  # the correlation microbench's frame (BASELINE config 2) and the default workload's
+# workload shapes: (frame H, W, batch per GPU, first sample seed, DSEC-style targets, golden of the reference's CPU forward)
+CONFIGS = {
+    "things": dict(H=544, W=960, batch=4, first_seed=1000, dsec=False, golden="model_bench_b4_544x960.npz",
+                   name="FlyingThings3D val shapes (BASELINE config 3)"),
+    "dsec": dict(H=480, W=640, batch=3, first_seed=2000, dsec=True, golden="model_bench_dsec_b3_480x640.npz",
+                 name="DSEC eval shapes, conf/test/dsec.yaml (BASELINE config 5)"),
+}
 
 
 def parse():
@@ -51,7 +58,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--batch", type=int, default=4, help="frame pairs per GPU per step (conf/test/things.yaml batch_size)")
+    p.add_argument("--config", choices=list(CONFIGS), default="things", help="workload shapes: things = 544x960, batch 4 (the headline); dsec = 480x640, batch 3")
+    p.add_argument("--batch", type=int, default=None, help="frame pairs per GPU per step (default: the configuration's: conf/test/*.yaml batch_size)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("--no-corr-microbench", action="store_true")
@@ -111,9 +119,9 @@ def usable_cores():
     return n
 
 
-def make_batch(B, device, first_seed=1000):
+def make_batch(B, device, first_seed=1000, H=H, W=W, dsec=False):
     from rpeflow_amd.synthetic import frame_pair
-    samples = [frame_pair(first_seed + i, H, W, NPTS) for i in range(B)]
+    samples = [frame_pair(first_seed + i, H, W, NPTS, dsec=dsec) for i in range(B)]
     return {k: torch.stack([torch.from_numpy(s[k]) for s in samples]).to(device) for k in samples[0]}
 
 
@@ -131,10 +139,7 @@ def golden_epe_delta(out, batch, golden):
             "mean_abs_flow_3d": float(np.abs(f3 - golden["flow_3d"]).mean())}
 
 
-CPU_BATCH = 4  # conf/test/things.yaml batch_size, the benched batch
-
-
-def cpu_baseline_worker(workload):
+def cpu_baseline_worker(workload, config="things"):
     """Child process (never touches the GPU): the reference's CPU/PyTorch fallback path, restated in
     oracle/torch_ref.py, on the host cores.  Sample: batch 4 (the benched batch), full size, 1 untimed + 3 timed steps."""
     from types import SimpleNamespace
@@ -142,12 +147,14 @@ def cpu_baseline_worker(workload):
     from rpeflow_amd.hotpath import OP_NAMES, HotPathWorkload
     cores = usable_cores()
     torch.set_num_threads(cores)
+    cfg = CONFIGS[config]
+    H, W, CPU_BATCH = cfg["H"], cfg["W"], cfg["batch"]  # noqa: N806
     ops = SimpleNamespace(**{n: getattr(torch_ref, n) for n in OP_NAMES})
     if workload == "forward":
         from rpeflow_amd.model import RPEFlow
         from rpeflow_amd.synthetic import load_seeded_parameters
         model = load_seeded_parameters(RPEFlow(ops=ops)).eval()
-        batch = make_batch(CPU_BATCH, "cpu")
+        batch = make_batch(CPU_BATCH, "cpu", first_seed=cfg["first_seed"], H=H, W=W, dsec=cfg["dsec"])
         step, what = (lambda: model(batch)), "full RPEFlow forward"
     else:
         wl = HotPathWorkload(batch=CPU_BATCH, height=H, width=W, n_points=NPTS, device="cpu", ops=ops)
@@ -159,16 +166,16 @@ def cpu_baseline_worker(workload):
         step()
     dt = (time.time() - t0) / steps
     print(json.dumps({"value": round(CPU_BATCH / dt, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-                      "sample": f"{steps} timed steps (+1 warm-up) of the {what}, batch {CPU_BATCH}, 544x960 + 8192 pts, "
+                      "sample": f"{steps} timed steps (+1 warm-up) of the {what}, batch {CPU_BATCH}, {H}x{W} + 8192 pts, "
                                 f"PyTorch-CPU port of the reference fallback path (matmul+topk KNN, Python-loop FPS, "
                                 f"81-slice correlation, stock CPU convs/attention), {dt:.2f} s/step, "
                                 f"host cpu_count={os.cpu_count()}"}))
 
 
-def cpu_baseline(workload, timeout_s=420):
+def cpu_baseline(workload, config="things", timeout_s=420):
     import subprocess
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--workload", workload], capture_output=True,
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--workload", workload, "--config", config], capture_output=True,
                            text=True, timeout=timeout_s, cwd=ROOT)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode == 0 and lines:
@@ -211,7 +218,7 @@ def launch_ranks(n_ranks, argv):
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        return cpu_baseline_worker(args.workload)
+        return cpu_baseline_worker(args.workload, args.config)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -279,6 +286,10 @@ def main():
     from rpeflow_amd import _lib, roofline
     from rpeflow_amd.hotpath import HotPathWorkload, SegmentGraphs, Timer
     _lib.lib()  # fail loudly now if librpeflow_hip.so is missing
+    cfg = CONFIGS[args.config]
+    H, W = cfg["H"], cfg["W"]  # noqa: N806 -- shadow the module's headline shape inside this run
+    if args.batch is None:
+        args.batch = cfg["batch"]
 
     # ---- hot-path sequence: per-category events (and the timed workload if --workload hotpath)
     wl = HotPathWorkload(batch=args.batch, height=H, width=W, n_points=NPTS, device=dev, seed=1000 + rank)
@@ -303,7 +314,7 @@ def main():
         from rpeflow_amd.synthetic import load_seeded_parameters
         # (eval_withocc.py:159 sets cudnn.benchmark; measured here it buys <1 % and costs minutes of MIOpen search per process)
         model = load_seeded_parameters(RPEFlow()).to(dev).eval()  # the parameters of the committed model goldens
-        batch = make_batch(args.batch, dev, first_seed=1000 + rank * args.batch)
+        batch = make_batch(args.batch, dev, first_seed=cfg["first_seed"] + rank * args.batch, H=H, W=W, dsec=cfg["dsec"])
         for _ in range(max(args.warmup, 1)):
             out = model(batch)
         sync()
@@ -329,12 +340,12 @@ def main():
             for key in ("flow_2d", "flow_3d"):  # the replayed graph (multi-stream branches included) must reproduce the eager forward
                 err = (out[key] - eager_out[key]).abs().mean().item() / (eager_out[key].abs().mean().item() + 1e-6)
                 assert err < 1e-3, "graph replay differs from the eager forward: relative mean |d %s| = %g" % (key, err)
-        golden = os.path.join(ROOT, "tests", "golden", "model_bench_b4_544x960.npz")
-        if rank == 0 and args.batch == 4 and os.path.exists(golden):  # untimed: this configuration's output vs the reference's
+        golden = os.path.join(ROOT, "tests", "golden", cfg["golden"])
+        if rank == 0 and args.batch == cfg["batch"] and os.path.exists(golden):  # untimed: this configuration's output vs the reference's
             import numpy as np
             d = golden_epe_delta(out, batch, np.load(golden))
             epe_delta = {"epe2d": float("%.3g" % d["epe2d"]), "epe3d": float("%.3g" % d["epe3d"]), "bound": 1e-4,
-                         "against": "the reference's CPU forward on this batch and these parameters (tests/golden/model_bench_b4_544x960.npz)"}
+                         "against": "the reference's CPU forward on this batch and these parameters (tests/golden/%s)" % cfg["golden"]}
             assert d["epe2d"] < 1e-4 and d["epe3d"] < 1e-4, "benched configuration is off the reference: %r" % (d,)
         dt = timed(fwd_step)
 
@@ -353,14 +364,14 @@ def main():
         fps_us = totals["fps+pyramid"][0] / totals["fps+pyramid"][1] * 1e3
         fps_bytes = roofline.fps(2 * args.batch, NPTS, 4096)
         line = {
-            "metric": "frame-pairs/sec (544x960 + 8192 pts)",
+            "metric": "frame-pairs/sec (%dx%d + 8192 pts)" % (H, W),
             "value": round(pairs / dt, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("full RPEFlow forward (RGB pair + 20-ch event voxel + 2x8192 pts), seeded random-init weights, "
-                                    "FlyingThings3D val shapes (BASELINE config 3)") if args.workload == "forward" else
-                                   ("RPEFlow hot path only (FPS, 43 KNN, correlation2d, warps, gathers, PointConv, Correlation3D) "
-                                    "at FlyingThings3D shapes; dense 2D convs/attention excluded"),
+                                    + cfg["name"]) if args.workload == "forward" else
+                                   ("RPEFlow hot path only (FPS, 43 KNN, correlation2d, warps, gathers, PointConv, Correlation3D) at "
+                                    + cfg["name"] + "; dense 2D convs/attention excluded"),
                        "frame": [H, W], "points": NPTS, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "sharding": f"frame pairs over {world} rank(s), no data-path collective",
                        "launch": launch, "runtime": RUNTIME},
@@ -386,7 +397,7 @@ def main():
         if world == 1 and not args.no_corr_microbench:
             line["roofline_corr"] = corr_microbench(dev)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload)
+            line["cpu_baseline"] = cpu_baseline(args.workload, args.config)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -198,3 +198,6 @@ def fblock_inputs(name):
 # The benched configuration (bench.py, BASELINE config 3): batch 4 of 544x960 frame pairs + 8192 points,
 # samples frame_pair(1000 + i), parameters tests.inputs.model_params
 BENCH_CASE = dict(B=4, H=544, W=960, N=8192, first_seed=1000)
+# ... and the DSEC evaluation shape (bench.py --config dsec, BASELINE config 5): batch 3 (conf/test/dsec.yaml:24) of 480x640
+# frame pairs + 8192 points, 4-channel flow_3d targets, samples frame_pair(2000 + i, dsec=True)
+BENCH_CASE_DSEC = dict(B=3, H=480, W=640, N=8192, first_seed=2000)

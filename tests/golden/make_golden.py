@@ -278,6 +278,26 @@ def gen_fblocks():
 
 
 @torch.no_grad()
+def gen_model_bench_dsec():
+    """bench.py --config dsec: batch 3 of 480x640 DSEC-shaped frame pairs (seeds 2000..2002) through the reference on the CPU."""
+    c = K.BENCH_CASE_DSEC
+    m = reference_model()
+    m.load_state_dict({k: T(v) for k, v in model_params(m).items()}, strict=True)
+    m.eval()
+    samples = [I.frame_pair(c["first_seed"] + i, H=c["H"], W=c["W"], N=c["N"], dsec=True) for i in range(c["B"])]
+    batch = {k: torch.stack([T(s[k]) for s in samples]) for k in samples[0]}
+    out = m(batch, is_Train=False)
+    f2, f3 = out["flow_2d"].numpy(), out["flow_3d"].numpy()
+    assert np.isfinite(f2).all() and np.isfinite(f3).all()
+    t2, t3 = batch["flow_2d"].numpy()[:, :2], batch["flow_3d"].numpy()[:, :3]
+    epe2 = float(np.sqrt(((f2 - t2) ** 2).sum(1)).mean())
+    epe3 = float(np.sqrt(((f3 - t3) ** 2).sum(1)).mean())
+    print("bench dsec flow_2d |max|", np.abs(f2).max(), "flow_3d |max|", np.abs(f3).max(), "EPE", epe2, epe3)
+    save("model_bench_dsec_b3_480x640", flow_2d_s8=f2[:, :, ::8, ::8].copy(), flow_3d=f3, epe2d=np.float64(epe2), epe3d=np.float64(epe3),
+         **ids_clouds())
+
+
+@torch.no_grad()
 def gen_model_bench():
     """The benched configuration itself (bench.py / BASELINE config 3): a batch of 4 synthetic 544x960 frame pairs
     (seeds 1000..1003) + 8192 points through the reference on the CPU, seeded parameters.  Stored: flow_2d on a stride-8
@@ -362,6 +382,6 @@ def gen_eval():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval", "fblocks", "model_bench"]
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval", "fblocks", "model_bench", "model_bench_dsec"]
     for w in which:
         globals()["gen_" + w]()

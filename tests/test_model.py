@@ -268,6 +268,34 @@ def test_every_pyramid_level_matches_the_reference(golden_dir):
 
 @pytest.mark.gpu
 @torch.no_grad()
+def test_benched_dsec_configuration_matches_reference_golden(golden_dir):
+    """bench.py --config dsec (BASELINE config 5 shapes on one GPU): batch 3 of 480x640 DSEC-shaped frame pairs (4-channel
+    flow_3d targets, no occlusion mask), built and replayed exactly as bench.py does, against the reference's CPU forward."""
+    import bench
+    from rpeflow_amd.model import RPEFlow
+    from rpeflow_amd.synthetic import load_seeded_parameters
+    cfg = bench.CONFIGS["dsec"]
+    g = np.load(os.path.join(golden_dir, cfg["golden"]))
+    dev = torch.device("cuda", 0)
+    model = load_seeded_parameters(RPEFlow()).to(dev).eval()
+    batch = bench.make_batch(cfg["batch"], dev, first_seed=cfg["first_seed"], H=cfg["H"], W=cfg["W"], dsec=True)
+    model(batch)
+    order = model.sample_order(batch)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        out = model.forward_ahead(batch, order, batch)
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    d = bench.golden_epe_delta(out, batch, g)
+    print("benched DSEC configuration, graph replay:", d)
+    assert out["flow_2d"].shape == (3, 2, 480, 640)
+    assert d["epe2d"] < GOLDEN_EPE_TOL and d["epe3d"] < GOLDEN_EPE_TOL
+    assert d["mean_abs_flow_2d"] < 1e-3 and d["mean_abs_flow_3d"] < 1e-4
+
+
+@pytest.mark.gpu
+@torch.no_grad()
 def test_benched_configuration_matches_reference_golden(golden_dir):
     """The configuration bench.py times, built the way bench.py builds it -- batch 4 of 544x960 frame pairs + 8192 points
     (seeds 1000..1003), seeded parameters, IDS transform on the device, furthest-point sampling one batch ahead
