@@ -332,8 +332,15 @@ def main():
             # thread_local: a query from another thread (the RCCL watchdog of a multi-rank run) must not invalidate the capture
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = model(batch) if args.no_ahead else model.forward_ahead(batch, order, batch)
-            for _ in range(max(args.warmup, 1)):  # untimed replays: graph upload, clocks back up after the capture
+            # untimed replays: graph upload, and the clocks back up after the capture (the chip needs ~50 ms of load for that:
+            # with a small --warmup the first timed replays would otherwise run 30 % slow); never fewer than --warmup
+            t_settle = time.perf_counter()
+            n_replays = 0
+            while n_replays < max(args.warmup, 1) or (n_replays < 12 and time.perf_counter() - t_settle < 0.25):
                 graph.replay()
+                n_replays += 1
+                if n_replays % 4 == 0:
+                    sync()
             sync()
             fwd_step, launch = graph.replay, "one HIP graph per forward" + (
                 "" if args.no_ahead else "; furthest-point sampling runs one batch ahead (the next batch's FPS inside this graph)")
