@@ -22,11 +22,6 @@ namespace {
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / RPE_WAVE;  // 16
 
-__device__ __forceinline__ void argmax_merge(float &v, int &i, float ov, int oi) {
-    const bool take = (ov > v) || (ov == v && oi < i);
-    v = take ? ov : v;
-    i = take ? oi : i;
-}
 
 // ---- DPP reductions (gfx9 row_shr / row_bcast controls): ~8 cycles a step instead of a
 // ds_bpermute round trip per __shfl_xor.  After the six steps lane 63 holds the result;
@@ -36,23 +31,11 @@ __device__ __forceinline__ float dpp_max(float v) {
     const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
     return fmaxf(v, __int_as_float(o));
 }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_min(int v) {
-    const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
-    return min(v, o);
-}
 __device__ __forceinline__ float row_max16(float v) {
     v = dpp_max<0x111, 0xf>(v);  // row_shr:1
     v = dpp_max<0x112, 0xf>(v);  // row_shr:2
     v = dpp_max<0x114, 0xf>(v);  // row_shr:4
     v = dpp_max<0x118, 0xf>(v);  // row_shr:8
-    return v;
-}
-__device__ __forceinline__ int row_min16(int v) {
-    v = dpp_min<0x111, 0xf>(v);
-    v = dpp_min<0x112, 0xf>(v);
-    v = dpp_min<0x114, 0xf>(v);
-    v = dpp_min<0x118, 0xf>(v);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
@@ -61,16 +44,10 @@ __device__ __forceinline__ float wave_max(float v) {
     v = dpp_max<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3
     return rpe_readlane(v, 63);
 }
-__device__ __forceinline__ int wave_min(int v) {
-    v = row_min16(v);
-    v = dpp_min<0x142, 0xa>(v);
-    v = dpp_min<0x143, 0xc>(v);
-    return rpe_readlane(v, 63);
-}
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// ---- variant 3: the same algorithm on the integer pipe, reductions as fused DPP instructions ----------------
+// ---- fps_kernel_int: running distances on the integer pipe, reductions as fused DPP instructions --------------------
 // Running distances are non-negative floats (sums of squares, 1e10 at the start), so their bit patterns order like
 // the values: min / max / == run as v_min_i32 / v_max3_i32 / v_cmp_eq_u32 with no NaN canonicalisation, invalid slots
 // hold -1.  The compiler expands every __builtin_amdgcn_update_dpp + max step into mov, nop, mov_dpp, 2 x max; here a
@@ -184,23 +161,6 @@ __global__ __launch_bounds__(kThreads) void fps_kernel_int(const float *__restri
 }
 
 
-// ---- spatially sorted FPS with exact skipping ---------------------------------------------
-// The two kernels above touch every point in every iteration.  But a new sample only lowers the
-// running distance of points closer to it than their current distance, and late in the run that is
-// a handful of points around the sample.  This kernel
-//   1. sorts the cloud along a Morton curve once (bitonic sort of (key, index) pairs in LDS), so
-//      that the PPT points a thread owns -- and the 64*PPT a wave owns -- are spatial neighbours;
-//   2. keeps per thread the bounding box of its points, their running distances, and its current
-//      candidate (max distance, lowest ORIGINAL index among equals, that point's coordinates);
-//   3. per sample evaluates one box-to-sample lower bound per thread; only threads where the bound
-//      (shrunk by 1e-4, far more than fp32 rounding of either side) is below their largest running
-//      distance recompute their points -- with exactly the reference arithmetic -- so a skipped point
-//      provably keeps its distance and the result is the reference's, index for index;
-//   4. re-reduces a wave's candidate only if one of its threads recomputed; every wave republishes
-//      its (possibly unchanged) candidate + coordinates to an LDS slot double-buffered by sample
-//      parity, one barrier, then all waves reduce the 16 slots (DPP) and read the winner's
-//      coordinates from the same slots: no separate coordinate lookup.
-// Rules as above (wrapper.py:83-96): start at index 0, nd = fl(fl(dx*dx+dy*dy)+dz*dz), first maximum.
 __device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
     v = (v | (v << 16)) & 0x030000FFu;
     v = (v | (v << 8)) & 0x0300F00Fu;
@@ -220,18 +180,14 @@ __device__ __forceinline__ float wave_minf(float v) {
     return rpe_readlane(v, 63);
 }
 
-// 0: shuffle-based fps_kernel, 1: DPP + packed math, 2: sorted + exact skipping (1024 < N <= 16384).
-// Measured on MI355X (8192 -> 4096): 1.68 / 1.19 / 1.32 us per sample.  Variant 2 removes ~95 % of the
-// distance arithmetic but not the per-sample latency chain (candidate update -> wave reduce -> LDS ->
-// barrier -> block reduce) that bounds all three, so 1 stays the default.
-// ---- variant 4: Morton-sorted clusters, skipped per wave, on the machinery of variant 3 ------------------
+// ---- Morton-sorted clusters, skipped per wave ---------------------------------------------------------------------
 // A new sample c lowers the running distance of point i only if d(i,c) < md[i].  Points are sorted along a Morton
-// curve so that a wave owns NCL spatially compact clusters (PPT / NCL rows of 64 points each) with known bounding
-// boxes.  Per sample a wave evaluates, for each of its clusters, a lower bound LB of the squared distance from c to
-// the box; if 0.99999 * LB exceeds the cluster's largest running distance no point of the cluster can change (the
-// margin is far larger than the rounding of either side) and the cluster is skipped: no distance arithmetic, no
-// reduction.  Late in the run one or two of the 16 waves do any work per sample.  Whatever is recomputed uses exactly
-// the reference arithmetic, ties resolve to the lowest ORIGINAL index, so the output is index-for-index the reference fallback's.
+// curve so that a wave owns a spatially compact cluster (PPT rows of 64 points) with a known bounding box.  Per sample
+// a wave evaluates a lower bound LB of the squared distance from c to its box; if 0.99999 * LB exceeds the cluster's
+// largest running distance no point of the cluster can change (the margin is far larger than the rounding of either
+// side) and the cluster is skipped: no distance arithmetic, no reduction.  Late in the run a few of the 16 waves do any
+// work per sample.  Whatever is recomputed uses exactly the reference arithmetic, ties resolve to the lowest ORIGINAL
+// index, so the output is index-for-index the reference fallback's.
 __device__ __forceinline__ int wave_min_i32(int v) {
     RPE_DPP_STEP("v_min_i32_dpp", v, "row_shr:1 row_mask:0xf bank_mask:0xf");
     RPE_DPP_STEP("v_min_i32_dpp", v, "row_shr:2 row_mask:0xf bank_mask:0xf");
@@ -247,8 +203,8 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 #ifdef RPE_FPS_STATS
 __device__ unsigned long long g_fps_stats[4];
 #endif
-// ---- variant 7: wave-level skipping with the skip test folded into the post-barrier reduction ----------------
-// As variant 4 (one Morton cluster per wave), but (a) every wave publishes its candidate's COORDINATES with its
+// ---- fps_pruned2_kernel: the skip test folded into the post-barrier reduction ---------------------------------------
+// One Morton cluster per wave; (a) every wave publishes its candidate's COORDINATES with its
 // partial, so the winner's coordinates are three v_readlane away instead of an LDS lookup, and (b) the skip test is
 // evaluated for all 16 candidates at once -- lane l tests candidate l against this wave's box -- while the DPP
 // reduction that picks the winner is in flight; the winner's lane then selects its bit.  A skipping wave's iteration
