@@ -73,8 +73,10 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void pointconv_fused_ker
     // the arithmetic -- two memory round trips a batch instead of two per query.  The batch loop stays rolled and the
     // values are parked in this wave's own rows of the LDS tile (unrolled over 16 queries the compiler keeps hundreds
     // of uniform temporaries alive and spills).
-    constexpr int QB = QW < 4 ? QW : 4;
-#pragma unroll 1
+    constexpr int QB = QW <= 8 ? QW : 4;  // (16 queries a wave: batches of 4, or the transient registers spill)
+    float bv[QW][4];  // stage-1 B operands of the chunk in flight (first chunk: requested here, with the coordinates)
+    const int first_chunk = 16 * min(kg, a.nchunks - 1);
+#pragma unroll
     for (int ib = 0; ib < QW; ib += QB) {
         int off[QB][4];
 #pragma unroll
@@ -83,6 +85,10 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void pointconv_fused_ker
 #pragma unroll
             for (int s = 0; s < 4; ++s) off[u][s] = (int)a.knn[((int64_t)b * a.Q + q) * a.knn_sq + 4 * s + kk] * a.CFp;
         }
+#pragma unroll
+        for (int u = 0; u < QB; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bv[ib + u][s] = rows_b[off[u][s] + first_chunk + n16];
         float nx[QB][4][3];
 #pragma unroll
         for (int u = 0; u < QB; ++u)
@@ -137,19 +143,6 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void pointconv_fused_ker
     // Software pipeline over the channel chunks: the gathered row pieces of chunk ci + 1 are requested before stage 2 of
     // chunk ci and land under its MFMAs; stage 2 keeps PD groups of B fragments in flight (the smaller the wave tile, the
     // fewer MFMAs a group has to hide an L2 round trip, the deeper the ring).
-    float bv[QW][4];
-#pragma unroll
-    for (int u = 0; u < QW; ++u)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bv[u][s] = rows_b[rowoff[(wave * QW + u) * 16 + 4 * s + kk] + 16 * min(kg, a.nchunks - 1) + n16];
-
-    f32x4 bf[PD][NT];
-    if (kg < a.nchunks) {
-#pragma unroll
-        for (int d = 0; d < PD - 1; ++d)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bf[d][nt] = a.Lp[(((int64_t)kg * 16 + d) * a.NTT + tbase + nt) * 64 + lane];
-    }
     for (int c0 = 0; c0 < a.nchunks; c0 += KS) {
         const int ci = c0 + kg;
         const bool live = KS == 1 || ci < a.nchunks;  // (group-uniform; every wave still meets both barriers)
@@ -162,6 +155,18 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void pointconv_fused_ker
             const int ql = wave * QW + u;
             const int blk = (4 * n16 + kk) ^ (ql & 15);
             *(f32x4 *)(atile + ql * 256 + 4 * blk) = g;
+        }
+        // Request order matters: vmcnt counts in order, and hipcc waits vmcnt(0) for the loop-carried gather registers at
+        // the head of stage 1.  So (1) the first PD - 1 fragment groups of THIS chunk, whose round trip then runs under
+        // the barrier, (2) the gather of the NEXT chunk, which has all of stage 2 to land; the fragments requested during
+        // stage 2 are younger than both.  (In-kernel stamps: with the fragments requested in front of stage 1 that
+        // vmcnt(0) sat on them for ~2000 cycles a chunk.)
+        f32x4 bf[PD][NT];
+        if (live) {
+#pragma unroll
+            for (int d = 0; d < PD - 1; ++d)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bf[d][nt] = a.Lp[(((int64_t)ci * 16 + d) * a.NTT + tbase + nt) * 64 + lane];
         }
         if (ci + KS < a.nchunks) {
 #pragma unroll
@@ -182,17 +187,11 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void pointconv_fused_ker
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 acc_odd = f32x4{0.f, 0.f, 0.f, 0.f};  // MT*NT == 1: a second chain hides the 40-cycle dependent latency
-        // B fragments: a ring that runs on across the chunk boundaries (group g + PD - 1 of this chunk, or the first groups of
-        // this wave group's next chunk), so only the very first groups of the kernel wait for their L2 round trip
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            {
-                const int gg = g + PD - 1;  // compile-time after unrolling
-                const int cn = ci + KS * (gg / 16);
-                if (cn < a.nchunks) {
+            if (g + PD - 1 < 16) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bf[gg % PD][nt] = a.Lp[(((int64_t)cn * 16 + (gg % 16)) * a.NTT + tbase + nt) * 64 + lane];
-                }
+                for (int nt = 0; nt < NT; ++nt) bf[(g + PD - 1) % PD][nt] = a.Lp[(((int64_t)ci * 16 + g + PD - 1) * a.NTT + tbase + nt) * 64 + lane];
             }
             f32x4 af[MT];
 #pragma unroll
