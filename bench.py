@@ -254,12 +254,21 @@ def main():
         sync()
 
     def timed(step):
+        marks = [] if (on_gpu and os.environ.get("RPE_BENCH_STEP_TIMES")) else None  # diagnostic: per-step device times to stderr
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
+            if marks is not None:
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
             step()
+        if marks is not None:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
         barrier()
         dt = time.perf_counter() - t0
+        if marks is not None:
+            print("step ms:", [round(a.elapsed_time(b), 2) for a, b in zip(marks[:-1], marks[1:])], file=sys.stderr, flush=True)
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
