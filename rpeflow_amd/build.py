@@ -15,6 +15,9 @@ LIB = os.path.join(SRC_DIR, "librpeflow_hip.so")
 # -ffp-contract=off: KNN/FPS must round exactly where the source says ("Exact arithmetic")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17",
          "-fvisibility=hidden", "-Wno-unused-result"]
+# per source: knn.hip's matrix kernel consumes every MFMA result on the VALU right away, so its accumulators belong in
+# VGPRs (the default puts them in AGPRs and copies 16 registers per step)
+FILE_FLAGS = {"knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def sources():
@@ -49,7 +52,7 @@ def build(force=False, verbose=False):
     todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdrs)]
 
     def compile_one(src):
-        cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-I", SRC_DIR, "-c", src, "-o", _obj(src)]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-I", INCLUDE, "-I", SRC_DIR, "-c", src, "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -15,6 +15,8 @@
 // common.h; equal distances are ordered by input index.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -279,6 +281,101 @@ struct SeqPairs {
     }
 };
 
+// ---- what happens to a finished (k + 1)-entry list: the tie check, the libstdc++ restatement if it fires, the store ----
+// Ld / Li: lane r holds rank r of query qi (wave-uniform coordinates qm2 = -2 q, qq = |q|^2).
+template <int D, bool SMALL>
+__device__ __forceinline__ void finish_query(float Ld, int Li, const float (&qm2)[3], float qq, const float *__restrict__ inp,
+                                             int64_t in_sn, int64_t in_sd, int M, int k, int kk, int exact_ties, int lane, int wave,
+                                             float *seq_lds, int row_stride, int64_t out_row, int64_t *__restrict__ idx,
+                                             float *__restrict__ dist) {
+    if (exact_ties && k < RPE_WAVE) {
+        // equal neighbours among the kk best (lane r against lane r + 1)?  Then redo this query as libstdc++ would.
+        const float nxt = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Ld), __float_as_int(Ld), 0x130, 0xf, 0xf, false));  // wave_shl:1
+        // exact_ties 1: only a tie ACROSS the boundary (k-th against (k+1)-th distance) can change WHICH neighbours are
+        // returned; ties inside the top k change their order only and keep the sweep's index order.  3: any tie.
+        unsigned long long dup = __ballot(lane + 1 < kk && Ld == nxt);
+        if (exact_ties == 1) dup &= 1ull << (k - 1);
+        if (dup) {
+            if (!SMALL || k * 64 <= M) {  // std::partial_sort: __heap_select over the row in index order, then __sort_heap
+                LaneHeap h;
+                h.v = INFINITY;
+                h.i = 0;
+                float top = 0.f;
+                for (int base = 0; base < M; base += RPE_WAVE) {
+                    const int pi = base + lane;
+                    const bool valid = pi < M;
+                    float p[3] = {0.f, 0.f, 0.f};
+                    if (valid) load_point<D>(inp, in_sn, in_sd, pi, p);
+                    const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;
+                    const float d = rpe_pair_dist<D>(qm2, qq, p, pp);
+                    unsigned long long m;
+                    if (base == 0) {  // the first k elements form the heap: std::__make_heap
+                        h.v = d;
+                        h.i = lane;
+                        for (int parent = (k - 2) / 2;; --parent) {
+                            h.adjust(parent, k, h.val(parent), rpe_readlane(h.i, parent), lane);
+                            if (parent == 0) break;
+                        }
+                        top = h.val(0);
+                        m = __ballot(lane >= k && d < top);
+                    } else {
+                        m = __ballot(d < top);
+                    }
+                    while (m) {  // __pop_heap(first, middle, i) for every later element below the heap's top, in order
+                        const int l = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const float nd = rpe_readlane(d, l);
+                        if (nd < top) {
+                            h.adjust(0, k, nd, base + l, lane);
+                            top = h.val(0);
+                        }
+                    }
+                }
+                for (int last = k - 1; last >= 1; --last) {  // std::__sort_heap
+                    const float lv = h.val(last);
+                    const int li = rpe_readlane(h.i, last);
+                    h.move(last, 0, lane);
+                    h.adjust(0, last, lv, li, lane);
+                }
+                Ld = h.v;
+                Li = h.i;
+            } else {  // std::nth_element(begin, begin + k - 1, end) + std::sort(begin, begin + k - 1) by one lane
+                SeqPairs sp{seq_lds + (size_t)wave * 2 * row_stride,
+                            reinterpret_cast<int *>(seq_lds + (size_t)wave * 2 * row_stride + row_stride)};
+                for (int base = 0; base < M; base += RPE_WAVE) {
+                    const int pi = base + lane;
+                    if (pi < M) {
+                        float p[3] = {0.f, 0.f, 0.f};
+                        load_point<D>(inp, in_sn, in_sd, pi, p);
+                        sp.v[pi] = rpe_pair_dist<D>(qm2, qq, p, rpe_sqnorm<D>(p));
+                        sp.i[pi] = pi;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                    int lg = 0;
+                    for (int t = M; t > 1; t >>= 1) ++lg;
+                    sp.introselect(0, k - 1, M, 2 * lg);
+                    sp.sort(0, k - 1);
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < k) {
+                    Ld = sp.v[lane];
+                    Li = sp.i[lane];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (lane < k) {
+        const int64_t o = out_row * k + lane;
+        idx[o] = (int64_t)Li;
+        if (dist) dist[o] = Ld;
+    }
+}
+
 // Several independent searches of one (B, D, k) in one launch: blockIdx.z picks the job.  The PointConv pyramid's five
 // neighbour searches depend on the sampled coordinates only (pointconv.py:46 per level); launched together, the small
 // levels fill the CUs the big one leaves idle instead of queueing behind it.
@@ -399,92 +496,365 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
     for (int j = 0; j < QW; ++j) {
         const int qi = qbase + j;
         if (qi >= Q) continue;  // wave-uniform
-        if (exact_ties && k < RPE_WAVE) {
-            // equal neighbours among the kk best (lane r against lane r + 1)?  Then redo this query as libstdc++ would.
-            const float nxt = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Ld[j]), __float_as_int(Ld[j]), 0x130, 0xf, 0xf, false));  // wave_shl:1
-            // exact_ties 1: only a tie ACROSS the boundary (k-th against (k+1)-th distance) can change WHICH neighbours are
-            // returned; ties inside the top k change their order only and keep the sweep's index order.  3: any tie.
-            unsigned long long dup = __ballot(lane + 1 < kk && Ld[j] == nxt);
-            if (exact_ties == 1) dup &= 1ull << (k - 1);
-            if (dup) {
-                if (!SMALL || k * 64 <= M) {  // std::partial_sort: __heap_select over the row in index order, then __sort_heap
-                    LaneHeap h;
-                    h.v = INFINITY;
-                    h.i = 0;
-                    float top = 0.f;
-                    for (int base = 0; base < M; base += RPE_WAVE) {
-                        const int pi = base + lane;
-                        const bool valid = pi < M;
-                        float p[3] = {0.f, 0.f, 0.f};
-                        if (valid) load_point<D>(inp, in_sn, in_sd, pi, p);
-                        const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;
-                        const float d = rpe_pair_dist<D>(qs.qm2[j], qs.qq[j], p, pp);
-                        unsigned long long m;
-                        if (base == 0) {  // the first k elements form the heap: std::__make_heap
-                            h.v = d;
-                            h.i = lane;
-                            for (int parent = (k - 2) / 2;; --parent) {
-                                h.adjust(parent, k, h.val(parent), rpe_readlane(h.i, parent), lane);
-                                if (parent == 0) break;
-                            }
-                            top = h.val(0);
-                            m = __ballot(lane >= k && d < top);
-                        } else {
-                            m = __ballot(d < top);
-                        }
-                        while (m) {  // __pop_heap(first, middle, i) for every later element below the heap's top, in order
-                            const int l = __builtin_ctzll(m);
-                            m &= m - 1;
-                            const float nd = rpe_readlane(d, l);
-                            if (nd < top) {
-                                h.adjust(0, k, nd, base + l, lane);
-                                top = h.val(0);
-                            }
-                        }
-                    }
-                    for (int last = k - 1; last >= 1; --last) {  // std::__sort_heap
-                        const float lv = h.val(last);
-                        const int li = rpe_readlane(h.i, last);
-                        h.move(last, 0, lane);
-                        h.adjust(0, last, lv, li, lane);
-                    }
-                    Ld[j] = h.v;
-                    Li[j] = h.i;
-                } else {  // std::nth_element(begin, begin + k - 1, end) + std::sort(begin, begin + k - 1) by one lane
-                    SeqPairs sp{seq_lds + (size_t)wave * 2 * row_stride,
-                                reinterpret_cast<int *>(seq_lds + (size_t)wave * 2 * row_stride + row_stride)};
-                    for (int base = 0; base < M; base += RPE_WAVE) {
-                        const int pi = base + lane;
-                        if (pi < M) {
-                            float p[3] = {0.f, 0.f, 0.f};
-                            load_point<D>(inp, in_sn, in_sd, pi, p);
-                            sp.v[pi] = rpe_pair_dist<D>(qs.qm2[j], qs.qq[j], p, rpe_sqnorm<D>(p));
-                            sp.i[pi] = pi;
-                        }
-                    }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == 0) {
-                        int lg = 0;
-                        for (int t = M; t > 1; t >>= 1) ++lg;
-                        sp.introselect(0, k - 1, M, 2 * lg);
-                        sp.sort(0, k - 1);
-                    }
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < k) {
-                        Ld[j] = sp.v[lane];
-                        Li[j] = sp.i[lane];
-                    }
-                    __builtin_amdgcn_wave_barrier();
+        finish_query<D, SMALL>(Ld[j], Li[j], qs.qm2[j], qs.qq[j], inp, in_sn, in_sd, M, k, kk, exact_ties, lane, wave, seq_lds, row_stride,
+                               (int64_t)b * Q + qi, idx, dist);
+    }
+}
+
+// ---- k >= 2 on large clouds: the distances on the matrix pipe -----------------------------------------------------------
+// squared_distance IS a matrix product (wrapper.py:49: -2 * matmul(xyz1, xyz2^T), then + |xyz1|^2, then + |xyz2|^2), and
+// v_mfma_f32_16x16x4_f32 accumulates its four k-slots as a sequential fp32 fma chain from C (measured bit for bit against
+// fmaf on this chip), so with A[p][0..3] = (px, py, pz, 1) and B[0..3][q] = (-2 qx, -2 qy, -2 qz, |q|^2) one instruction
+// yields fl(fl(-2 q.p) + |q|^2) for 16 points x 16 queries exactly as rpe_pair_dist computes it; the four-block
+// v_mfma_f32_16x16x1_f32 with A = |p|^2, B = 1 then adds |p|^2 to four such tiles (64 points) at once.  5 matrix
+// instructions replace 7 VALU instructions per 64 pairs x 16.
+//
+// A wave owns 16 queries; the block's four waves share the cloud, which streams through an LDS ring (LDS-DMA, counted
+// waits).  D layout: lane (g = l >> 4, c = l & 15) works for query c; register 4 b + r holds point 16 b + 4 g + r of the
+// 64-point step.  A lane therefore sees one query and a fixed quarter of the cloud, and the selection
+// needs no cross-lane traffic in the sweeps -- threshold + collect instead of sorted insertion:
+//   pass A  running minimum per register: for every query 64 minima over 64 DISJOINT subsets of the cloud (4 lanes x 16
+//           registers); their kk-th smallest bounds the kk-th smallest distance from above (about the 1.2 kk-th smallest
+//           in practice).  Found by a bitonic sort of the 64 values where they are;
+//   pass B  same sweep; every lane appends the points below the bound to its own short list in LDS, branch-free: the entry
+//           is always written, the list only grows on a hit.  ~1.2 kk entries per query over its four lanes;
+//   then    per query: the entries of its four lists are ranked by (distance, index) with a counting loop, permuted into
+//           the "lane r = rank r" form and handed to finish_query (tie check, libstdc++ restatement, store) exactly as the
+//           insertion kernel does.  A lane list that fills up (15 entries: heavy ties) sends the query to the serial sweep.
+typedef float knn_f32x4 __attribute__((ext_vector_type(4)));
+typedef float knn_f32x8 __attribute__((ext_vector_type(8)));
+typedef float knn_f32x16 __attribute__((ext_vector_type(16)));
+// v_min_f32 as it is (fminf adds a canonicalising v_max per operand; NaN distances are not modelled)
+__device__ __forceinline__ float knn_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float knn_min3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+constexpr int kMq = 16;                   // queries per wave
+constexpr int kRow = 80;                  // floats per coordinate row of a ring slot: 64 + 16, so the four k-slots of an A fragment hit different banks
+constexpr int kSlotFloats = 3 * kRow;
+constexpr int kLaneList = 16;             // entries per lane list (15 usable: the slot after the last entry is scratch)
+#ifndef RPE_KNN_MATRIX_MIN_M
+#define RPE_KNN_MATRIX_MIN_M 1024
+#endif
+constexpr int kMatrixMinM = RPE_KNN_MATRIX_MIN_M;  // below this the fixed costs (bound sort, ranking) outweigh the sweep
+constexpr long kMatrixMinQueries = 16384;          // B * Q: 16 queries a wave, and fewer than one wave per SIMD are latency-bound
+constexpr int kChunkSteps = 4;            // a chunk = 4 steps of 64 points; wave w of the block loads step w of every chunk
+#ifndef RPE_KNN_CHUNKS
+#define RPE_KNN_CHUNKS 4
+#define RPE_KNN_AHEAD 2
+#endif
+constexpr int kChunks = RPE_KNN_CHUNKS;      // ring depth in chunks (a power of two)
+constexpr int kChunksAhead = RPE_KNN_AHEAD;  // chunk t + 2 is requested before chunk t is used (kChunks >= kChunksAhead + 2)
+
+struct MfmaBlockLds {
+    float ring[kChunks][kChunkSteps][kSlotFloats];  // the cloud streams through here once per pass, shared by the block's four waves
+    float ones[kRow];
+    int count[kWavesPerBlock][RPE_WAVE];
+    unsigned long long list[kWavesPerBlock][kLaneList][RPE_WAVE];  // entry s of lane l at [s][l] (lane-interleaved: no bank conflicts): (index << 32) | distance bits
+};
+
+// one query, the insertion sweep with plain loads (the fallback of the matrix kernel; not a fast path)
+template <int D>
+__device__ void serial_select(const float *__restrict__ inp, int64_t in_sn, int64_t in_sd, int M, const float (&qm2)[3], float qq,
+                              int kk, int lane, float &Ld, int &Li) {
+    Ld = INFINITY;
+    Li = 0;
+    float tau = INFINITY;
+    for (int base = 0; base < M; base += RPE_WAVE) {
+        const bool valid = base + lane < M;
+        float p[3] = {0.f, 0.f, 0.f};
+        if (valid) load_point<D>(inp, in_sn, in_sd, base + lane, p);
+        const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;
+        const float d = rpe_pair_dist<D>(qm2, qq, p, pp);
+        unsigned long long m = __ballot(d < tau);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const float nd = rpe_readlane(d, l);
+            if (nd < tau) {
+                const int ni = base + l;
+                const float upd = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Ld), __float_as_int(Ld), 0x138, 0xf, 0xf, false));
+                const int upi = __builtin_amdgcn_update_dpp(Li, Li, 0x138, 0xf, 0xf, false);
+                const bool gt = nd < Ld;
+                const bool gtp = (lane > 0) && (nd < upd);
+                Ld = gt ? (gtp ? upd : nd) : Ld;
+                Li = gt ? (gtp ? upi : ni) : Li;
+                tau = rpe_readlane(Ld, kk - 1);
+            }
+        }
+    }
+}
+
+template <int D>
+struct MfmaSweep {
+    const float *inp;
+    int64_t sn, sd;
+    int M, lane, wave;
+    MfmaBlockLds *L;
+    float qb;            // B fragment (queries): lane (kq = l >> 4, col = l & 15): -2 q[kq] of query col, |q|^2 for kq = 3
+    int aoff;            // A fragment (points) source of this lane: float offset inside a step's slot, or -1: the row of ones
+
+    // LDS-DMA, no staging registers; every request issues exactly D loads (lanes / steps past the end re-read the last
+    // point), so the counted waits are exact
+    __device__ __forceinline__ void request(int chunk) const {
+        const int base = (chunk * kChunkSteps + wave) * RPE_WAVE;
+        const int pi = min(base + lane, M - 1);
+        const float *src = inp + (int64_t)pi * sn;
+        float *dst = L->ring[chunk & (kChunks - 1)][wave];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            __builtin_amdgcn_global_load_lds((knn_glb_void_t *)(src + d * sd), (knn_lds_void_t *)(dst + d * kRow), 4, 0, 0);
+    }
+    // (raw s_barrier: __syncthreads() would drain vmcnt(0), i.e. wait for the chunks just requested)
+    __device__ __forceinline__ void start() const {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // nobody still reads the ring of the previous pass
+#pragma unroll
+        for (int t = 0; t < kChunksAhead; ++t) request(t);
+    }
+    // chunk t is complete in LDS for the whole block; chunk t + kChunksAhead is on its way
+    __device__ __forceinline__ void acquire(int chunk) const {
+        request(chunk + kChunksAhead);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kChunksAhead * D) : "memory");
+    }
+    __device__ __forceinline__ void finish() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // distances of the 64 points of step `st` of `chunk` to the 16 queries (layout above)
+    __device__ __forceinline__ knn_f32x16 step(int chunk, int st) const {
+        const float *slot = L->ring[chunk & (kChunks - 1)][st];
+        const int base = (chunk * kChunkSteps + st) * RPE_WAVE;
+        const float *row = slot + lane;
+        float p[3];
+        p[0] = row[0];
+        p[1] = D > 1 ? row[kRow] : 0.f;
+        p[2] = D > 2 ? row[2 * kRow] : 0.f;
+        const float pp = base + lane < M ? rpe_sqnorm<D>(p) : INFINITY;  // past the end: every distance +inf
+        const float *ap = aoff >= 0 ? slot + aoff : L->ones + (lane & 15);
+        const knn_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const knn_f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], qb, zero, 0, 0, 0);
+        const knn_f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16], qb, zero, 0, 0, 0);
+        const knn_f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[32], qb, zero, 0, 0, 0);
+        const knn_f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[48], qb, zero, 0, 0, 0);
+        const knn_f32x8 d01 = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const knn_f32x8 d23 = __builtin_shufflevector(d2, d3, 0, 1, 2, 3, 4, 5, 6, 7);
+        const knn_f32x16 acc = __builtin_shufflevector(d01, d23, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        return __builtin_amdgcn_mfma_f32_16x16x1f32(pp, 1.0f, acc, 0, 0, 0);
+    }
+};
+
+// compare-exchange: afterwards x <= y if asc, x >= y otherwise (equal values: either way)
+__device__ __forceinline__ void knn_cex(float &x, float &y, bool asc) {
+    const bool swap = (y < x) == asc;
+    const float nx = swap ? y : x, ny = swap ? x : y;
+    x = nx;
+    y = ny;
+}
+
+// bitonic sort, ascending, of the 64 values {v[i] of lanes c, 16 + c, 32 + c, 48 + c}: element e = 16 g + i, for all 16 c at once
+__device__ __forceinline__ void bitonic64_cols(knn_f32x16 &v, int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int s = 2; s <= 64; s <<= 1) {
+#pragma unroll
+        for (int j = s >> 1; j > 0; j >>= 1) {
+            if (j < 16) {  // partner register i ^ j of the same lane
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (i & j) continue;
+                    const bool asc = s < 16 ? (i & s) == 0 : s == 16 ? (g & 1) == 0 : s == 32 ? (g & 2) == 0 : true;  // bit s of e = 16 g + i
+                    float x = v[i], y = v[i | j];
+                    knn_cex(x, y, asc);
+                    v[i] = x;
+                    v[i | j] = y;
+                }
+            } else {  // partner lane l ^ j (j = 16: g ^ 1, j = 32: g ^ 2)
+                const bool lower = (lane & j) == 0;
+                const bool asc = s == 32 ? (g & 2) == 0 : true;
+                const bool keep_min = lower == asc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float x = v[i];
+                    const float y = __shfl_xor(x, j);
+                    v[i] = ((y < x) == keep_min) ? y : x;
                 }
             }
         }
-        if (lane < k) {
-            const int64_t o = ((int64_t)b * Q + qi) * k + lane;
-            idx[o] = (int64_t)Li[j];
-            if (dist) dist[o] = Ld[j];
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_kernel(KnnJobs jobs, int k, int exact_ties) {
+    __shared__ MfmaBlockLds lds;
+    const rpe_knn_job &J = jobs.job[blockIdx.z];
+    const float *__restrict__ inp = J.input;
+    const float *__restrict__ qry = J.query;
+    const int64_t in_sb = J.in_sb, in_sn = J.in_sn, in_sd = J.in_sd, q_sb = J.q_sb, q_sn = J.q_sn, q_sd = J.q_sd;
+    const int M = J.M, Q = J.Q;
+    int64_t *__restrict__ idx = J.idx;
+    float *__restrict__ dist = J.dist;
+    const int lane = rpe_lane(), g = lane >> 4, c = lane & 15;
+    const int wave = rpe_uniform((int)(threadIdx.x >> 6));
+    const int b = blockIdx.y;
+    if ((int)blockIdx.x * kWavesPerBlock * kMq >= Q) return;  // whole block beyond this job's queries (block-uniform)
+    const int qbase = (blockIdx.x * kWavesPerBlock + wave) * kMq;  // a wave beyond Q still loads its share of the cloud
+    inp += (int64_t)b * in_sb;
+    qry += (int64_t)b * q_sb;
+    if (threadIdx.x < kRow) lds.ones[threadIdx.x] = 1.0f;
+
+    MfmaSweep<D> sw;
+    sw.inp = inp, sw.sn = in_sn, sw.sd = in_sd, sw.M = M, sw.lane = lane, sw.wave = wave, sw.L = &lds;
+    float qv[3];  // lane c of every group: query qbase + c
+    load_point<D>(qry, q_sn, q_sd, min(qbase + c, Q - 1), qv);
+    sw.qb = g == 0 ? -2.0f * qv[0] : g == 1 ? -2.0f * qv[1] : g == 2 ? -2.0f * qv[2] : rpe_sqnorm<D>(qv);  // (a missing dimension is 1 * 0)
+    sw.aoff = g < D ? g * kRow + c : -1;
+    const int kk = (exact_ties && k < M && k < RPE_WAVE) ? k + 1 : k;
+    const int n_chunks = (M + kChunkSteps * RPE_WAVE - 1) / (kChunkSteps * RPE_WAVE);
+
+    // ---- pass A: 64 minima per query over disjoint subsets, their kk-th smallest
+    knn_f32x16 lm;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lm[i] = INFINITY;
+    sw.start();
+    for (int t = 0; t < n_chunks; ++t) {
+        sw.acquire(t);
+#pragma unroll
+        for (int st = 0; st < kChunkSteps; ++st) {
+            const knn_f32x16 acc = sw.step(t, st);  // (steps past the end give +inf)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lm[i] = knn_min(lm[i], acc[i]);
         }
+    }
+    sw.finish();
+    bitonic64_cols(lm, lane);
+    float tau;
+    {
+        const int ei = (kk - 1) & 15;
+        float sel = lm[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) sel = ei == i ? lm[i] : sel;
+        const float bound = __shfl(sel, (((kk - 1) >> 4) << 4) | c);
+        // strict comparison below: step to the next float up so that d == bound still passes
+        const int bits = __float_as_int(bound);
+        tau = !(bound < INFINITY) ? INFINITY : bound == 0.f ? __int_as_float(1) : bound > 0.f ? __int_as_float(bits + 1) : __int_as_float(bits - 1);
+    }
+
+    // ---- pass B: every lane collects the points below its query's bound (index order inside a lane)
+    // The entry is ALWAYS written to the slot behind the lane's last one and the list only grows on a hit: no divergent
+    // code, no cross-lane traffic; a 16-point tile without a hit in any lane is skipped as a whole (one v_min3 + v_min).
+    const unsigned list_base = (unsigned)(uintptr_t)&lds.list[wave][0][lane];  // LDS byte address of this lane's slot 0
+    int cnt = 0;
+    auto collect = [&](const knn_f32x16 &acc, int base) {
+        float m4[4];
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) m4[bb] = knn_min(knn_min3(acc[4 * bb], acc[4 * bb + 1], acc[4 * bb + 2]), acc[4 * bb + 3]);
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            if (__ballot(m4[bb] < tau) == 0ull) continue;  // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[4 * bb + r];
+                const unsigned addr = list_base + (unsigned)min(cnt, kLaneList - 1) * (unsigned)(RPE_WAVE * 8);
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" ::"v"(addr), "v"(d), "v"(base + 16 * bb + r) : "memory");
+                cnt += d < tau ? 1 : 0;
+            }
+        }
+    };
+    sw.start();
+    for (int t = 0; t < n_chunks; ++t) {
+        sw.acquire(t);
+        // the matrix instructions of the next step are issued before the current step's results are looked at
+        knn_f32x16 cur = sw.step(t, 0);
+#pragma unroll
+        for (int st = 0; st < kChunkSteps; ++st) {
+            knn_f32x16 nxt = cur;
+            if (st + 1 < kChunkSteps) nxt = sw.step(t, st + 1);
+            collect(cur, (t * kChunkSteps + st) * RPE_WAVE + 4 * g);
+            cur = nxt;
+        }
+    }
+    sw.finish();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the asm stores above are invisible to the compiler's counters
+    lds.count[wave][lane] = cnt;
+
+    // ---- rank the collected entries, all 16 queries at once.  key = (orderable distance bits, index): the order the
+    // insertion sweep produces.  (1) every lane moves its entries to a dense per-query array; (2) lane (g, c) takes entries
+    // g, g + 4, ... of query c and counts the entries of that query with a smaller key; (3) rank r goes to out[c][r].  dense
+    // and out both live in the list memory (a lane holds what it still needs in registers; one wave, LDS in order).
+    const int have = min(cnt, kLaneList - 1);
+    int have_g[4];
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) have_g[gg] = min(lds.count[wave][16 * gg + c], kLaneList - 1);
+    const unsigned long long full_lanes = __ballot(cnt >= kLaneList);
+    const int n_query = have_g[0] + have_g[1] + have_g[2] + have_g[3];  // (<= 60)
+    int dense_at = 0;  // entries of this query in the lanes before this one
+#pragma unroll
+    for (int gg = 0; gg < 3; ++gg) dense_at += gg < g ? have_g[gg] : 0;
+    int max_n = n_query;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) max_n = max(max_n, __shfl_xor(max_n, off));
+    max_n = rpe_uniform(max_n);
+    unsigned long long *const dense = &lds.list[wave][0][0] + c * RPE_WAVE;  // this lane's query: [64]
+    {
+        unsigned long long own[kLaneList - 1];
+#pragma unroll
+        for (int sl = 0; sl < kLaneList - 1; ++sl) own[sl] = lds.list[wave][sl][lane];
+#pragma unroll
+        for (int sl = 0; sl < kLaneList - 1; ++sl)
+            if (sl < have) dense[dense_at + sl] = own[sl];
+    }
+    auto key_of = [](unsigned long long e) {  // (index << 32 | distance bits) -> (orderable distance << 32 | index)
+        const unsigned db = (unsigned)e, ix = (unsigned)(e >> 32);
+        const unsigned ord = db ^ (((int)db >> 31) | 0x80000000u);  // distances are never -0 (|p|^2, |q|^2 >= +0)
+        return ((unsigned long long)ord << 32) | ix;
+    };
+    auto rank_all = [&](auto ns_tag) {
+        constexpr int NS = decltype(ns_tag)::value;  // entries per lane: ceil(max_n / 4)
+        unsigned long long mine_e[NS], mine_k[NS];
+        int rank[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            const int at = g + 4 * j;
+            mine_e[j] = dense[at & (RPE_WAVE - 1)];
+            mine_k[j] = at < n_query ? key_of(mine_e[j]) : ~0ull;
+            rank[j] = 0;
+        }
+        for (int o = 0; o < max_n; ++o) {
+            const unsigned long long ok = o < n_query ? key_of(dense[o]) : ~0ull;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) rank[j] += ok < mine_k[j] ? 1 : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+            if (g + 4 * j < n_query) dense[rank[j]] = mine_e[j];  // ranks are a permutation of 0 .. n_query - 1
+    };
+    if (max_n <= 16) rank_all(std::integral_constant<int, 4>{});
+    else if (max_n <= 32) rank_all(std::integral_constant<int, 8>{});
+    else rank_all(std::integral_constant<int, 16>{});
+
+    for (int q = 0; q < kMq; ++q) {
+        const int qi = qbase + q;
+        if (qi >= Q) break;  // wave-uniform
+        float qc[3], qm2[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) qc[d] = rpe_readlane(qv[d], q);
+        const float qq = rpe_sqnorm<D>(qc);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) qm2[d] = -2.0f * qc[d];
+        float Ld;
+        int Li;
+        const int n = rpe_readlane(n_query, q);
+        if (((full_lanes >> q) & 0x0001000100010001ull) != 0ull || n > RPE_WAVE) {  // a lane list of this query filled up
+            serial_select<D>(inp, in_sn, in_sd, M, qm2, qq, kk, lane, Ld, Li);
+        } else {
+            const unsigned long long e = lds.list[wave][0][q * RPE_WAVE + lane];
+            Ld = lane < n ? __int_as_float((int)(unsigned)e) : INFINITY;
+            Li = lane < n ? (int)(e >> 32) : 0;
+        }
+        finish_query<D, false>(Ld, Li, qm2, qq, inp, in_sn, in_sd, M, k, kk, exact_ties, lane, wave, nullptr, 0, (int64_t)b * Q + qi, idx, dist);
     }
 }
 
@@ -613,6 +983,34 @@ int launch_knn_d(int qw, const KnnJobs &jobs, int njobs, int max_q, int min_m, i
     }
 }
 
+// the jobs of one launch group (all through the insertion / lane-minimum kernels, or all through the matrix kernel)
+int launch_group(const rpe_knn_job *const *jobs, int njobs, bool matrix, int B, int D, int k, int tie_mode, hipStream_t st) {
+    KnnJobs packed;
+    int max_q = 0, min_m = 0x7fffffff, max_m = 0;
+    long total_q = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const rpe_knn_job &j = *jobs[i];
+        packed.job[i] = j;
+        max_q = j.Q > max_q ? j.Q : max_q;
+        min_m = j.M < min_m ? j.M : min_m;
+        max_m = j.M > max_m ? j.M : max_m;
+        total_q += j.Q;
+    }
+    if (max_q == 0) return 0;
+    if (matrix) {
+        const int per_block = kWavesPerBlock * kMq;
+        dim3 grid((max_q + per_block - 1) / per_block, B, njobs), block(kWavesPerBlock * RPE_WAVE);
+        if (D == 3) hipLaunchKernelGGL(knn_mfma_kernel<3>, grid, block, 0, st, packed, k, tie_mode);
+        else if (D == 2) hipLaunchKernelGGL(knn_mfma_kernel<2>, grid, block, 0, st, packed, k, tie_mode);
+        else hipLaunchKernelGGL(knn_mfma_kernel<1>, grid, block, 0, st, packed, k, tie_mode);
+        return rpe_launch_status();
+    }
+    const int qw = pick_qw(B, (int)total_q);
+    if (D == 3) return launch_knn_d<3>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
+    if (D == 2) return launch_knn_d<2>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
+    return launch_knn_d<1>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
+}
+
 }  // namespace
 
 RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, int tie_mode, rpe_stream_t stream) {
@@ -620,24 +1018,22 @@ RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int 
     if (tie_mode != RPE_KNN_TIES_TORCH && tie_mode != RPE_KNN_TIES_SET && tie_mode != RPE_KNN_TIES_INDEX) return RPE_EINVAL;
     if (k > RPE_WAVE) return RPE_EUNSUPPORTED;
     if (B > 65535) return RPE_EUNSUPPORTED;
-    KnnJobs packed;
-    int max_q = 0, min_m = 0x7fffffff, max_m = 0;
-    long total_q = 0;
+    // k >= 2, a cloud of at least kMatrixMinM points in topk's partial_sort regime (64 k <= M), enough queries: the matrix kernel
+    const rpe_knn_job *big[RPE_KNN_MAX_JOBS], *rest[RPE_KNN_MAX_JOBS];
+    int nbig = 0, nrest = 0;
     for (int i = 0; i < njobs; ++i) {
         const rpe_knn_job &j = jobs[i];
         if (!j.input || !j.query || !j.idx || j.M <= 0 || j.Q < 0 || k > j.M) return RPE_EINVAL;
-        packed.job[i] = j;
-        max_q = j.Q > max_q ? j.Q : max_q;
-        min_m = j.M < min_m ? j.M : min_m;
-        max_m = j.M > max_m ? j.M : max_m;
-        total_q += j.Q;
+        if (k >= 2 && k < RPE_WAVE && j.M >= kMatrixMinM && (long)j.M >= 64L * k && (long)B * j.Q >= kMatrixMinQueries) big[nbig++] = &j;
+        else rest[nrest++] = &j;
     }
-    if (B == 0 || max_q == 0) return 0;
+    if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    const int qw = pick_qw(B, (int)total_q);
-    if (D == 3) return launch_knn_d<3>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
-    if (D == 2) return launch_knn_d<2>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
-    return launch_knn_d<1>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
+    if (nbig) {
+        const int rc = launch_group(big, nbig, true, B, D, k, tie_mode, st);
+        if (rc) return rc;
+    }
+    return nrest ? launch_group(rest, nrest, false, B, D, k, tie_mode, st) : 0;
 }
 
 RPE_API int rpe_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,

@@ -90,6 +90,25 @@ def test_knn_ragged_shapes(B, M, Q, D, k):
     assert_bits_equal(dist.cpu().numpy(), od)
 
 
+@pytest.mark.parametrize("B,M,Q,D,k", [
+    # rpe_knn_multi sends k >= 2, M >= 1024, 64 k <= M, B * Q >= 16384 to the matrix kernel (knn_mfma_kernel: distances on
+    # v_mfma_f32_16x16x4_f32, threshold + collect): ragged M (not a multiple of 256 / 64) and Q (not a multiple of 64 / 16),
+    # every D, k up to 63
+    (2, 1500, 8200, 3, 16), (1, 4100, 16390, 3, 3), (3, 1024, 5500, 2, 5), (2, 1030, 8192, 1, 2), (1, 2000, 16384, 3, 31),
+    (1, 4100, 16384, 3, 63), (8, 8192, 2048, 3, 16),
+])
+def test_knn_matrix_kernel_shapes(B, M, Q, D, k):
+    r = I.rng(7300 + M + Q + k)
+    inp, qry = I.ids_cloud(r, B, M, D), I.ids_cloud(r, B, Q, D)
+    idx, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k)
+    oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert_bits_equal(dist.cpu().numpy(), od)
+    # channel-first views, as the model passes them
+    cf = ops.k_nearest_neighbor(dev(inp.transpose(0, 2, 1)), dev(qry.transpose(0, 2, 1)), k)
+    assert np.array_equal(cf.cpu().numpy(), oi)
+
+
 def test_knn_duplicates_and_strided_views():
     r = I.rng(7100)
     base = I.unit_cloud(r, 2, 150, 3)
@@ -302,6 +321,13 @@ def test_knn_multi_equals_separate_calls():
     got = W.k_nearest_neighbor_multi(pairs, 16)
     for (inp, qry), g in zip(pairs, got):
         assert torch.equal(g, ops.k_nearest_neighbor(inp, qry, 16))
+    # a launch whose jobs split between the matrix kernel (M >= 1024, B * Q >= 16384) and the insertion kernel
+    big = I.ids_cloud(r, 8, 4096)
+    lv = [dev(big[:, :n].copy()) for n in (4096, 2048, 1024, 300)]
+    mixed = [(lv[0], lv[1]), (lv[1], lv[2]), (lv[2], lv[3]), (lv[0], lv[0])]
+    for (inp, qry), g in zip(mixed, W.k_nearest_neighbor_multi(mixed, 16)):
+        assert torch.equal(g, ops.k_nearest_neighbor(inp, qry, 16))
+        assert np.array_equal(g[:2, :64].cpu().numpy(), O.k_nearest_neighbor(inp[:2].cpu().numpy(), qry[:2, :64].cpu().numpy(), 16))
     cf = [(a.transpose(1, 2).contiguous(), b.transpose(1, 2).contiguous()) for a, b in pairs]  # channel-first layout, k = 1 kernel
     for (inp, qry), g in zip(cf, W.k_nearest_neighbor_multi(cf, 1)):
         assert torch.equal(g, ops.k_nearest_neighbor(inp, qry, 1))
@@ -313,7 +339,10 @@ def test_knn_multi_equals_separate_calls():
                                        # k - 1 > 16: topk's std::sort is an introsort there; 32 is the reference extension's cap
                                        # (k_nearest_neighbor_kernel.cu:24,68); both regimes (k * 64 <= M or not)
                                        (2, 700, 200, 3, 32), (1, 2048, 300, 3, 32), (1, 3000, 100, 3, 24), (1, 1500, 64, 2, 20),
-                                       (1, 4000, 50, 3, 63), (1, 5000, 40, 3, 40), (1, 40, 40, 3, 40)])
+                                       (1, 4000, 50, 3, 63), (1, 5000, 40, 3, 40), (1, 40, 40, 3, 40),
+                                       # enough queries for the matrix kernel: on a lattice nearly every lane list overflows (serial
+                                       # sweep per query) or ties (libstdc++ restatement); M ragged and a multiple of the 256-point chunk
+                                       (2, 1500, 8200, 3, 17), (1, 2048, 16384, 3, 16), (4, 1100, 4100, 2, 3)])
 def test_knn_equal_distances_follow_torch_topk(B, M, Q, D, k):
     """Points on a coarse integer lattice: most distances tie.  Indices AND their order must be what the reference's
     matmul + torch.topk gives on the CPU, in both of topk's regimes (k * 64 <= M: partial_sort; else nth_element + sort)."""
