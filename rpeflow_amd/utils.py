@@ -376,6 +376,7 @@ def ids_flow_inverse(xyz, flow, intrinsics, persp, paral):
 _MLP_PAIRS = [(1, 1), (1, 2), (2, 4), (4, 6), (6, 8), (8, 12), (8, 4)]
 _MLP_SINGLE = [1, 2, 4, 6, 8, 12]
 _ACT_CODE = {None: 0, "relu": 1, "leaky_relu": 2}
+_MLP_MAX_WEIGHTS = (16384, 45000)  # one layer, two layers: beyond, the library GEMM + epilogue is as fast or faster (see _mlp_pack)
 
 
 def _mlp_pack(blocks):
@@ -391,10 +392,11 @@ def _mlp_pack(blocks):
     convs = [blk.conv_fn for blk in blocks]
     plain = all(c.kernel_size == (1,) and c.stride == (1,) and c.padding == (0,) and c.groups == 1 for c in convs)
     epis = [blk._epilogue() for blk in blocks]
-    # every wave streams all the weights for its 16 points: worth it for the small layers only (a 273 -> 192 layer on
-    # 1024 points took 71 us against ~20 for the library GEMM + epilogue)
+    # every workgroup streams all the weights for its 16 points: worth it for the small layers only.  Measured, B = 4,
+    # fused vs library GEMM + epilogue launches: 128 -> 128 -> 64 7 vs 14 us, 195 -> 128 -> 128 10 vs 14, 64 -> 64 4 vs 7,
+    # 192 -> 128 and 273 -> 192 level, 192 -> 192 -> 128 (no instantiation: two launches) 31 vs 14.
     weights = sum(c.in_channels * c.out_channels for c in convs)
-    if plain and all(e is not None for e in epis) and weights <= (25000 if len(blocks) == 2 else 16384):
+    if plain and all(e is not None for e in epis) and weights <= _MLP_MAX_WEIGHTS[len(blocks) - 1]:
         need = [(c.out_channels + 15) // 16 for c in convs]
         if len(blocks) == 2:
             fits = [p for p in _MLP_PAIRS if p[0] >= need[0] and p[1] >= need[1]]
