@@ -30,8 +30,8 @@ for op in pointconv knn16 knn3 corr3d; do
 done
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_summary.py pointconv_fused_kernel $OUT/pointconv_pmc.json "PointConvNoSampling 195->128, B=4, N=4096 (tools/prof_ops.py pointconv 6)" /tmp/pmc_pointconv_a /tmp/pmc_pointconv_b /tmp/pmc_pointconv_c
-python3 tools/pmc_summary.py "knn_select_kernel" $OUT/knn16_pmc.json "k_nearest_neighbor 3-D k=16, B=4, 8192 -> 4096 (tools/prof_ops.py knn16 6)" /tmp/pmc_knn16_a /tmp/pmc_knn16_b /tmp/pmc_knn16_c
-python3 tools/pmc_summary.py "knn_select_kernel" $OUT/knn3_pmc.json "k_nearest_neighbor 3-D k=3, B=4, 4096 -> 4096 (tools/prof_ops.py knn3 6)" /tmp/pmc_knn3_a /tmp/pmc_knn3_b /tmp/pmc_knn3_c
+python3 tools/pmc_summary.py "knn_mfma_kernel" $OUT/knn16_pmc.json "k_nearest_neighbor 3-D k=16, B=4, 8192 -> 4096 (tools/prof_ops.py knn16 6)" /tmp/pmc_knn16_a /tmp/pmc_knn16_b /tmp/pmc_knn16_c
+python3 tools/pmc_summary.py "knn_mfma_kernel" $OUT/knn3_pmc.json "k_nearest_neighbor 3-D k=3, B=4, 4096 -> 4096 (tools/prof_ops.py knn3 6)" /tmp/pmc_knn3_a /tmp/pmc_knn3_b /tmp/pmc_knn3_c
 python3 tools/pmc_summary.py corr3d_cost_kernel $OUT/corr3d_cost_pmc.json "Correlation3D cost kernel, B=4, N=4096, C=32 (tools/prof_ops.py corr3d 6)" /tmp/pmc_corr3d_a /tmp/pmc_corr3d_b /tmp/pmc_corr3d_c
 # 5. corr microbench PMC (kernel of roofline_corr)
 for pass in a b c; do
