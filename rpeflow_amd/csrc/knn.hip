@@ -162,7 +162,7 @@ struct SeqPairs {
             }
         }
     }
-    __device__ int partition_pivot(int first, int last) {  // std::__unguarded_partition_pivot
+    __device__ void median_to_first(int first, int last) {  // std::__move_median_to_first(first, first + 1, mid, last - 1)
         const int mid = first + (last - first) / 2, a = first + 1, b = mid, c = last - 1;
         if (v[a] < v[b]) {
             if (v[b] < v[c]) swap(first, b);
@@ -171,6 +171,9 @@ struct SeqPairs {
         } else if (v[a] < v[c]) swap(first, a);
         else if (v[b] < v[c]) swap(first, c);
         else swap(first, b);
+    }
+    __device__ int partition_pivot(int first, int last) {  // std::__unguarded_partition_pivot
+        median_to_first(first, last);
         int lo = first + 1, hi = last;
         for (;;) {
             while (v[lo] < v[first]) ++lo;
@@ -281,12 +284,97 @@ struct SeqPairs {
     }
 };
 
+// ---- the same libstdc++ code paths, executed by the whole wave ------------------------------------------------------------
+// One lane walking an LDS array pays ~100 cycles per element (80 us for nth_element over 512 distances: the tail of every
+// small-level search that has a tie anywhere).  Hoare's partition is a deterministic pairing, though: with
+// A = positions of [lo, hi) whose value is not below the pivot (where the upward scan stops) and B = positions whose value is
+// not above it, plus the pivot's own slot as the last stop (where the downward scan stops), the sequential loop swaps the
+// t-th element of A counted from the left with the t-th element of B counted from the right for t = 0 .. T - 1, T = the
+// first t whose pair has crossed, and returns the T-th element of A or the upper slot of the last swap, whichever comes
+// first.  (Until they cross, the scans stay inside the window between the last swapped pair, so membership can be taken
+// from the values before any swap.)  Ranks come from ballots row by row; positions go to two
+// 16-bit LDS arrays; all swaps of a partition happen at once.
+struct WavePartition {
+    SeqPairs sp;
+    unsigned short *posA, *posB;  // [row_stride + 1] each
+    int lane;
+
+    __device__ __forceinline__ void sync() const {
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // std::__unguarded_partition_pivot(first, last)
+    __device__ int partition_pivot(int first, int last) {
+        if (lane == 0) sp.median_to_first(first, last);
+        sync();
+        const float pivot = sp.v[first];
+        const int lo0 = first + 1, hi0 = last, rows = (hi0 - lo0 + RPE_WAVE - 1) / RPE_WAVE;
+        int nA = 0, nB = 0;
+        for (int j = 0; j < rows; ++j) {  // A ascending
+            const int pos = lo0 + j * RPE_WAVE + lane;
+            const bool in = pos < hi0 && !(sp.v[min(pos, hi0 - 1)] < pivot);
+            const unsigned long long m = __ballot(in);
+            if (in) posA[nA + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)pos;
+            nA += (int)__builtin_popcountll(m);
+        }
+        for (int j = rows - 1; j >= 0; --j) {  // B descending
+            const int pos = lo0 + j * RPE_WAVE + lane;
+            const bool in = pos < hi0 && !(pivot < sp.v[min(pos, hi0 - 1)]);
+            const unsigned long long m = __ballot(in);
+            const unsigned long long above = lane == RPE_WAVE - 1 ? 0ull : m >> (lane + 1);
+            if (in) posB[nB + (int)__builtin_popcountll(above)] = (unsigned short)pos;
+            nB += (int)__builtin_popcountll(m);
+        }
+        if (lane == 0) posB[nB] = (unsigned short)first;  // the pivot's own slot stops the downward scan
+        ++nB;
+        sync();
+        const int lim = min(nA, nB);
+        int T = 0;  // pairs that have not crossed (the condition is monotone in t)
+        for (int t0 = 0; t0 < lim; t0 += RPE_WAVE) {
+            const int t = t0 + lane;
+            const bool ok = t < lim && posA[min(t, lim - 1)] < posB[min(t, lim - 1)];
+            const int c = (int)__builtin_popcountll(__ballot(ok));
+            T += c;
+            if (c < RPE_WAVE) break;
+        }
+        // the upward scan after swap T - 1 stops at the next element of A -- or, if there is none before it, at the slot
+        // that swap just filled with a value from A
+        int cut = T < nA ? (int)posA[T] : hi0;
+        if (T > 0) cut = min(cut, (int)posB[T - 1]);
+        for (int t0 = 0; t0 < T; t0 += RPE_WAVE) {
+            const int t = t0 + lane;
+            if (t < T) sp.swap((int)posA[t], (int)posB[t]);
+        }
+        sync();
+        return cut;
+    }
+    // std::__introselect(first, nth, last, depth_limit)
+    __device__ void introselect(int first, int nth, int last, int depth_limit) {
+        while (last - first > 3) {
+            if (depth_limit == 0) {
+                if (lane == 0) {
+                    sp.heap_select(first, nth + 1, last);
+                    sp.swap(first, nth);
+                }
+                sync();
+                return;
+            }
+            --depth_limit;
+            const int cut = partition_pivot(first, last);
+            if (cut <= nth) first = cut;
+            else last = cut;
+        }
+        if (lane == 0) sp.insertion_sort(first, last);
+        sync();
+    }
+};
+
 // ---- what happens to a finished (k + 1)-entry list: the tie check, the libstdc++ restatement if it fires, the store ----
 // Ld / Li: lane r holds rank r of query qi (wave-uniform coordinates qm2 = -2 q, qq = |q|^2).
 template <int D, bool SMALL>
 __device__ __forceinline__ void finish_query(float Ld, int Li, const float (&qm2)[3], float qq, const float *__restrict__ inp,
                                              int64_t in_sn, int64_t in_sd, int M, int k, int kk, int exact_ties, int lane, int wave,
-                                             float *seq_lds, int row_stride, int64_t out_row, int64_t *__restrict__ idx,
+                                             float *seq_lds, int row_stride, int wide, int64_t out_row, int64_t *__restrict__ idx,
                                              float *__restrict__ dist) {
     if (exact_ties && k < RPE_WAVE) {
         // equal neighbours among the kk best (lane r against lane r + 1)?  Then redo this query as libstdc++ would.
@@ -353,17 +441,38 @@ __device__ __forceinline__ void finish_query(float Ld, int Li, const float (&qm2
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
-                if (lane == 0) {
-                    int lg = 0;
-                    for (int t = M; t > 1; t >>= 1) ++lg;
-                    sp.introselect(0, k - 1, M, 2 * lg);
-                    sp.sort(0, k - 1);
+                int lg = 0;
+                for (int t = M; t > 1; t >>= 1) ++lg;
+                if (wide) {
+                    unsigned short *pos = reinterpret_cast<unsigned short *>(seq_lds + (size_t)kWavesPerBlock * 2 * row_stride) + (size_t)wave * 2 * (row_stride + 2);
+                    WavePartition wp{sp, pos, pos + row_stride + 2, lane};
+                    wp.introselect(0, k - 1, M, 2 * lg);
+                } else {  // (no LDS left for the position arrays: rows of several thousand distances, k > 32)
+                    if (lane == 0) sp.introselect(0, k - 1, M, 2 * lg);
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                if (lane < k) {
-                    Ld = sp.v[lane];
-                    Li = sp.i[lane];
+                if (k - 1 <= 16) {
+                    // std::sort of at most 16 elements is __insertion_sort alone, and that is a STABLE sort: rank by (value, position)
+                    const bool mine = lane < k - 1;
+                    const float v0 = lane < k ? sp.v[lane] : INFINITY;
+                    const int i0 = lane < k ? sp.i[lane] : 0;
+                    int rank = 0;
+                    for (int t = 0; t < k - 1; ++t) {
+                        const float vt = rpe_readlane(v0, t);
+                        rank += (vt < v0 || (vt == v0 && t < lane)) ? 1 : 0;
+                    }
+                    rank = mine ? rank : lane;  // the k-th element (and the idle lanes) stay where they are
+                    Ld = __int_as_float(__builtin_amdgcn_ds_permute(rank << 2, __float_as_int(v0)));
+                    Li = __builtin_amdgcn_ds_permute(rank << 2, i0);
+                } else {
+                    if (lane == 0) sp.sort(0, k - 1);
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < k) {
+                        Ld = sp.v[lane];
+                        Li = sp.i[lane];
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -385,7 +494,7 @@ struct KnnJobs {
 
 // ---- k >= 2: cross-lane sorted list ----------------------------------------
 template <int D, int QW, bool SMALL>  // SMALL: some job has M < 64 k (topk's nth_element form): LDS room for one row per wave
-__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(KnnJobs jobs, int k, int exact_ties, int row_stride) {
+__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(KnnJobs jobs, int k, int exact_ties, int row_stride, int wide) {
     extern __shared__ float seq_lds[];  // SMALL: per wave row_stride values then row_stride indices
     __shared__ float tile_ring[kWavesPerBlock][kRingSlots * 3 * RPE_WAVE];
     const rpe_knn_job &J = jobs.job[blockIdx.z];
@@ -496,7 +605,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_select_kernel(K
     for (int j = 0; j < QW; ++j) {
         const int qi = qbase + j;
         if (qi >= Q) continue;  // wave-uniform
-        finish_query<D, SMALL>(Ld[j], Li[j], qs.qm2[j], qs.qq[j], inp, in_sn, in_sd, M, k, kk, exact_ties, lane, wave, seq_lds, row_stride,
+        finish_query<D, SMALL>(Ld[j], Li[j], qs.qm2[j], qs.qq[j], inp, in_sn, in_sd, M, k, kk, exact_ties, lane, wave, seq_lds, row_stride, wide,
                                (int64_t)b * Q + qi, idx, dist);
     }
 }
@@ -854,7 +963,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_kernel(Knn
             Ld = lane < n ? __int_as_float((int)(unsigned)e) : INFINITY;
             Li = lane < n ? (int)(e >> 32) : 0;
         }
-        finish_query<D, false>(Ld, Li, qm2, qq, inp, in_sn, in_sd, M, k, kk, exact_ties, lane, wave, nullptr, 0, (int64_t)b * Q + qi, idx, dist);
+        finish_query<D, false>(Ld, Li, qm2, qq, inp, in_sn, in_sd, M, k, kk, exact_ties, lane, wave, nullptr, 0, 0, (int64_t)b * Q + qi, idx, dist);
     }
 }
 
@@ -960,15 +1069,19 @@ int launch_knn(const KnnJobs &jobs, int njobs, int max_q, int min_m, int max_m, 
     } else if (ties && k < RPE_WAVE && min_m < 64 * k) {
         // some job is in topk's nth_element regime: every wave gets LDS room for one such row (values + indices)
         const int row = max_m < 64 * k ? max_m : 64 * k;  // only rows shorter than 64 k are ever copied
-        const size_t lds = (size_t)kWavesPerBlock * 2 * row * sizeof(float);
+        // ... and two 16-bit position arrays for the wave-wide partition, while they fit
+        const size_t narrow = (size_t)kWavesPerBlock * 2 * row * sizeof(float);
+        size_t lds = narrow + (size_t)kWavesPerBlock * 2 * (row + 2) * sizeof(unsigned short);
+        const int wide = lds <= 128 * 1024;
+        if (!wide) lds = narrow;
         if (lds > 160 * 1024) return RPE_EUNSUPPORTED;
         if (lds > 64 * 1024) {  // beyond the default dynamic-LDS limit (k > 32 with a few thousand points)
             hipError_t e = hipFuncSetAttribute((const void *)knn_select_kernel<D, QW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL((knn_select_kernel<D, QW, true>), grid, block, lds, st, jobs, k, ties, row);
+        hipLaunchKernelGGL((knn_select_kernel<D, QW, true>), grid, block, lds, st, jobs, k, ties, row, wide);
     } else {
-        hipLaunchKernelGGL((knn_select_kernel<D, QW, false>), grid, block, 0, st, jobs, k, ties, 0);
+        hipLaunchKernelGGL((knn_select_kernel<D, QW, false>), grid, block, 0, st, jobs, k, ties, 0, 0);
     }
     return rpe_launch_status();
 }

@@ -342,7 +342,11 @@ def test_knn_multi_equals_separate_calls():
                                        (1, 4000, 50, 3, 63), (1, 5000, 40, 3, 40), (1, 40, 40, 3, 40),
                                        # enough queries for the matrix kernel: on a lattice nearly every lane list overflows (serial
                                        # sweep per query) or ties (libstdc++ restatement); M ragged and a multiple of the 256-point chunk
-                                       (2, 1500, 8200, 3, 17), (1, 2048, 16384, 3, 16), (4, 1100, 4100, 2, 3)])
+                                       (2, 1500, 8200, 3, 17), (1, 2048, 16384, 3, 16), (4, 1100, 4100, 2, 3),
+                                       # nth_element regime, every query tied: the wave-wide emulation of libstdc++'s Hoare partition
+                                       # (row lengths around the 64-lane rows and the three-element end game)
+                                       (2, 511, 600, 3, 7), (1, 1000, 500, 3, 15), (3, 65, 200, 1, 2), (1, 777, 300, 2, 12), (2, 100, 400, 3, 16),
+                                       (1, 129, 300, 3, 2), (2, 4, 50, 3, 3), (1, 67, 90, 2, 17)])
 def test_knn_equal_distances_follow_torch_topk(B, M, Q, D, k):
     """Points on a coarse integer lattice: most distances tie.  Indices AND their order must be what the reference's
     matmul + torch.topk gives on the CPU, in both of topk's regimes (k * 64 <= M: partial_sort; else nth_element + sort)."""
