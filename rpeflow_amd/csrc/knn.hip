@@ -388,34 +388,46 @@ __device__ __forceinline__ void finish_query(float Ld, int Li, const float (&qm2
                 LaneHeap h;
                 h.v = INFINITY;
                 h.i = 0;
-                float top = 0.f;
-                for (int base = 0; base < M; base += RPE_WAVE) {
-                    const int pi = base + lane;
-                    const bool valid = pi < M;
-                    float p[3] = {0.f, 0.f, 0.f};
-                    if (valid) load_point<D>(inp, in_sn, in_sd, pi, p);
-                    const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;
-                    const float d = rpe_pair_dist<D>(qm2, qq, p, pp);
-                    unsigned long long m;
-                    if (base == 0) {  // the first k elements form the heap: std::__make_heap
-                        h.v = d;
+                float top = INFINITY;
+                // Four tiles a round: this wave is alone with its row (a lone wave issues a dependent instruction every
+                // ~10 cycles and paid ~800 per 64-point tile, most rounds without a single candidate), so the loads and the
+                // distance arithmetic of 256 points run as four independent chains and one test skips the round.
+                constexpr int kTieTiles = 4;
+                for (int base0 = 0; base0 < M; base0 += kTieTiles * RPE_WAVE) {
+                    float d[kTieTiles];
+                    unsigned long long m[kTieTiles];
+                    float pt[kTieTiles][3];
+#pragma unroll
+                    for (int u = 0; u < kTieTiles; ++u) load_point<D>(inp, in_sn, in_sd, min(base0 + u * RPE_WAVE + lane, M - 1), pt[u]);
+#pragma unroll
+                    for (int u = 0; u < kTieTiles; ++u) {
+                        const float pp = base0 + u * RPE_WAVE + lane < M ? rpe_sqnorm<D>(pt[u]) : INFINITY;
+                        d[u] = rpe_pair_dist<D>(qm2, qq, pt[u], pp);
+                    }
+                    if (base0 == 0) {  // the first k elements form the heap: std::__make_heap
+                        h.v = d[0];
                         h.i = lane;
                         for (int parent = (k - 2) / 2;; --parent) {
                             h.adjust(parent, k, h.val(parent), rpe_readlane(h.i, parent), lane);
                             if (parent == 0) break;
                         }
                         top = h.val(0);
-                        m = __ballot(lane >= k && d < top);
-                    } else {
-                        m = __ballot(d < top);
                     }
-                    while (m) {  // __pop_heap(first, middle, i) for every later element below the heap's top, in order
-                        const int l = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const float nd = rpe_readlane(d, l);
-                        if (nd < top) {
-                            h.adjust(0, k, nd, base + l, lane);
+                    unsigned long long any = 0ull;
+#pragma unroll
+                    for (int u = 0; u < kTieTiles; ++u) {
+                        m[u] = __ballot((base0 > 0 || u > 0 || lane >= k) && d[u] < top);  // (top only falls: a superset of what passes later)
+                        any |= m[u];
+                    }
+                    if (!any) continue;
+#pragma unroll
+                    for (int u = 0; u < kTieTiles; ++u) {
+                        unsigned long long mu = m[u] & __ballot(d[u] < top);  // against the top as it is now
+                        while (mu) {  // __pop_heap(first, middle, i) for every later element below the heap's top, in order
+                            const int l = __builtin_ctzll(mu);
+                            h.adjust(0, k, rpe_readlane(d[u], l), base0 + u * RPE_WAVE + l, lane);
                             top = h.val(0);
+                            mu &= (~1ull << l) & __ballot(d[u] < top);  // what is left of this tile, against the new top
                         }
                     }
                 }
