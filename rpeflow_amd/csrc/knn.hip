@@ -370,130 +370,175 @@ struct WavePartition {
 };
 
 // ---- what happens to a finished (k + 1)-entry list: the tie check, the libstdc++ restatement if it fires, the store ----
-// Ld / Li: lane r holds rank r of query qi (wave-uniform coordinates qm2 = -2 q, qq = |q|^2).
+// One query redone the libstdc++ way (wave-uniform coordinates qm2 = -2 q, qq = |q|^2): the result in lane r = rank r.
+template <int D, bool SMALL>
+__device__ __forceinline__ void resolve_ties(float &Ld, int &Li, const float (&qm2)[3], float qq, const float *__restrict__ inp,
+                                             int64_t in_sn, int64_t in_sd, int M, int k, int lane, int wave, float *seq_lds, int row_stride,
+                                             int wide) {
+    if (!SMALL || k * 64 <= M) {  // std::partial_sort: __heap_select over the row in index order, then __sort_heap
+        LaneHeap h;
+        h.v = INFINITY;
+        h.i = 0;
+        float top = INFINITY;
+        // Four tiles a round: this wave is alone with its row (a lone wave issues a dependent instruction every
+        // ~10 cycles and paid ~800 per 64-point tile, most rounds without a single candidate), so the loads and the
+        // distance arithmetic of 256 points run as four independent chains and one test skips the round.
+        constexpr int kTieTiles = 4;
+        for (int base0 = 0; base0 < M; base0 += kTieTiles * RPE_WAVE) {
+            float d[kTieTiles];
+            unsigned long long m[kTieTiles];
+            float pt[kTieTiles][3];
+#pragma unroll
+            for (int u = 0; u < kTieTiles; ++u) load_point<D>(inp, in_sn, in_sd, min(base0 + u * RPE_WAVE + lane, M - 1), pt[u]);
+#pragma unroll
+            for (int u = 0; u < kTieTiles; ++u) {
+                const float pp = base0 + u * RPE_WAVE + lane < M ? rpe_sqnorm<D>(pt[u]) : INFINITY;
+                d[u] = rpe_pair_dist<D>(qm2, qq, pt[u], pp);
+            }
+            if (base0 == 0) {  // the first k elements form the heap: std::__make_heap
+                h.v = d[0];
+                h.i = lane;
+                for (int parent = (k - 2) / 2;; --parent) {
+                    h.adjust(parent, k, h.val(parent), rpe_readlane(h.i, parent), lane);
+                    if (parent == 0) break;
+                }
+                top = h.val(0);
+            }
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int u = 0; u < kTieTiles; ++u) {
+                m[u] = __ballot((base0 > 0 || u > 0 || lane >= k) && d[u] < top);  // (top only falls: a superset of what passes later)
+                any |= m[u];
+            }
+            if (!any) continue;
+#pragma unroll
+            for (int u = 0; u < kTieTiles; ++u) {
+                unsigned long long mu = m[u] & __ballot(d[u] < top);  // against the top as it is now
+                while (mu) {  // __pop_heap(first, middle, i) for every later element below the heap's top, in order
+                    const int l = __builtin_ctzll(mu);
+                    h.adjust(0, k, rpe_readlane(d[u], l), base0 + u * RPE_WAVE + l, lane);
+                    top = h.val(0);
+                    mu &= (~1ull << l) & __ballot(d[u] < top);  // what is left of this tile, against the new top
+                }
+            }
+        }
+        for (int last = k - 1; last >= 1; --last) {  // std::__sort_heap
+            const float lv = h.val(last);
+            const int li = rpe_readlane(h.i, last);
+            h.move(last, 0, lane);
+            h.adjust(0, last, lv, li, lane);
+        }
+        Ld = h.v;
+        Li = h.i;
+    } else {  // std::nth_element(begin, begin + k - 1, end) + std::sort(begin, begin + k - 1) by one lane
+        SeqPairs sp{seq_lds + (size_t)wave * 2 * row_stride,
+                    reinterpret_cast<int *>(seq_lds + (size_t)wave * 2 * row_stride + row_stride)};
+        for (int base = 0; base < M; base += RPE_WAVE) {
+            const int pi = base + lane;
+            if (pi < M) {
+                float p[3] = {0.f, 0.f, 0.f};
+                load_point<D>(inp, in_sn, in_sd, pi, p);
+                sp.v[pi] = rpe_pair_dist<D>(qm2, qq, p, rpe_sqnorm<D>(p));
+                sp.i[pi] = pi;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        int lg = 0;
+        for (int t = M; t > 1; t >>= 1) ++lg;
+        if (wide) {
+            unsigned short *pos = reinterpret_cast<unsigned short *>(seq_lds + (size_t)kWavesPerBlock * 2 * row_stride) + (size_t)wave * 2 * (row_stride + 2);
+            WavePartition wp{sp, pos, pos + row_stride + 2, lane};
+            wp.introselect(0, k - 1, M, 2 * lg);
+        } else {  // (no LDS left for the position arrays: rows of several thousand distances, k > 32)
+            if (lane == 0) sp.introselect(0, k - 1, M, 2 * lg);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (k - 1 <= 16) {
+            // std::sort of at most 16 elements is __insertion_sort alone, and that is a STABLE sort: rank by (value, position)
+            const bool mine = lane < k - 1;
+            const float v0 = lane < k ? sp.v[lane] : INFINITY;
+            const int i0 = lane < k ? sp.i[lane] : 0;
+            int rank = 0;
+            for (int t = 0; t < k - 1; ++t) {
+                const float vt = rpe_readlane(v0, t);
+                rank += (vt < v0 || (vt == v0 && t < lane)) ? 1 : 0;
+            }
+            rank = mine ? rank : lane;  // the k-th element (and the idle lanes) stay where they are
+            Ld = __int_as_float(__builtin_amdgcn_ds_permute(rank << 2, __float_as_int(v0)));
+            Li = __builtin_amdgcn_ds_permute(rank << 2, i0);
+        } else {
+            if (lane == 0) sp.sort(0, k - 1);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < k) {
+                Ld = sp.v[lane];
+                Li = sp.i[lane];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// equal neighbours among the kk best (lane r against lane r + 1)?  exact_ties 1: only a tie ACROSS the boundary (k-th against
+// (k+1)-th distance) can change WHICH neighbours are returned; ties inside the top k change their order only and keep the
+// sweep's index order.  3: any tie.
+__device__ __forceinline__ bool has_ties(float Ld, int k, int kk, int exact_ties, int lane) {
+    if (!exact_ties || k >= RPE_WAVE) return false;
+    const float nxt = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Ld), __float_as_int(Ld), 0x130, 0xf, 0xf, false));  // wave_shl:1
+    unsigned long long dup = __ballot(lane + 1 < kk && Ld == nxt);
+    if (exact_ties == 1) dup &= 1ull << (k - 1);
+    return dup != 0ull;
+}
+
+// Ld / Li: lane r holds rank r of the query (wave-uniform coordinates qm2 = -2 q, qq = |q|^2).
 template <int D, bool SMALL>
 __device__ __forceinline__ void finish_query(float Ld, int Li, const float (&qm2)[3], float qq, const float *__restrict__ inp,
                                              int64_t in_sn, int64_t in_sd, int M, int k, int kk, int exact_ties, int lane, int wave,
                                              float *seq_lds, int row_stride, int wide, int64_t out_row, int64_t *__restrict__ idx,
                                              float *__restrict__ dist) {
-    if (exact_ties && k < RPE_WAVE) {
-        // equal neighbours among the kk best (lane r against lane r + 1)?  Then redo this query as libstdc++ would.
-        const float nxt = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Ld), __float_as_int(Ld), 0x130, 0xf, 0xf, false));  // wave_shl:1
-        // exact_ties 1: only a tie ACROSS the boundary (k-th against (k+1)-th distance) can change WHICH neighbours are
-        // returned; ties inside the top k change their order only and keep the sweep's index order.  3: any tie.
-        unsigned long long dup = __ballot(lane + 1 < kk && Ld == nxt);
-        if (exact_ties == 1) dup &= 1ull << (k - 1);
-        if (dup) {
-            if (!SMALL || k * 64 <= M) {  // std::partial_sort: __heap_select over the row in index order, then __sort_heap
-                LaneHeap h;
-                h.v = INFINITY;
-                h.i = 0;
-                float top = INFINITY;
-                // Four tiles a round: this wave is alone with its row (a lone wave issues a dependent instruction every
-                // ~10 cycles and paid ~800 per 64-point tile, most rounds without a single candidate), so the loads and the
-                // distance arithmetic of 256 points run as four independent chains and one test skips the round.
-                constexpr int kTieTiles = 4;
-                for (int base0 = 0; base0 < M; base0 += kTieTiles * RPE_WAVE) {
-                    float d[kTieTiles];
-                    unsigned long long m[kTieTiles];
-                    float pt[kTieTiles][3];
-#pragma unroll
-                    for (int u = 0; u < kTieTiles; ++u) load_point<D>(inp, in_sn, in_sd, min(base0 + u * RPE_WAVE + lane, M - 1), pt[u]);
-#pragma unroll
-                    for (int u = 0; u < kTieTiles; ++u) {
-                        const float pp = base0 + u * RPE_WAVE + lane < M ? rpe_sqnorm<D>(pt[u]) : INFINITY;
-                        d[u] = rpe_pair_dist<D>(qm2, qq, pt[u], pp);
-                    }
-                    if (base0 == 0) {  // the first k elements form the heap: std::__make_heap
-                        h.v = d[0];
-                        h.i = lane;
-                        for (int parent = (k - 2) / 2;; --parent) {
-                            h.adjust(parent, k, h.val(parent), rpe_readlane(h.i, parent), lane);
-                            if (parent == 0) break;
-                        }
-                        top = h.val(0);
-                    }
-                    unsigned long long any = 0ull;
-#pragma unroll
-                    for (int u = 0; u < kTieTiles; ++u) {
-                        m[u] = __ballot((base0 > 0 || u > 0 || lane >= k) && d[u] < top);  // (top only falls: a superset of what passes later)
-                        any |= m[u];
-                    }
-                    if (!any) continue;
-#pragma unroll
-                    for (int u = 0; u < kTieTiles; ++u) {
-                        unsigned long long mu = m[u] & __ballot(d[u] < top);  // against the top as it is now
-                        while (mu) {  // __pop_heap(first, middle, i) for every later element below the heap's top, in order
-                            const int l = __builtin_ctzll(mu);
-                            h.adjust(0, k, rpe_readlane(d[u], l), base0 + u * RPE_WAVE + l, lane);
-                            top = h.val(0);
-                            mu &= (~1ull << l) & __ballot(d[u] < top);  // what is left of this tile, against the new top
-                        }
-                    }
-                }
-                for (int last = k - 1; last >= 1; --last) {  // std::__sort_heap
-                    const float lv = h.val(last);
-                    const int li = rpe_readlane(h.i, last);
-                    h.move(last, 0, lane);
-                    h.adjust(0, last, lv, li, lane);
-                }
-                Ld = h.v;
-                Li = h.i;
-            } else {  // std::nth_element(begin, begin + k - 1, end) + std::sort(begin, begin + k - 1) by one lane
-                SeqPairs sp{seq_lds + (size_t)wave * 2 * row_stride,
-                            reinterpret_cast<int *>(seq_lds + (size_t)wave * 2 * row_stride + row_stride)};
-                for (int base = 0; base < M; base += RPE_WAVE) {
-                    const int pi = base + lane;
-                    if (pi < M) {
-                        float p[3] = {0.f, 0.f, 0.f};
-                        load_point<D>(inp, in_sn, in_sd, pi, p);
-                        sp.v[pi] = rpe_pair_dist<D>(qm2, qq, p, rpe_sqnorm<D>(p));
-                        sp.i[pi] = pi;
-                    }
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                int lg = 0;
-                for (int t = M; t > 1; t >>= 1) ++lg;
-                if (wide) {
-                    unsigned short *pos = reinterpret_cast<unsigned short *>(seq_lds + (size_t)kWavesPerBlock * 2 * row_stride) + (size_t)wave * 2 * (row_stride + 2);
-                    WavePartition wp{sp, pos, pos + row_stride + 2, lane};
-                    wp.introselect(0, k - 1, M, 2 * lg);
-                } else {  // (no LDS left for the position arrays: rows of several thousand distances, k > 32)
-                    if (lane == 0) sp.introselect(0, k - 1, M, 2 * lg);
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (k - 1 <= 16) {
-                    // std::sort of at most 16 elements is __insertion_sort alone, and that is a STABLE sort: rank by (value, position)
-                    const bool mine = lane < k - 1;
-                    const float v0 = lane < k ? sp.v[lane] : INFINITY;
-                    const int i0 = lane < k ? sp.i[lane] : 0;
-                    int rank = 0;
-                    for (int t = 0; t < k - 1; ++t) {
-                        const float vt = rpe_readlane(v0, t);
-                        rank += (vt < v0 || (vt == v0 && t < lane)) ? 1 : 0;
-                    }
-                    rank = mine ? rank : lane;  // the k-th element (and the idle lanes) stay where they are
-                    Ld = __int_as_float(__builtin_amdgcn_ds_permute(rank << 2, __float_as_int(v0)));
-                    Li = __builtin_amdgcn_ds_permute(rank << 2, i0);
-                } else {
-                    if (lane == 0) sp.sort(0, k - 1);
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < k) {
-                        Ld = sp.v[lane];
-                        Li = sp.i[lane];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
+    if (has_ties(Ld, k, kk, exact_ties, lane))  // then redo this query as libstdc++ would
+        resolve_ties<D, SMALL>(Ld, Li, qm2, qq, inp, in_sn, in_sd, M, k, lane, wave, seq_lds, row_stride, wide);
     if (lane < k) {
         const int64_t o = out_row * k + lane;
         idx[o] = (int64_t)Li;
         if (dist) dist[o] = Ld;
+    }
+}
+
+// The matrix kernel's waves own 16 queries each and ~1.4 % of the queries of a real cloud tie (|q|^2 + |p|^2 - 2 q.p cancels
+// to a few thousand distinct values among the nearest neighbours); one takes a wave 30-50 us, and the wave with the most of
+// them set the kernel's time.  There a tied query goes to a queue of the workgroup, and once every wave is through its own
+// queries the four waves take the queued ones in turn.  (With at most 8 queries a wave the insertion kernel measured
+// faster redoing them on the spot.)
+struct TieQueue {
+    int n;
+    int query[kWavesPerBlock * 16];
+};
+
+template <int D>
+__device__ __forceinline__ void drain_ties(TieQueue *tq, const rpe_knn_job &J, int b, int k, int lane, int wave) {
+    __syncthreads();
+    const int n = tq->n;
+    const float *inp = J.input + (int64_t)b * J.in_sb;
+    for (int t = wave; t < n; t += kWavesPerBlock) {
+        const int qi = tq->query[t];
+        float q[3], qm2[3];
+        load_point<D>(J.query + (int64_t)b * J.q_sb, J.q_sn, J.q_sd, qi, q);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) q[d] = rpe_uniform(q[d]);
+        const float qq = rpe_sqnorm<D>(q);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) qm2[d] = -2.0f * q[d];
+        float Ld = 0.f;
+        int Li = 0;
+        resolve_ties<D, false>(Ld, Li, qm2, qq, inp, J.in_sn, J.in_sd, J.M, k, lane, wave, nullptr, 0, 0);
+        if (lane < k) {
+            const int64_t o = ((int64_t)b * J.Q + qi) * k + lane;
+            J.idx[o] = (int64_t)Li;
+            if (J.dist) J.dist[o] = Ld;
+        }
     }
 }
 
@@ -825,6 +870,8 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_kernel(Knn
     inp += (int64_t)b * in_sb;
     qry += (int64_t)b * q_sb;
     if (threadIdx.x < kRow) lds.ones[threadIdx.x] = 1.0f;
+    __shared__ TieQueue tq;
+    if (threadIdx.x == 0) tq.n = 0;  // (the sweeps' barriers come before the first push)
 
     MfmaSweep<D> sw;
     sw.inp = inp, sw.sn = in_sn, sw.sd = in_sd, sw.M = M, sw.lane = lane, sw.wave = wave, sw.L = &lds;
@@ -975,8 +1022,15 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_kernel(Knn
             Ld = lane < n ? __int_as_float((int)(unsigned)e) : INFINITY;
             Li = lane < n ? (int)(e >> 32) : 0;
         }
-        finish_query<D, false>(Ld, Li, qm2, qq, inp, in_sn, in_sd, M, k, kk, exact_ties, lane, wave, nullptr, 0, 0, (int64_t)b * Q + qi, idx, dist);
+        if (has_ties(Ld, k, kk, exact_ties, lane)) {
+            if (lane == 0) tq.query[atomicAdd(&tq.n, 1)] = qi;
+        } else if (lane < k) {
+            const int64_t o = ((int64_t)b * Q + qi) * k + lane;
+            idx[o] = (int64_t)Li;
+            if (dist) dist[o] = Ld;
+        }
     }
+    if (exact_ties) drain_ties<D>(&tq, J, b, k, lane, wave);
 }
 
 // ---- k == 1: lane-local minimum ----------------------------------------------
