@@ -709,7 +709,7 @@ constexpr int kLaneList = 16;             // entries per lane list (15 usable: t
 #define RPE_KNN_MATRIX_MIN_M 1024
 #endif
 constexpr int kMatrixMinM = RPE_KNN_MATRIX_MIN_M;  // below this the fixed costs (bound sort, ranking) outweigh the sweep
-constexpr long kMatrixMinQueries = 16384;          // B * Q: 16 queries a wave, and fewer than one wave per SIMD are latency-bound
+constexpr long kMatrixMinQueries = 16384;  // B * Q: 16 queries a wave; below one wave per SIMD the insertion kernel is faster (2048^2, B = 4: 32 vs 38 us)
 constexpr int kChunkSteps = 4;            // a chunk = 4 steps of 64 points; wave w of the block loads step w of every chunk
 #ifndef RPE_KNN_CHUNKS
 #define RPE_KNN_CHUNKS 4
