@@ -718,9 +718,12 @@ constexpr int kChunkSteps = 4;            // a chunk = 4 steps of 64 points; wav
 constexpr int kChunks = RPE_KNN_CHUNKS;      // ring depth in chunks (a power of two)
 constexpr int kChunksAhead = RPE_KNN_AHEAD;  // chunk t + 2 is requested before chunk t is used (kChunks >= kChunksAhead + 2)
 
-struct MfmaBlockLds {
+struct MfmaRing {
     float ring[kChunks][kChunkSteps][kSlotFloats];  // the cloud streams through here once per pass, shared by the block's four waves
     float ones[kRow];
+};
+struct MfmaBlockLds {
+    MfmaRing r;
     int count[kWavesPerBlock][RPE_WAVE];
     unsigned long long list[kWavesPerBlock][kLaneList][RPE_WAVE];  // entry s of lane l at [s][l] (lane-interleaved: no bank conflicts): (index << 32) | distance bits
 };
@@ -762,7 +765,7 @@ struct MfmaSweep {
     const float *inp;
     int64_t sn, sd;
     int M, lane, wave;
-    MfmaBlockLds *L;
+    MfmaRing *L;
     float qb;            // B fragment (queries): lane (kq = l >> 4, col = l & 15): -2 q[kq] of query col, |q|^2 for kq = 3
     int aoff;            // A fragment (points) source of this lane: float offset inside a step's slot, or -1: the row of ones
 
@@ -869,12 +872,12 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_kernel(Knn
     const int qbase = (blockIdx.x * kWavesPerBlock + wave) * kMq;  // a wave beyond Q still loads its share of the cloud
     inp += (int64_t)b * in_sb;
     qry += (int64_t)b * q_sb;
-    if (threadIdx.x < kRow) lds.ones[threadIdx.x] = 1.0f;
+    if (threadIdx.x < kRow) lds.r.ones[threadIdx.x] = 1.0f;
     __shared__ TieQueue tq;
     if (threadIdx.x == 0) tq.n = 0;  // (the sweeps' barriers come before the first push)
 
     MfmaSweep<D> sw;
-    sw.inp = inp, sw.sn = in_sn, sw.sd = in_sd, sw.M = M, sw.lane = lane, sw.wave = wave, sw.L = &lds;
+    sw.inp = inp, sw.sn = in_sn, sw.sd = in_sd, sw.M = M, sw.lane = lane, sw.wave = wave, sw.L = &lds.r;
     float qv[3];  // lane c of every group: query qbase + c
     load_point<D>(qry, q_sn, q_sd, min(qbase + c, Q - 1), qv);
     sw.qb = g == 0 ? -2.0f * qv[0] : g == 1 ? -2.0f * qv[1] : g == 2 ? -2.0f * qv[2] : rpe_sqnorm<D>(qv);  // (a missing dimension is 1 * 0)
@@ -1033,6 +1036,65 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_kernel(Knn
     if (exact_ties) drain_ties<D>(&tq, J, b, k, lane, wave);
 }
 
+// ---- k == 1 on large clouds, many queries: the same matrix sweep, a running (minimum, index) per lane ------------------------
+// A lane sees its query's points in index order (register 4 b + r = point 16 b + 4 g + r of the step), so a strict '<'
+// keeps the first index inside the lane; the four lanes of a query then merge by (distance, index).  5 matrix + ~50 vector
+// instructions per 64 points x 16 queries against ~130 vector instructions in knn_nearest_kernel.
+template <int D>
+__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_nearest_kernel(KnnJobs jobs) {
+    __shared__ MfmaRing lds;
+    const rpe_knn_job &J = jobs.job[blockIdx.z];
+    const int M = J.M, Q = J.Q;
+    const int lane = rpe_lane(), g = lane >> 4, c = lane & 15;
+    const int wave = rpe_uniform((int)(threadIdx.x >> 6));
+    const int b = blockIdx.y;
+    if ((int)blockIdx.x * kWavesPerBlock * kMq >= Q) return;  // whole block beyond this job's queries (block-uniform)
+    const int qbase = (blockIdx.x * kWavesPerBlock + wave) * kMq;  // a wave beyond Q still loads its share of the cloud
+    const float *inp = J.input + (int64_t)b * J.in_sb, *qry = J.query + (int64_t)b * J.q_sb;
+    if (threadIdx.x < kRow) lds.ones[threadIdx.x] = 1.0f;
+
+    MfmaSweep<D> sw;
+    sw.inp = inp, sw.sn = J.in_sn, sw.sd = J.in_sd, sw.M = M, sw.lane = lane, sw.wave = wave, sw.L = &lds;
+    float qv[3];
+    load_point<D>(qry, J.q_sn, J.q_sd, min(qbase + c, Q - 1), qv);
+    sw.qb = g == 0 ? -2.0f * qv[0] : g == 1 ? -2.0f * qv[1] : g == 2 ? -2.0f * qv[2] : rpe_sqnorm<D>(qv);
+    sw.aoff = g < D ? g * kRow + c : -1;
+    const int n_chunks = (M + kChunkSteps * RPE_WAVE - 1) / (kChunkSteps * RPE_WAVE);
+
+    float bd = INFINITY;
+    int bi = 0x7fffffff;
+    sw.start();
+    for (int t = 0; t < n_chunks; ++t) {
+        sw.acquire(t);
+#pragma unroll
+        for (int st = 0; st < kChunkSteps; ++st) {
+            const int base = (t * kChunkSteps + st) * RPE_WAVE + 4 * g;
+            const knn_f32x16 acc = sw.step(t, st);  // (points past the end: +inf, never taken)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool take = acc[i] < bd;  // strict: first index wins inside a lane
+                bd = take ? acc[i] : bd;
+                bi = take ? base + 16 * (i >> 2) + (i & 3) : bi;
+            }
+        }
+    }
+    sw.finish();
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        const float od = __shfl_xor(bd, off);
+        const int oi = __shfl_xor(bi, off);
+        const bool take = (od < bd) || (od == bd && oi < bi);
+        bd = take ? od : bd;
+        bi = take ? oi : bi;
+    }
+    const int qi = qbase + c;
+    if (g == 0 && qi < Q) {
+        const int64_t o = (int64_t)b * Q + qi;
+        J.idx[o] = bi == 0x7fffffff ? 0 : (int64_t)bi;
+        if (J.dist) J.dist[o] = bd;
+    }
+}
+
 // ---- k == 1: lane-local minimum ----------------------------------------------
 template <int D, int QW>
 __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_nearest_kernel(KnnJobs jobs) {
@@ -1179,7 +1241,11 @@ int launch_group(const rpe_knn_job *const *jobs, int njobs, bool matrix, int B, 
     if (matrix) {
         const int per_block = kWavesPerBlock * kMq;
         dim3 grid((max_q + per_block - 1) / per_block, B, njobs), block(kWavesPerBlock * RPE_WAVE);
-        if (D == 3) hipLaunchKernelGGL(knn_mfma_kernel<3>, grid, block, 0, st, packed, k, tie_mode);
+        if (k == 1) {  // (M >= 64: topk's partial_sort with a one-element heap keeps the first minimum, as this kernel does)
+            if (D == 3) hipLaunchKernelGGL(knn_mfma_nearest_kernel<3>, grid, block, 0, st, packed);
+            else if (D == 2) hipLaunchKernelGGL(knn_mfma_nearest_kernel<2>, grid, block, 0, st, packed);
+            else hipLaunchKernelGGL(knn_mfma_nearest_kernel<1>, grid, block, 0, st, packed);
+        } else if (D == 3) hipLaunchKernelGGL(knn_mfma_kernel<3>, grid, block, 0, st, packed, k, tie_mode);
         else if (D == 2) hipLaunchKernelGGL(knn_mfma_kernel<2>, grid, block, 0, st, packed, k, tie_mode);
         else hipLaunchKernelGGL(knn_mfma_kernel<1>, grid, block, 0, st, packed, k, tie_mode);
         return rpe_launch_status();
@@ -1197,13 +1263,13 @@ RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int 
     if (tie_mode != RPE_KNN_TIES_TORCH && tie_mode != RPE_KNN_TIES_SET && tie_mode != RPE_KNN_TIES_INDEX) return RPE_EINVAL;
     if (k > RPE_WAVE) return RPE_EUNSUPPORTED;
     if (B > 65535) return RPE_EUNSUPPORTED;
-    // k >= 2, a cloud of at least kMatrixMinM points in topk's partial_sort regime (64 k <= M), enough queries: the matrix kernel
+    // a cloud of at least kMatrixMinM points in topk's partial_sort regime (64 k <= M), enough queries: the matrix kernels
     const rpe_knn_job *big[RPE_KNN_MAX_JOBS], *rest[RPE_KNN_MAX_JOBS];
     int nbig = 0, nrest = 0;
     for (int i = 0; i < njobs; ++i) {
         const rpe_knn_job &j = jobs[i];
         if (!j.input || !j.query || !j.idx || j.M <= 0 || j.Q < 0 || k > j.M) return RPE_EINVAL;
-        if (k >= 2 && k < RPE_WAVE && j.M >= kMatrixMinM && (long)j.M >= 64L * k && (long)B * j.Q >= kMatrixMinQueries) big[nbig++] = &j;
+        if (k < RPE_WAVE && j.M >= kMatrixMinM && (long)j.M >= 64L * k && (long)B * j.Q >= kMatrixMinQueries) big[nbig++] = &j;
         else rest[nrest++] = &j;
     }
     if (B == 0) return 0;

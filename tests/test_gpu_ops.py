@@ -96,6 +96,8 @@ def test_knn_ragged_shapes(B, M, Q, D, k):
     # every D, k up to 63
     (2, 1500, 8200, 3, 16), (1, 4100, 16390, 3, 3), (3, 1024, 5500, 2, 5), (2, 1030, 8192, 1, 2), (1, 2000, 16384, 3, 31),
     (1, 4100, 16384, 3, 63), (8, 8192, 2048, 3, 16),
+    # k = 1 with as many queries: knn_mfma_nearest_kernel (running minimum + index per lane)
+    (2, 1100, 9000, 2, 1), (1, 4100, 16500, 3, 1), (3, 1024, 5500, 1, 1), (4, 4096, 8640, 2, 1),
 ])
 def test_knn_matrix_kernel_shapes(B, M, Q, D, k):
     r = I.rng(7300 + M + Q + k)
@@ -342,7 +344,7 @@ def test_knn_multi_equals_separate_calls():
                                        (1, 4000, 50, 3, 63), (1, 5000, 40, 3, 40), (1, 40, 40, 3, 40),
                                        # enough queries for the matrix kernel: on a lattice nearly every lane list overflows (serial
                                        # sweep per query) or ties (libstdc++ restatement); M ragged and a multiple of the 256-point chunk
-                                       (2, 1500, 8200, 3, 17), (1, 2048, 16384, 3, 16), (4, 1100, 4100, 2, 3),
+                                       (2, 1500, 8200, 3, 17), (1, 2048, 16384, 3, 16), (4, 1100, 4100, 2, 3), (2, 1500, 8200, 2, 1),
                                        # nth_element regime, every query tied: the wave-wide emulation of libstdc++'s Hoare partition
                                        # (row lengths around the 64-lane rows and the three-element end game)
                                        (2, 511, 600, 3, 7), (1, 1000, 500, 3, 15), (3, 65, 200, 1, 2), (1, 777, 300, 2, 12), (2, 100, 400, 3, 16),
