@@ -44,4 +44,10 @@ for pass in a b c; do
   (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_corr_$pass -- python3 $GRAFT_REPO_ROOT/tools/prof_corr.py 0 6 > /tmp/pmc_corr_$pass.log 2>&1)
 done
 python3 tools/pmc_summary.py corr_mfma_dma_kernel $OUT/corr_microbench_pmc.json "correlation2d 1x256x544x960 md=4 fp32 (tools/prof_corr.py 0 6)" /tmp/pmc_corr_a /tmp/pmc_corr_b /tmp/pmc_corr_c
+# 6. the hot-path sequence alone, eager, kernel stats; and the FPS PMC passes
+(cd /tmp && rm -rf /tmp/p6 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p6 -- python3 $GRAFT_REPO_ROOT/bench.py --workload hotpath --eager --steps 10 --warmup 2 --no-cpu-baseline --no-corr-microbench > /tmp/p6.log 2>&1)
+cp $(find /tmp/p6 -name "*kernel_stats.csv" | head -1) $OUT/hotpath_kernel_stats.csv
+# 7. the bench lines themselves (default and dsec), un-profiled
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python3 bench.py --config dsec > $OUT/bench_dsec.json 2> $OUT/bench_dsec.err
 ls -la $OUT
