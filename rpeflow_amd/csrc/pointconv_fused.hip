@@ -40,6 +40,7 @@ struct PcArgs {
     float *out;
     int out_mode, out_stride;  // 0: [B,Cout,Q];  1: rows [B,Q,out_stride] = [xyz_q | y | zeros]
     int Cout, Q;
+    int tiles, nsplit;  // query tiles per cloud, output splits: the grid is 1-D, tiles * nsplit * B workgroups (see the kernel)
 };
 
 __device__ __forceinline__ float leaky(float x, float slope) { return x >= 0.f ? x : x * slope; }
@@ -61,7 +62,13 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void pointconv_fused_ker
     float *atile = smem + kg * (BM * 256);        // [BM][256] floats per group, 16-byte blocks XOR-swizzled by (row & 15)
     int *rowoff = (int *)(smem + KS * BM * 256);  // [BM][16] element offsets of the gathered rows (every group writes the same)
     const int kk = lane >> 4, n16 = lane & 15;
-    const int b = blockIdx.y, q0 = blockIdx.x * BM;
+    // Workgroup ids go round the 8 XCDs (id % 8 shares an L2); remapped so that an XCD works through a CONTIGUOUS stretch of
+    // (cloud, query tile, output split): its L2 then holds one cloud's rows instead of all of them, and the splits of a
+    // query tile, which gather the same rows, run side by side.  (Pure placement: any id -> XCD assignment is correct.)
+    const int nwg = (int)gridDim.x, orig = (int)blockIdx.x, xcd = orig & 7, per = nwg >> 3, rem = nwg & 7;
+    const int wgid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (orig >> 3);
+    const int bz = wgid % a.nsplit, bx = (wgid / a.nsplit) % a.tiles;
+    const int b = wgid / (a.nsplit * a.tiles), q0 = bx * BM;
     const float *rows_b = a.rows + (int64_t)b * a.M * a.CFp;
 
     // ---- prologue: weight net of this wave's QW queries, in the stage-1 A-operand layout (lane = (j-slot kk, w = n16))
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void pointconv_fused_ker
     __syncthreads();  // every wave holds its values before stage 1 overwrites the tile
 
     const int wm = wave / WN, wn = wave % WN;
-    const int tbase = blockIdx.z * (WN * NT) + wn * NT;
+    const int tbase = bz * (WN * NT) + wn * NT;
     // Two-level sums: an MFMA accumulator is one sequential fp32 fma chain, so each chunk (K = 256) gets a fresh one and
     // the chunk totals are added up separately -- the blocked summation of a library GEMM, not a 3000-term chain.
     f32x4 total[MT][NT];
@@ -270,9 +277,9 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void pointconv_fused_ker
             }
         }
     }
-    if (a.out_mode == 1 && blockIdx.z == 0) {
+    if (a.out_mode == 1 && bz == 0) {
         // the rows' xyz columns and the zero tail beyond the last output tile
-        const int covered = 3 + 16 * (int)gridDim.z * WN * NT;
+        const int covered = 3 + 16 * a.nsplit * WN * NT;
         for (int i = threadIdx.x; i < BM * 16; i += 256) {  // (KS == 2: group 0 only is left, threadIdx.x < 256)
             const int ql = i >> 4, c = i & 15, q = q0 + ql;
             if (q >= a.Q) continue;
@@ -321,7 +328,7 @@ __global__ __launch_bounds__(256) void pointconv_pack_kernel(PackSrc s, int M, i
 }
 
 template <int MT, int WM, int NT, int WN, int KS = 1>
-int launch_fused(const PcArgs &a, int B, int nsplit, hipStream_t st) {
+int launch_fused(PcArgs a, int B, int nsplit, hipStream_t st) {
     constexpr int BM = 16 * MT * WM;
     constexpr int smem = KS * BM * 256 * 4 + BM * 16 * 4;
     static bool configured = false;  // idempotent attribute: a race only repeats the call
@@ -330,8 +337,11 @@ int launch_fused(const PcArgs &a, int B, int nsplit, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    dim3 grid((a.Q + BM - 1) / BM, B, nsplit);
-    hipLaunchKernelGGL((pointconv_fused_kernel<MT, WM, NT, WN, KS>), grid, dim3(256 * KS), smem, st, a);
+    a.tiles = (a.Q + BM - 1) / BM;
+    a.nsplit = nsplit;
+    const int64_t nwg = (int64_t)a.tiles * nsplit * B;
+    if (nwg >= (1ll << 31)) return RPE_EUNSUPPORTED;
+    hipLaunchKernelGGL((pointconv_fused_kernel<MT, WM, NT, WN, KS>), dim3((unsigned)nwg), dim3(256 * KS), smem, st, a);
     return rpe_launch_status();
 }
 
@@ -375,7 +385,7 @@ RPE_API int rpe_pointconv_fused(const float *rows, int CFp, int M, const int64_t
     if (B == 0 || Q == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
     PcArgs a{rows, CFp, CFp / 16, M, knn, knn_row_stride, q_xyz, q_sb, q_sd, q_sn, w1, b1, w2, b2, leaky_slope,
-             (const f32x4 *)packed_linear, n_tiles, scale, shift, act, act_slope, out, out_mode, out_stride, Cout, Q};
+             (const f32x4 *)packed_linear, n_tiles, scale, shift, act, act_slope, out, out_mode, out_stride, Cout, Q, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     // Tile choice: BN = 128 outputs per workgroup (64 for narrow layers) and the largest BM in {64, 32, 16} queries that
     // still gives every CU two workgroups (one in its gather / stage 1 while the other multiplies); the smallest levels
