@@ -25,6 +25,8 @@ Extra objects on the line ("Measurement"):
   epe_delta      |EPE2D|, |EPE3D| differences of THIS configuration's output (the replayed
                  graph, untimed) against the reference's CPU forward on the same batch
   roofline_corr  BASELINE config 2, the correlation-only microbench 1x256x544x960 (N=1 only)
+  roofline_knn   the forward's largest 3-D neighbour search against the fp32 matrix peak, 2 D + 3
+                 flops a pair (N=1 only)
   cpu_baseline   the PyTorch-CPU port of the reference fallback (oracle/torch_ref.py) on the
                  host cores, bounded sample (rank 0, N=1 only)
 """
@@ -43,6 +45,7 @@ RUNTIME = runtime.configure()  # before anything initialises the HIP runtime (gr
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (SURVEY.md 8d prices KNN against it)
 H, W, NPTS = 544, 960, 8192  # the correlation microbench's frame (BASELINE config 2) and the default workload's
 # workload shapes: (frame H, W, batch per GPU, first sample seed, DSEC-style targets, golden of the reference's CPU forward)
 CONFIGS = {
@@ -96,6 +99,32 @@ def corr_microbench(dev, iters=40):
     return {"kernel": "corr_mfma_dma_kernel<2,8,2,3,3,true>", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "us_per_launch": round(us, 1),
             "algorithmic_bytes": alg, "workload": "correlation2d 1x256x544x960 md=4 fp32 NCHW (BASELINE config 2)"}
+
+
+def knn_microbench(dev, iters=30):
+    """SURVEY.md 8(d) prices k_nearest_neighbor against the fp32 matrix peak: a pair costs 2 D + 3 flops.  The forward's
+    largest 3-D search, 8192 -> 4096 points, k = 16, both frames of the batch of 4 (B = 8), default tie mode."""
+    import rpeflow_amd.csrc as ops
+    g = torch.Generator(device="cpu").manual_seed(0)
+    B, M, Q, D, k = 8, NPTS, NPTS // 2, 3, 16
+    cloud = (torch.rand(B, D, M, generator=g) * 30).to(dev)
+    query = cloud[:, :, :Q].contiguous()
+    for _ in range(10):
+        ops.k_nearest_neighbor(cloud, query, k)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        ops.k_nearest_neighbor(cloud, query, k)
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) / iters * 1e3
+    pairs = B * M * Q
+    tflops = pairs * (2 * D + 3) / us / 1e6
+    return {"kernel": "knn_mfma_kernel<3> (+ the workgroup's tied queries redone the libstdc++ way)", "bound": "mfma", "achieved": round(tflops, 2),
+            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("knn16_pmc.json"),
+            "us_per_launch": round(us, 1), "pairs_per_s": round(pairs / us * 1e6), "algorithmic_bytes": 4 * B * D * (M + Q) + 8 * B * Q * k,
+            "workload": "k_nearest_neighbor 3-D, 8 x (8192 -> 4096), k = 16, fp32, indices as torch.topk returns them"}
 
 
 def pmc_traffic(suffix):
@@ -421,6 +450,7 @@ def main():
             line["epe_delta"] = epe_delta
         if world == 1 and not args.no_corr_microbench:
             line["roofline_corr"] = corr_microbench(dev)
+            line["roofline_knn"] = knn_microbench(dev)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.config)
     if rank == 0:

@@ -3,12 +3,17 @@ import sys
 
 import pytest
 
-# No MIOpen / HIP environment overrides here: tests, bench.py and rpeflow_amd.evaluate all run the library's default
-# convolution solvers (one policy, rpeflow_amd/runtime.py), and the parity bounds below are measured under them.
+# One runtime policy for tests, bench.py and rpeflow_amd.evaluate (rpeflow_amd/runtime.py): MIOpen's default solver
+# selection from a find-db seeded with the recorded search results of the benched shapes; nothing else is overridden.
+# The parity bounds below are measured under it.
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+from rpeflow_amd import runtime  # noqa: E402
+
+runtime.configure()  # (before anything initialises the GPU)
 
 
 def pytest_configure(config):
