@@ -372,12 +372,14 @@ def main():
                          "against": "the reference's CPU forward on this batch and these parameters (tests/golden/%s)" % cfg["golden"]}
             assert d["epe2d"] < 1e-4 and d["epe3d"] < 1e-4, "benched configuration is off the reference: %r" % (d,)
         # Untimed warm-up steps, immediately in front of the timed region: --warmup of them at least, and enough of them
-        # (up to 12, a quarter of a second) for the clocks to be back up -- the chip drops them within tens of milliseconds
-        # of idling (the host-side parity check above is such a pause) and needs ~50 ms of load to recover; without this the
-        # first timed steps of about every other run went 5-8 % slow.
+        # for the clocks to be back up -- the chip drops them within tens of milliseconds of idling (the host-side parity
+        # check above is such a pause) and needs ~50 ms of load to recover; without this the first timed steps of about
+        # every other run went 5-8 % slow.  Up to 40 replays / 0.8 s: about one process in five, always the first on a
+        # fresh machine, has ONE replay of ~48 ms instead of 18 among its first ~20 (per-step times, RPE_BENCH_STEP_TIMES=1;
+        # same solvers, same numbers: a one-off stall of the runtime, not of a kernel), which read as 205 instead of 222.
         t_settle = time.perf_counter()
         n_replays = 0
-        while n_replays < max(args.warmup, 1) or (n_replays < 12 and time.perf_counter() - t_settle < 0.25):
+        while n_replays < max(args.warmup, 1) or (n_replays < 40 and time.perf_counter() - t_settle < 0.8):
             fwd_step()
             n_replays += 1
             if n_replays % 4 == 0:

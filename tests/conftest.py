@@ -3,9 +3,8 @@ import sys
 
 import pytest
 
-# One runtime policy for tests, bench.py and rpeflow_amd.evaluate (rpeflow_amd/runtime.py): MIOpen's default solver
-# selection from a find-db seeded with the recorded search results of the benched shapes; nothing else is overridden.
-# The parity bounds below are measured under it.
+# One runtime policy for tests, bench.py and rpeflow_amd.evaluate (rpeflow_amd/runtime.py): the HIP graph-queue count it
+# sets and MIOpen's default solvers; nothing else is overridden.  The parity bounds below are measured under it.
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
