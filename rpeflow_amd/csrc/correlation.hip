@@ -46,7 +46,16 @@ __global__ __launch_bounds__(256) void corr_direct_kernel(const float *__restric
     if (y2 >= 0 && y2 < H && x2 >= 0 && x2 < W) {
         const float *a = in1 + (int64_t)b * C * HW + (int64_t)y * W + x;
         const float *c2 = in2 + (int64_t)b * C * HW + (int64_t)y2 * W + x2;
-        for (int c = 0; c < C; ++c) s = __fmaf_rn(a[c * HW], c2[c * HW], s);
+        // eight independent partial sums: as one chain of C dependent fma + load pairs the small levels (where this
+        // kernel runs) took ~58 us for a few MFLOP
+        float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = __fmaf_rn(a[(c + u) * HW], c2[(c + u) * HW], p[u]);
+        }
+        for (; c < C; ++c) p[0] = __fmaf_rn(a[c * HW], c2[c * HW], p[0]);
+        s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     }
     s = s / (float)C;
     if (slope != 0.f) s = s >= 0.f ? s : s * slope;
@@ -452,13 +461,14 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
     const int n = 2 * md + 1;
     const bool aligned = ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
     // pick (measured on MI355X, B=4, see profiles/): the LDS-DMA ring kernels where their alignment
-    // conditions hold -- 8 waves x 2 rows from 144x240 maps up, 4 waves x 2 rows down to 36x60 --
-    // the register-staged MFMA kernel for other large maps, one thread per output for the rest.
+    // conditions hold -- 8 waves x 2 rows from 144x240 maps up, 4 waves x 2 rows down to 72x120 --
+    // the register-staged MFMA kernel for other large maps, one thread per output for the rest: on maps of a few
+    // thousand pixels the tiled kernels are launch- and latency-bound (36x60, C = 96: 68 us against 32).
     if (algo == 0) {
         const bool dma_ok = md == MD && W % 4 == 0 && aligned && B <= 65535 && (int64_t)H * W * 4 < (1ll << 31);
         const int64_t px = (int64_t)H * W;
         if (dma_ok && C % 2 == 0 && px >= 144 * 240) algo = 7;
-        else if (dma_ok && C % 4 == 0 && px >= 36 * 60) algo = 4;
+        else if (dma_ok && C % 4 == 0 && px >= 72 * 120) algo = 4;
         else if (md == MD && px >= 72 * 120) algo = 2;
         else algo = 1;
     }

@@ -39,8 +39,8 @@ def main():
             us = timeit(lambda: ops.correlation2d(x, y, 4))
             us1 = timeit(lambda: W._correlation2d_algo(x, y, 4, 1))
             us2 = timeit(lambda: W._correlation2d_algo(x, y, 4, 2))
-            dma = [timeit(lambda: W._correlation2d_algo(x, y, 4, al)) if Wd % 4 == 0 else float("nan") for al in (4, 5, 6)]
-            print(f"corr model {B}x{C}x{H}x{Wd}: picked {us:9.1f} us   direct {us1:9.1f} us  mfma {us2:9.1f} us  dma4/5/6 {dma[0]:7.1f} {dma[1]:7.1f} {dma[2]:7.1f}")
+            dma = [timeit(lambda: W._correlation2d_algo(x, y, 4, al)) if Wd % 4 == 0 else float("nan") for al in (4, 7)]
+            print(f"corr model {B}x{C}x{H}x{Wd}: picked {us:9.1f} us   direct {us1:9.1f} us  mfma {us2:9.1f} us  dma4/7 {dma[0]:7.1f} {dma[1]:7.1f}")
     if "knn" in which:
         for (B, M, Q, D, k) in [(4, 8192, 4096, 3, 16), (4, 4096, 4096, 3, 16), (4, 4096, 34560, 2, 1), (4, 2048, 8640, 2, 1),
                                 (4, 4096, 4096, 3, 3), (4, 2048, 4096, 3, 3), (4, 256, 256, 3, 16), (4, 8192, 8192, 3, 16)]:
