@@ -61,7 +61,11 @@ __device__ __forceinline__ float column_sum(f32x4 v) {
     return s;
 }
 
-template <int T>  // Cp = 16 * T channels
+// SPLIT (wide layers): the four waves of a workgroup share ONE point, wave w takes output tiles w, w + 4, ... -- a quarter
+// of the MFMA chain and of the weight fragments each (one wave per point streamed T^2 KB of fragments through a chain of
+// 4 T^2 MFMAs: 45 us at C = 192 whatever the point count); the gather and the first layer are repeated per wave, they
+// are 1/T of the work.  Else four points a workgroup, one wave each.
+template <int T, bool SPLIT>  // Cp = 16 * T channels
 __global__ __launch_bounds__(256) void corr3d_cost_kernel(
     const float *__restrict__ p1rows, const float *__restrict__ p2rows, const float *__restrict__ wc4, const f32x4 *__restrict__ w2p,
     const float *__restrict__ b2, Net3 net, const float *__restrict__ xyz_q, int64_t q_sb, int64_t q_sd, int64_t q_sn,
@@ -72,7 +76,11 @@ __global__ __launch_bounds__(256) void corr3d_cost_kernel(
     for (int i = threadIdx.x; i < Cp; i += 256) wc_lds[i] = ((const f32x4 *)wc4)[i];
     __syncthreads();
     const int lane = rpe_lane(), kk = lane >> 4, j = lane & 15;
-    const int n = blockIdx.x * 4 + rpe_uniform((int)(threadIdx.x >> 6));
+    const int wave = rpe_uniform((int)(threadIdx.x >> 6));
+    const int n = SPLIT ? (int)blockIdx.x : blockIdx.x * 4 + wave;
+    constexpr int TP = SPLIT ? (T + 3) / 4 : T;  // output tiles of this wave: t = first + step * p
+    const int first = SPLIT ? wave : 0;
+    constexpr int step = SPLIT ? 4 : 1;
     const int b = blockIdx.y;
     if (n >= N) return;
     const int idx = (int)knn[((int64_t)b * N + n) * knn_sq + j];
@@ -85,14 +93,25 @@ __global__ __launch_bounds__(256) void corr3d_cost_kernel(
 
     const f32x4 *p1 = (const f32x4 *)(p1rows + ((int64_t)b * N + n) * Cp) + kk;
     const f32x4 *p2 = (const f32x4 *)(p2rows + ((int64_t)b * M + idx) * Cp) + kk;
-    f32x4 acc[T];
+    f32x4 acc[TP];
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < TP; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the row pieces and the weight fragments of K-group g + 1 are requested before the MFMAs of group g
+    auto load_w = [&](int g, f32x4 (&bf)[TP]) {
+        const f32x4 *wf = w2p + (int64_t)min(g, T - 1) * T * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < TP; ++p) bf[p] = wf[min(first + step * p, T - 1) * 64];
+    };
     f32x4 v1 = p1[0], v2 = p2[0];
+    f32x4 bfa[TP], bfb[TP];
+    load_w(0, bfa);
 #pragma unroll 2
     for (int g = 0; g < T; ++g) {
         const f32x4 a1 = v1, a2 = v2;
         if (g + 1 < T) v1 = p1[4 * (g + 1)], v2 = p2[4 * (g + 1)];
+        f32x4 (&cur)[TP] = (g & 1) ? bfb : bfa;
+        f32x4 (&nxt)[TP] = (g & 1) ? bfa : bfb;
+        if (g + 1 < T) load_w(g + 1, nxt);
         float hid[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -101,17 +120,16 @@ __global__ __launch_bounds__(256) void corr3d_cost_kernel(
             v = v + (w[0] * rel[0] + w[1] * rel[1] + w[2] * rel[2]);
             hid[s] = leaky(v, slope);
         }
-        const f32x4 *wf = w2p + (int64_t)g * T * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const f32x4 bf = wf[t * 64];
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[t] = mfma16(hid[s], bf[s], acc[t]);
-        }
+            for (int p = 0; p < TP; ++p) acc[p] = mfma16(hid[s], cur[p][s], acc[p]);
     }
     float *o = p2n_rows + ((int64_t)b * N + n) * Cp;
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
+    for (int p = 0; p < TP; ++p) {
+        const int t = first + step * p;
+        if (t >= T) continue;  // (wave-uniform)
         const int c = 16 * t + j;  // D layout: column = lane & 15
         const float bias2 = b2[c], bias3 = net.b3[c];
         const f32x2 w3 = net.w3p[t * 64 + lane];
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(256) void corr3d_cost_kernel(
         wn = mfma16(na1, w3[1], wn);
         f32x4 prod;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) prod[r] = fmaxf(wn[r] + bias3, 0.f) * leaky(acc[t][r] + bias2, slope);
+        for (int r = 0; r < 4; ++r) prod[r] = fmaxf(wn[r] + bias3, 0.f) * leaky(acc[p][r] + bias2, slope);
         const float s = column_sum(prod);
         if (kk == 0) o[c] = s;
     }
@@ -166,7 +184,8 @@ template <int T>
 int launch_cost(const float *p1rows, const float *p2rows, const float *wc4, const float *w2p, const float *b2, const Net3 &net, const float *xyz_q,
                 int64_t q_sb, int64_t q_sd, int64_t q_sn, const float *xyz_s, int64_t s_sb, int64_t s_sd, int64_t s_sn, const int64_t *knn,
                 int64_t knn_sq, int B, int N, int M, float slope, float *p2n_rows, hipStream_t st) {
-    hipLaunchKernelGGL(corr3d_cost_kernel<T>, dim3((N + 3) / 4, B), dim3(256), 0, st, p1rows, p2rows, wc4, (const f32x4 *)w2p, b2, net, xyz_q, q_sb,
+    constexpr bool kSplit = T >= 12;  // (measured: 46 -> 24 us at C = 192; C = 128 level, C <= 96 slower: the weight net and gather repeat per wave)
+    hipLaunchKernelGGL((corr3d_cost_kernel<T, kSplit>), dim3(kSplit ? N : (N + 3) / 4, B), dim3(256), 0, st, p1rows, p2rows, wc4, (const f32x4 *)w2p, b2, net, xyz_q, q_sb,
                        q_sd, q_sn, xyz_s, s_sb, s_sd, s_sn, knn, knn_sq, N, M, slope, p2n_rows);
     return rpe_launch_status();
 }
