@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 2
+#define RPE_ABI_VERSION 3
 
 #define RPE_EINVAL (-1)       /* bad size / null pointer */
 #define RPE_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
@@ -203,6 +203,14 @@ int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int6
                              const float *feat_2d, int C2, int H, int W,
                              const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
                              const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream);
+/* The same with sample(feat_2d, xy) handed in: sampled_2d [B,C2,N] through element strides (batch, channel, point) is what
+ * grid_sample_wrapper(feat_2d, xy) returned -- the 3-D fuser of the same (map, points) pair computes it anyway
+ * (RPEFlow_core.py:334-337, 394-395), and the per-point bilinear taps are the expensive half of this operator.  NULL: as above. */
+int rpe_project_feat_nn_corr_sampled(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
+                                     const float *feat_2d, int C2, int H, int W,
+                                     const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
+                                     const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
+                                     const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream);
 
 /* ---- PointConv in one kernel (models/pointconv.py:33-61, 90-122) -----------------
  * rpe_pointconv_pack_rows: rows[b][m][:] = [xyz[b][:,m] | srcs[0][b][:,m] | ... | zeros] -- cat([xyz, features]) channel-last

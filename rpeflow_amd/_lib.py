@@ -58,6 +58,8 @@ _PROTOTYPES = {
                             _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_project_feat_nn_corr": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int,
                                  _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
+    "rpe_project_feat_nn_corr_sampled": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64,
+                                         _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_pointconv_pack_rows": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_pointconv_fused": [_c_ptr, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                             _c_float, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -71,7 +73,7 @@ _PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 2  # RPE_ABI_VERSION of include/rpeflow_hip.h
+ABI_VERSION = 3  # RPE_ABI_VERSION of include/rpeflow_hip.h
 KNN_TIES = {"torch": 3, "set": 1, "index": 0}  # RPE_KNN_TIES_* (how equal distances are resolved)
 
 

@@ -227,14 +227,18 @@ __global__ __launch_bounds__(256) void resize_frames_kernel(const T *__restrict_
 __global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
                                                          const float *__restrict__ feat2d, int C2, int H, int W,
                                                          const float *__restrict__ feat3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn,
-                                                         int C3, int N, int c_per_block, float *__restrict__ rows) {
+                                                         int C3, int N, int c_per_block, const float *__restrict__ sampled,
+                                                         int64_t sm_sb, int64_t sm_sc, int64_t sm_sn, float *__restrict__ rows) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.z;
     if (i >= N) return;
     const int CT = C2 + C3;
     const int c0 = blockIdx.y * c_per_block, c1 = min(CT, c0 + c_per_block);
     float *row = rows + ((int64_t)b * N + i) * CT;
-    if (c0 < C2) {
+    if (c0 < C2 && sampled) {  // the caller has grid_sample_wrapper(feat_2d, xy) already (the 3-D fuser of the same pair needs it)
+        const float *sp = sampled + (int64_t)b * sm_sb + (int64_t)i * sm_sn;
+        for (int c = c0; c < min(c1, C2); ++c) row[c] = sp[(int64_t)c * sm_sc];
+    } else if (c0 < C2) {
         const float px = xy[(int64_t)b * xy_sb + (int64_t)i * xy_sn], py = xy[(int64_t)b * xy_sb + xy_sd + (int64_t)i * xy_sn];
         Bilinear bl;
         bl.setup(px, py, H, W, false);
@@ -392,9 +396,10 @@ RPE_API int rpe_upsample2x_pair(const float *a, int Ca, float scale_a, const flo
     return rpe_launch_status();
 }
 
-RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
-                                     int H, int W, const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
-                                     const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream) {
+RPE_API int rpe_project_feat_nn_corr_sampled(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
+                                             int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
+                                             const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
+                                             const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream) {
     if (!xy || !feat_2d || !feat_3d || !nn_idx || !out || !workspace || B < 0 || C2 < 1 || C3 < 0 || H < 1 || W < 1 || N < 1)
         return RPE_EINVAL;
     if (B == 0) return 0;
@@ -402,8 +407,15 @@ RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_
     hipStream_t st = (hipStream_t)stream;
     const int cpb = 8;  // channels per thread: 32-byte row segments, (C2+C3)/8 times the threads
     hipLaunchKernelGGL(point_rows_kernel, dim3((N + 255) / 256, (C2 + C3 + cpb - 1) / cpb, B), dim3(256), 0, st, xy, xy_sb, xy_sd,
-                       xy_sn, feat_2d, C2, H, W, feat_3d, f3_sb, f3_sc, f3_sn, C3, N, cpb, workspace);
+                       xy_sn, feat_2d, C2, H, W, feat_3d, f3_sb, f3_sc, f3_sn, C3, N, cpb, sampled_2d, sm_sb, sm_sc, sm_sn, workspace);
     hipLaunchKernelGGL(project_rows_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2,
                        H, W, C3, N, workspace, nn_idx, out);
     return rpe_launch_status();
+}
+
+RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
+                                     int H, int W, const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
+                                     const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream) {
+    return rpe_project_feat_nn_corr_sampled(xy, xy_sb, xy_sd, xy_sn, feat_2d, C2, H, W, nullptr, 0, 0, 0, feat_3d, f3_sb, f3_sc, f3_sn, C3, nn_idx,
+                                            B, N, workspace, out, stream);
 }

@@ -162,6 +162,8 @@ class HotPathWorkload(torch.nn.Module):
         correlation2d, k_nearest_neighbor, build_pc_pyramid = o.correlation2d, o.k_nearest_neighbor, o.build_pc_pyramid
         backwarp_2d, backwarp_3d, grid_sample_wrapper = o.backwarp_2d, o.backwarp_3d, o.grid_sample_wrapper
         knn_interpolation, project_feat_with_nn_corr = o.knn_interpolation, o.project_feat_with_nn_corr
+        import inspect
+        shares = "sampled_2d" in inspect.signature(project_feat_with_nn_corr).parameters
         sh, sw = self.sensor
         with t.span("fps+pyramid"):
             xyzs1, xyzs2, _, _ = build_pc_pyramid(self.pc1, self.pc2, N_SAMPLES)
@@ -191,10 +193,13 @@ class HotPathWorkload(torch.nn.Module):
             with t.span("knn3d_k16"):
                 knn_1in1 = k_nearest_neighbor(xyz1, xyz1, k=16)
 
-            with t.span("project_feat"):  # pyramid fusers 2D (RPEFlow_core.py:334-335)
-                project_feat_with_nn_corr(xy_both, f_2d_both, f_3d_both, nn_proj_both[..., 0])
+            # The 2-D and the 3-D fuser of a pair sample the same map at the same points (RPEFlow_core.py:334-337): the 3-D
+            # fuser's grid_sample_wrapper goes first and the 2-D fuser takes its result instead of repeating the taps
+            # (``shares``: the native operators; a CPU port of the reference passed as ``ops`` keeps the reference's calls).
             with t.span("grid_sample"):  # pyramid fusers 3D (:336-337)
-                grid_sample_wrapper(f_2d_both, xy_both)
+                sampled = grid_sample_wrapper(f_2d_both, xy_both)
+            with t.span("project_feat"):  # pyramid fusers 2D (:334-335)
+                project_feat_with_nn_corr(xy_both, f_2d_both, f_3d_both, nn_proj_both[..., 0], **({"sampled_2d": sampled} if shares else {}))
 
             if level == 5:
                 with t.span("torch_glue"):
@@ -215,22 +220,23 @@ class HotPathWorkload(torch.nn.Module):
             with t.span("correlation2d"):
                 corr_2d = torch.nn.functional.leaky_relu(correlation2d(f1_2d, f2_2d_warp, 4), 0.1)
 
+            with t.span("grid_sample"):  # corr fuser 3D (:376; utils via RPEFlow_core.py:107-108)
+                sampled = grid_sample_wrapper(torch.cat([corr_2d, self.flow_2d[level]], 1), xy1)
+                grid_sample_wrapper(ef_2d, xy1)
             with t.span("project_feat"):  # corr fuser 2D (:373)
                 flow_3d_to_2d = last_flow_3d[:, :2] * scale
-                project_feat_with_nn_corr(xy1, corr_2d, torch.cat([corr_3d, flow_3d_to_2d], 1), nn_proj1[..., 0])
-            with t.span("grid_sample"):  # corr fuser 3D (:376; utils via RPEFlow_core.py:107-108)
-                grid_sample_wrapper(torch.cat([corr_2d, self.flow_2d[level]], 1), xy1)
-                grid_sample_wrapper(ef_2d, xy1)
+                project_feat_with_nn_corr(xy1, corr_2d, torch.cat([corr_3d, flow_3d_to_2d], 1), nn_proj1[..., 0],
+                                          **({"sampled_2d": sampled[:, :corr_2d.shape[1]]} if shares else {}))
 
             with t.span("flow_estimator_3d"):
                 x_3d = [self.aligners[level](corr_3d), self.aligners[level](f1_3d), last_flow_3d, last_flow_feat_3d]
                 if not getattr(self.flow_estimator_3d, "concatenates", False):
                     x_3d = torch.cat(x_3d, 1)
                 flow_feat_3d = self.flow_estimator_3d(xyz1, x_3d, knn_1in1)
-            with t.span("project_feat"):  # decoder fusers (:394-395)
-                project_feat_with_nn_corr(xy1, self.flow_feat_2d[level], flow_feat_3d, nn_proj1[..., 0])
-            with t.span("grid_sample"):
-                grid_sample_wrapper(self.flow_feat_2d[level], xy1)
+            with t.span("grid_sample"):  # decoder fusers (:394-395)
+                sampled = grid_sample_wrapper(self.flow_feat_2d[level], xy1)
+            with t.span("project_feat"):
+                project_feat_with_nn_corr(xy1, self.flow_feat_2d[level], flow_feat_3d, nn_proj1[..., 0], **({"sampled_2d": sampled} if shares else {}))
 
             with t.span("torch_glue"):
                 flows_3d.append(last_flow_3d + self.flow_head_3d(flow_feat_3d))

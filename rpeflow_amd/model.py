@@ -268,8 +268,10 @@ class PyramidFeatureFuser2D(nn.Module):
         self.mi = Mutual_info_reg_2D(in_channels_2d, in_channels_2d // 2)
         self.fuse = CrossTransformerBlock2D(dim=in_channels_2d, num_heads=num_heads)
 
-    def forward(self, xy, feat_2d, feat_3d, nn_proj):
-        return self.fuse(feat_2d, self.mlps(self._ops.project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])))
+    def forward(self, xy, feat_2d, feat_3d, nn_proj, sampled_2d=None):
+        """``sampled_2d``: grid_sample_wrapper(feat_2d, xy) when the caller has it (the 3-D fuser of the pair computes it)."""
+        extra = {"sampled_2d": sampled_2d} if sampled_2d is not None else {}
+        return self.fuse(feat_2d, self.mlps(self._ops.project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0], **extra)))
 
 
 class PyramidFeatureFuser3D(nn.Module):
@@ -280,8 +282,10 @@ class PyramidFeatureFuser3D(nn.Module):
         self.mi = Mutual_info_reg_3D(in_channels_3d, in_channels_3d // 2)
         self.fuse = CrossTransformerBlock3D(dim=in_channels_3d, num_heads=num_heads)
 
-    def forward(self, xy, feat_2d, feat_3d):
-        return self.fuse(feat_3d, self.mlps(self._ops.grid_sample_wrapper(feat_2d, xy)))
+    def forward(self, xy, feat_2d, feat_3d, return_sampled=False):
+        sampled = self._ops.grid_sample_wrapper(feat_2d, xy)
+        fused = self.fuse(feat_3d, self.mlps(sampled))
+        return (fused, sampled) if return_sampled else fused
 
 
 class CorrFeatureFuser2D(nn.Module):
@@ -534,6 +538,8 @@ class RPEFlow_core(nn.Module):
             CorrFeatureFuser3D(ops, corr_ch, c, num_heads=h) for c, h in zip(widths, heads_p)])
         self.estimator_feat_fuser_2d = DecoderFeatureFuser2D(ops, self.flow_estimator_2d.flow_feat_dim, 64, num_heads=2)
         self.estimator_feat_fuser_3d = DecoderFeatureFuser3D(ops, self.flow_estimator_2d.flow_feat_dim, 64, num_heads=2)
+        import inspect  # (a CPU port of the reference passed as ``ops`` has the reference's signature, without ``sampled_2d``)
+        self._project_feat_params = tuple(inspect.signature(ops.project_feat_with_nn_corr).parameters)
 
         self.conv_last_2d = nn.Conv2d(self.flow_estimator_2d.flow_feat_dim, 2, kernel_size=3, stride=1, padding=1)
         self.conv_last_3d = nn.Conv1d(64, 3, kernel_size=1)
@@ -574,8 +580,11 @@ class RPEFlow_core(nn.Module):
             grid = mesh_grid(2 * batch_size, image_h, image_w, xy_both.device).reshape(2 * batch_size, 2, -1)
             nn_proj_both = k_nearest_neighbor(xy_both, grid, k=1)
             knn_1in1 = k_nearest_neighbor(xyzs1[level], xyzs1[level], k=k)
-            fused_2d = self.pyramid_feat_fusers_2d[level](xy_both, feats_2d_both[level], feats_3d_both[level], nn_proj_both)
-            fused_3d = self.pyramid_feat_fusers_3d[level](xy_both, feats_2d_both[level], feats_3d_both[level])
+            # (same map, same points, same stream: the 3-D fuser's samples serve the 2-D fuser's per-point rows)
+            share = "sampled_2d" in self._project_feat_params
+            fused_3d, sampled = self.pyramid_feat_fusers_3d[level](xy_both, feats_2d_both[level], feats_3d_both[level], return_sampled=True)
+            fused_2d = self.pyramid_feat_fusers_2d[level](xy_both, feats_2d_both[level], feats_3d_both[level], nn_proj_both,
+                                                          sampled_2d=sampled if share else None)
             # the aligners of the estimator inputs (:385-390) read the fused frame-1 features and the event features only
             aligned = (self.feature_aligners_2d[level](fused_2d[:batch_size]), self.efeature_aligners_2d[level](efeats_2d[level]),
                        self.feature_aligners_3d[level](fused_3d[:batch_size]))

@@ -315,10 +315,12 @@ def grid_sample_wrapper(feat_2d, xy):
 
 
 @torch.no_grad()
-def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None):
+def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=None):
     """utils.py:297-317.  xy [B,2,N], feat_2d [B,C2,H,W], feat_3d [B,C3,N], nn_indices [B,H*W]
     -> [B,C3+3,H,W].  Two launches (per-point rows, then per-pixel gather + correlation); the
-    reference runs grid_sample over all N points, three gathers, a product, a mean and a concat."""
+    reference runs grid_sample over all N points, three gathers, a product, a mean and a concat.
+    ``sampled_2d`` [B,C2,N] (optional, any strides): ``grid_sample_wrapper(feat_2d, xy)`` if the caller has it -- the 3-D
+    fuser of the same (map, points) pair computes it anyway; the per-point bilinear taps are then not repeated."""
     _lib.require_gpu(xy, feat_2d, feat_3d, op="project_feat_with_nn_corr")
     xy, feat_2d, feat_3d = _f32(xy), _f32(feat_2d).contiguous(), _f32(feat_3d)
     B, C2, H, W = feat_2d.shape
@@ -331,6 +333,13 @@ def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None):
     C3, N = feat_3d.shape[1], feat_3d.shape[2]
     out = torch.empty((B, C3 + 3, H, W), dtype=torch.float32, device=feat_2d.device)
     rows = torch.empty((B, N, C2 + C3), dtype=torch.float32, device=feat_2d.device)  # kernel scratch
+    if sampled_2d is not None:
+        sampled_2d = _f32(sampled_2d)
+        assert sampled_2d.shape == (B, C2, N)
+        _launch(feat_2d, "project_feat_with_nn_corr", _lib.lib().rpe_project_feat_nn_corr_sampled,
+                _ptr(xy), *xy.stride(), _ptr(feat_2d), C2, H, W, _ptr(sampled_2d), *sampled_2d.stride(), _ptr(feat_3d), *feat_3d.stride(), C3,
+                _ptr(nn_indices), B, N, _ptr(rows), _ptr(out))
+        return out
     _launch(feat_2d, "project_feat_with_nn_corr", _lib.lib().rpe_project_feat_nn_corr,
             _ptr(xy), *xy.stride(), _ptr(feat_2d), C2, H, W, _ptr(feat_3d), *feat_3d.stride(), C3,
             _ptr(nn_indices), B, N, _ptr(rows), _ptr(out))

@@ -428,3 +428,19 @@ def test_correlation3d_projection_is_hoistable():
     proj = m.project_stacked(torch.cat([dev(x["feat1"]), dev(x["feat2"])], 0))
     b = m(dev(x["xyz1"]), dev(x["feat1"]), dev(x["xyz2"]), dev(x["feat2"]), projected=proj)
     assert torch.equal(a, b)
+
+
+def test_project_feat_takes_the_3d_fusers_samples():
+    """project_feat_with_nn_corr(..., sampled_2d=grid_sample_wrapper(feat_2d, xy)) == project_feat_with_nn_corr(...): the 2-D
+    fuser reuses what the 3-D fuser of the same (map, points) pair sampled (RPEFlow_core.py:334-337), bit for bit."""
+    import rpeflow_amd.utils as U
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, C2, C3, H, W, N = 2, 19, 13, 18, 30, 700
+    feat_2d = torch.randn(B, C2 + 2, H, W, generator=g).to(DEV)
+    feat_3d = torch.randn(B, C3, N, generator=g).to(DEV)
+    xy = (torch.rand(B, 2, N, generator=g) * torch.tensor([W + 3.0, H + 3.0])[None, :, None] - 1.5).to(DEV)  # some points outside the map
+    nn = torch.randint(0, N, (B, H * W), generator=g).to(DEV)
+    plain = U.project_feat_with_nn_corr(xy, feat_2d[:, :C2].contiguous(), feat_3d, nn)
+    sampled = U.grid_sample_wrapper(feat_2d, xy)  # a wider map, as the correlation fuser has it: the first C2 channels are a strided view
+    shared = U.project_feat_with_nn_corr(xy, feat_2d[:, :C2].contiguous(), feat_3d, nn, sampled_2d=sampled[:, :C2])
+    assert torch.equal(plain, shared)
