@@ -175,6 +175,7 @@ class HotPathWorkload(torch.nn.Module):
             feats1_3d, feats2_3d = [f[:B] for f in feats_both], [f[B:] for f in feats_both]
 
         flows_3d, flow_feats_3d = [], []
+        interp_knn = {}  # level l -> the 3 nearest points of level l + 1 for every point of level l
         for level in range(5, 0, -1):
             xyz1, xyz2 = xyzs1[level], xyzs2[level]
             f1_2d, f2_2d, ef_2d = self.feats1_2d[level], self.feats2_2d[level], self.efeats_2d[level]
@@ -210,7 +211,11 @@ class HotPathWorkload(torch.nn.Module):
                 with t.span("backwarp_2d"):
                     f2_2d_warp = backwarp_2d(f2_2d, self.flow_2d[level], padding_mode="border")
                 with t.span("knn_interpolation"):
-                    up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], 1), xyz1)
+                    if shares:  # the same two clouds are interpolated again in the final up-sampling below: one search
+                        up, interp_knn[level] = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], 1), xyz1,
+                                                                  return_indices=True)
+                    else:
+                        up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], 1), xyz1)
                     last_flow_3d, last_flow_feat_3d = up[:, :3], up[:, 3:]
                 with t.span("backwarp_3d"):
                     xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
@@ -245,5 +250,6 @@ class HotPathWorkload(torch.nn.Module):
         flows_3d = flows_3d[::-1]
         with t.span("knn_interpolation"):  # final upsampling (:429-430)
             for i in range(len(flows_3d)):
-                flows_3d[i] = knn_interpolation(xyzs1[i + 1], flows_3d[i], xyzs1[i])
+                extra = {"knn_indices": interp_knn[i]} if i in interp_knn else {}
+                flows_3d[i] = knn_interpolation(xyzs1[i + 1], flows_3d[i], xyzs1[i], **extra)
         return flows_3d[0], corr_2d

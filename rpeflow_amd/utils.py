@@ -209,12 +209,17 @@ def _interpolate(input_xyz, input_features, query_xyz, knn_indices, k, scale=1.0
     return out
 
 
-def knn_interpolation(input_xyz, input_features, query_xyz, k=3):
+def knn_interpolation(input_xyz, input_features, query_xyz, k=3, knn_indices=None, return_indices=False):
     """utils.py:140-156.  [B,3,M], [B,C,M], [B,3,Q] -> [B,C,Q]: KNN kernel + one fused kernel
-    (the reference: KNN + 2 gathers + norm + clamp + reciprocal + 2 reductions + multiply)."""
+    (the reference: KNN + 2 gathers + norm + clamp + reciprocal + 2 reductions + multiply).
+    ``knn_indices`` [B,Q,>=k]: the k nearest inputs of every query when the caller has them -- the decoder interpolates
+    level l + 1 -> l inside the recurrence and again for the final up-sampling of the same two clouds
+    (RPEFlow_core.py:352, 426-430); ``return_indices``: also return them."""
     _lib.require_gpu(input_xyz, input_features, query_xyz, op="knn_interpolation")
-    knn_indices = k_nearest_neighbor(input_xyz, query_xyz, k)
-    return _interpolate(input_xyz, input_features, query_xyz, knn_indices, k)
+    if knn_indices is None:
+        knn_indices = k_nearest_neighbor(input_xyz, query_xyz, k)
+    out = _interpolate(input_xyz, input_features, query_xyz, knn_indices, k)
+    return (out, knn_indices) if return_indices else out
 
 
 def backwarp_3d(xyz1, xyz2, flow12, k=3):

@@ -444,3 +444,12 @@ def test_project_feat_takes_the_3d_fusers_samples():
     sampled = U.grid_sample_wrapper(feat_2d, xy)  # a wider map, as the correlation fuser has it: the first C2 channels are a strided view
     shared = U.project_feat_with_nn_corr(xy, feat_2d[:, :C2].contiguous(), feat_3d, nn, sampled_2d=sampled[:, :C2])
     assert torch.equal(plain, shared)
+
+
+def test_knn_interpolation_with_the_callers_indices():
+    g = torch.Generator(device="cpu").manual_seed(6)
+    coarse, fine = torch.randn(2, 3, 300, generator=g).to(DEV), torch.randn(2, 3, 700, generator=g).to(DEV)
+    feat = torch.randn(2, 11, 300, generator=g).to(DEV)
+    plain, idx = U.knn_interpolation(coarse, feat, fine, return_indices=True)
+    assert idx.shape == (2, 700, 3) and torch.equal(plain, U.knn_interpolation(coarse, feat, fine))
+    assert torch.equal(plain, U.knn_interpolation(coarse, feat, fine, knn_indices=idx))
