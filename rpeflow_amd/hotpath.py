@@ -152,7 +152,8 @@ class HotPathWorkload(torch.nn.Module):
             [torch.nn.Identity()] + [ops.Correlation3D(c, c, k=16) for c in PYRAMID_3D[1:]])
         self.flow_estimator_3d = ops.FlowEstimator3D([64 + 64 + 3 + 64, 128, 128, 64], None, conv_last=False, k=16)
         self.flow_head_3d = torch.nn.Conv1d(64, 3, kernel_size=1)
-        self.aligners = torch.nn.ModuleList([torch.nn.Conv1d(c, 64, 1) for c in PYRAMID_3D])
+        from .utils import Conv1dNormRelu  # feature_aligners_3d / correlation_aligners_3d are Conv1dNormRelu(c, 64) (RPEFlow_core.py:220-242)
+        self.aligners = torch.nn.ModuleList([Conv1dNormRelu(c, 64) for c in PYRAMID_3D])
         self.to(device).eval()
 
     @torch.no_grad()
