@@ -34,3 +34,20 @@ def test_launcher_world_size_must_match_gpus():
 def test_failed_rank_fails_the_launch():
     r = run("--gpus", "2", "--workload", "selftest", "--backend", "nccl")  # selftest refuses nccl: both ranks exit non-zero
     assert r.returncode != 0
+
+
+def test_hotpath_sequence_runs_with_the_cpu_port():
+    """bench.py's cpu_baseline leg (--workload hotpath) drives rpeflow_amd.hotpath.HotPathWorkload with the PyTorch-CPU port of
+    the reference path as ``ops``: the harness must not depend on the native operators' extra arguments."""
+    from types import SimpleNamespace
+
+    import torch
+
+    from oracle import torch_ref
+    from rpeflow_amd.hotpath import OP_NAMES, HotPathWorkload
+
+    ops = SimpleNamespace(**{n: getattr(torch_ref, n) for n in OP_NAMES})
+    wl = HotPathWorkload(batch=1, height=64, width=128, n_points=8192, device="cpu", ops=ops)
+    flow_3d, corr_2d = wl()
+    assert flow_3d.shape == (1, 3, 8192) and corr_2d.shape[:2] == (1, 81)
+    assert torch.isfinite(flow_3d).all() and torch.isfinite(corr_2d).all()
