@@ -339,7 +339,11 @@ def test_resize_flow2d_against_reference_golden(golden_dir, name):
 @torch.no_grad()
 @pytest.mark.parametrize("C0,C1,C2,N,norm,act", [(3, 16, 16, 100, "batch_norm", "leaky_relu"), (16, 16, 32, 777, "batch_norm", "leaky_relu"),
                                                  (13, 9, 21, 50, None, "relu"), (128, 128, 64, 1030, None, "leaky_relu"),
-                                                 (96, 96, 128, 513, "batch_norm", None), (24, 24, 16, 16, None, "leaky_relu")])
+                                                 (96, 96, 128, 513, "batch_norm", None), (24, 24, 16, 16, None, "leaky_relu"),
+                                                 # the remaining tile pairs of the split kernel (four waves over the output tiles,
+                                                 # tile counts that do not divide by four, a padded second layer)
+                                                 (64, 64, 96, 300, "batch_norm", "leaky_relu"), (128, 128, 192, 200, None, "relu"),
+                                                 (195, 128, 128, 130, None, "leaky_relu"), (32, 40, 70, 17, "batch_norm", "leaky_relu")])
 def test_fused_mlp1d_two_layers(C0, C1, C2, N, norm, act):
     """MLP1d (two Conv1dNormRelu, utils.py:65-98) in one launch against the same module on the CPU: odd channel counts,
     N not a multiple of 16, channel-first and PointConv-rows output."""
@@ -369,7 +373,7 @@ def test_fused_mlp1d_two_layers(C0, C1, C2, N, norm, act):
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("C0,C1,N", [(64, 64, 300), (5, 17, 33), (128, 64, 4096), (192, 64, 257)])
+@pytest.mark.parametrize("C0,C1,N", [(64, 64, 300), (5, 17, 33), (128, 64, 4096), (192, 64, 257), (60, 96, 100), (85, 128, 31), (80, 192, 50)])
 def test_fused_conv1d_single_layer(C0, C1, N):
     """Conv1dNormRelu (1x1) in one launch; a layer too wide for the kernel takes the library path and still agrees."""
     torch.manual_seed(C0 * 3 + N)
