@@ -142,6 +142,21 @@ def test_correlation3d_module(golden_dir):
     close_sum(out2, O.correlation3d(p, x["xyz1"], x["feat1"], x["xyz2"], x["feat2"], knn11, c["k"]))
 
 
+@torch.no_grad()
+@pytest.mark.parametrize("C,N", [(32, 150), (64, 130), (96, 70), (128, 97), (192, 61)])
+def test_correlation3d_every_pyramid_width(C, N):
+    """The model's Correlation3D widths (RPEFlow_core.py:228-234): every instantiation of the cost / n2n kernels -- C = 192 runs
+    the cost kernel with the four waves of a workgroup sharing one point -- against the oracle."""
+    r = I.rng(9100 + C)
+    xyz1 = np.ascontiguousarray(I.ids_cloud(r, 2, N).transpose(0, 2, 1))
+    xyz2 = (xyz1 + r.standard_normal(xyz1.shape, dtype=np.float32) * np.float32(0.2)).astype(np.float32)
+    feat1 = r.standard_normal((2, C, N), dtype=np.float32)
+    feat2 = r.standard_normal((2, C, N), dtype=np.float32)
+    m, p = _load(P3.Correlation3D(C, C, k=16), _shapes_corr3d(C), 4000 + C)
+    out = m(dev(xyz1), dev(feat1), dev(xyz2), dev(feat2))
+    close_sum(out, O.correlation3d(p, xyz1, feat1, xyz2, feat2, k=16))
+
+
 def _own_shapes(module):
     """(key, shape) in state-dict order: the reference's order when the module tree mirrors the reference's."""
     return [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
