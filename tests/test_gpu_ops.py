@@ -144,6 +144,23 @@ def test_knn_self_query_full_size_property():
     assert_bits_equal(dist[:, rows], od)
 
 
+def test_knn_nearest_pixel_search_full_size():
+    """The forward's largest 2-D search (every pixel of a 144 x 240 map against the 8192 projected points, k = 1:
+    project_feat_with_nn_corr's nn_proj, RPEFlow_core.py:325-327) through the matrix-pipe kernel: a random sample of rows
+    equals the oracle; every index is in range."""
+    r = I.rng(7250)
+    pts = I.ids_cloud(r, 2, 8192, 2)
+    gx, gy = np.meshgrid(np.arange(240, dtype=np.float32) * 0.125 - 14.5, np.arange(144, dtype=np.float32) * 0.125 - 8.5)
+    grid = np.broadcast_to(np.stack([gx.ravel(), gy.ravel()], -1)[None], (2, 34560, 2)).copy()
+    idx, dist = W.k_nearest_neighbor_with_distances(dev(pts), dev(grid), 1)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    assert idx.shape == (2, 34560, 1) and idx.min() >= 0 and idx.max() < 8192
+    rows = r.choice(34560, 400, replace=False)
+    oi, od = O.k_nearest_neighbor(pts, grid[:, rows], 1, return_dists=True)
+    assert np.array_equal(idx[:, rows], oi)
+    assert_bits_equal(dist[:, rows], od)
+
+
 def test_knn_errors():
     x = torch.rand(1, 10, 3, device=DEV)
     with pytest.raises(RuntimeError):  # fallback's topk: k > M
