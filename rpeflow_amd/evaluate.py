@@ -127,15 +127,36 @@ class GraphedForward:
         entry["graph"] = graph
         return entry
 
+    def _padded_entry(self, batch):
+        """A captured graph of the same sample shapes and a LARGER batch: the short last batch of a shard rides in its first
+        rows (samples are independent in eval mode; the other rows keep the previous batch), instead of costing a capture
+        and a MIOpen search for a batch size seen once."""
+        n = batch["pcs"].shape[0]
+        for key, entry in self.entries.items():
+            if all(tuple(batch[k].shape[1:]) == shape[1:] and batch[k].dtype == dtype and shape[0] > n for k, shape, dtype in key):
+                return entry
+        return None
+
     @torch.no_grad()
     def __call__(self, batch, next_batch=None):
         key = self._key(batch)
         entry = self.entries.get(key)
+        n = None
         if entry is None:
-            entry = self.entries[key] = self._capture(batch)
+            entry = self._padded_entry(batch)
+            if entry is not None:
+                n = batch["pcs"].shape[0]
+            else:
+                entry = self.entries[key] = self._capture(batch)
         static = entry["static"]
         for k in self.INPUTS:
-            static[k].copy_(batch[k], non_blocking=True)
+            (static[k] if n is None else static[k][:n]).copy_(batch[k], non_blocking=True)
+        if n is not None:  # rows n.. hold the previous batch: sample the mixture in place, announce nothing
+            if self.ahead:
+                entry["order"].copy_(self.model.sample_order(static))
+                entry["announced"] = None
+            entry["graph"].replay()
+            return {k: v[:n] for k, v in entry["out"].items()}
         if self.ahead:
             if entry["announced"] is not batch["pcs"]:  # nobody sampled this batch ahead of time
                 entry["order"].copy_(self.model.sample_order(static))
@@ -148,26 +169,45 @@ class GraphedForward:
         return entry["out"]
 
 
+def default_workers():
+    """Loader threads per rank: the cores this process may use (affinity, cgroup quota), shared by the ranks of the node,
+    minus the main thread; at most 4 (a batch is ~0.2 GB of memcpy: two threads keep up with one GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    return max(1, min(4, n // max(1, local) - 1))
+
+
 @torch.no_grad()
-def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=None, graph=None):
+def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=None, graph=None, workers=None,
+             processes=False, forward=None, stats=None):
     """Evaluates this rank's shard and returns the GLOBAL metrics (identical on every rank).
-    ``graph``: replay the forward from HIP graphs (default: on for GPU models that can be captured, i.e. IDS on device)."""
+    ``graph``: replay the forward from HIP graphs (default: on for GPU models that can be captured, i.e. IDS on device);
+    ``forward``: a GraphedForward to reuse (its captures outlive this call).  Input pipeline (rpeflow_amd/loader.py, the
+    counterpart of the reference's DataLoader(num_workers=8), eval_withocc.py:25-29): ``workers`` loader threads -- or
+    DataLoader worker processes with ``processes=True`` -- fill pinned host batches, a copy stream moves them to the device
+    one batch ahead of the forward.  ``stats``: a dict that receives the pipeline's counters."""
+    from .loader import InputPipeline
     acc = new_accumulator(device)
     mine = shard_indices(len(dataset), rank, world_size)
     if graph is None:  # capture costs a few seconds once: worth it from a few dozen batches on
-        graph = (torch.device(device).type == "cuda" and not getattr(model, "ids_on_host", False)
-                 and len(mine) >= 32 * batch_size)
-    forward = GraphedForward(model) if graph else None
-    load = lambda start: to_device(collate([dataset[i] for i in mine[start:start + batch_size]]), device)
-    starts = list(range(0, len(mine), batch_size))  # the last batch may be short
-    batch = load(starts[0]) if starts else None
-    for n, start in enumerate(starts):
-        upcoming = load(starts[n + 1]) if n + 1 < len(starts) else None  # resident one batch early: its sampling runs now
+        graph = forward is not None or (torch.device(device).type == "cuda" and not getattr(model, "ids_on_host", False)
+                                        and len(mine) >= 32 * batch_size)
+    if graph and forward is None:
+        forward = GraphedForward(model)
+    pipe = InputPipeline(dataset, mine, batch_size, device, workers=default_workers() if workers is None else workers, processes=processes)
+    for batch, upcoming in pipe.pairs():  # ``upcoming`` is resident already: its sampling runs inside this batch's replay
         accumulate(acc, forward(batch, upcoming) if graph else model(batch), batch)
-        batch = upcoming
     if world_size > 1:
         import torch.distributed as dist
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # the one collective of the evaluation
+    if stats is not None:
+        stats.update(pipe.stats, shard=len(mine), workers=pipe.workers)
     return finalize(acc), acc
 
 

@@ -1,0 +1,240 @@
+"""Input pipeline of the sharded evaluation: the counterpart of ``DataLoader(dataset, batch_size, num_workers=8,
+pin_memory=True)`` + ``copy_to_device`` (eval_withocc.py:25-29, 56; conf/test/things.yaml:5; utils.py:34-43).
+
+The forward of a batch of four 544x960 frame pairs takes ~18 ms on an MI355X; its inputs are 208 MB (4 x [3 MB
+uint8 frames + 42 MB event voxel + 6 MB target flow + clouds]).  A loop that builds the batch inline and copies it
+from pageable memory on the compute stream feeds 4 frame pairs a second.  Here the three stages run concurrently:
+
+  stage 1  ``workers`` threads (or DataLoader worker processes, ``processes=True``: datasets that hold the GIL while
+           decoding) load samples STRAIGHT into a ring of pinned host batches -- the collate is the load, there is no
+           per-sample tensor and no torch.stack pass;
+  stage 2  one copy thread moves filled host batches into a ring of device batches on a dedicated HIP stream (SDMA
+           engines: the copies overlap the previous batch's replay), in batch order;
+  stage 3  the consumer (evaluate()) iterates ``pairs()``: (batch j, batch j+1) with j+1 already resident, so that the
+           forward of j can run the furthest-point sampling of j+1 (model.forward_ahead).  The compute stream waits on
+           the copy stream's event, never the host; a device batch is handed back with an event recorded on the
+           compute stream, and the copy stream waits on that before overwriting it.
+
+Samples that already lie in pinned memory (``SyntheticPairs(pin=True)``, a registered memory-mapped set) skip stage 1:
+they are copied to the device from where they are.
+
+On a CPU device (the gloo tests) the same code runs without the device ring: stage 1 prefetches, stage 2 passes on.
+Batch order and contents never depend on the number of workers (tests/test_loader.py).
+"""
+import queue
+import threading
+
+import torch
+
+
+class _Stop(Exception):
+    pass
+
+
+def _put(q, item, stop):
+    while not stop.is_set():
+        try:
+            return q.put(item, timeout=0.1)
+        except queue.Full:
+            pass
+    raise _Stop
+
+
+def _get(q, stop):
+    while not stop.is_set():
+        try:
+            return q.get(timeout=0.1)
+        except queue.Empty:
+            pass
+    raise _Stop
+
+
+class InputPipeline:
+    def __init__(self, dataset, indices, batch_size, device, workers=4, depth=3, processes=False):
+        self.dataset, self.device = dataset, torch.device(device)
+        self.batches = [list(indices[s:s + batch_size]) for s in range(0, len(indices), batch_size)]  # the last one may be short
+        self.batch_size, self.workers, self.depth, self.processes = batch_size, max(1, int(workers)), max(3, int(depth)), processes
+        self.cuda = self.device.type == "cuda"
+        self.stats = {"batches": 0, "bytes": 0, "direct": 0}
+        self._threads, self._stop, self._error = [], threading.Event(), None
+
+    def __len__(self):
+        return len(self.batches)
+
+    # ------------------------------------------------------------------ stage 1: samples -> host batches
+    def _ring(self, like, count, **kw):
+        q = queue.Queue()
+        for _ in range(count):
+            q.put(({k: torch.empty((self.batch_size,) + tuple(v.shape), dtype=v.dtype, **kw) for k, v in like.items()}, None))
+        return q
+
+    def _sample(self, i):
+        first, self._first = self._first, None  # the sample _start() looked at is not loaded twice
+        return first[1] if first is not None and first[0] == i else self.dataset[i]
+
+    def _worker(self):
+        """One task = one SAMPLE of a batch (the first batch is resident after one sample's load time, not four).  Tasks and
+        host slots are handed out in batch order under one lock: the copier's next batch can never starve for a slot."""
+        try:
+            while True:
+                with self._next_lock:
+                    if self._next >= len(self._tasks):
+                        return
+                    j, n = self._tasks[self._next]
+                    self._next += 1
+                    if n == 0:
+                        slot, busy = (None, None) if self._direct else _get(self._free_host, self._stop)
+                        if busy is not None:
+                            busy.synchronize()  # the H2D that last read this slot
+                        self._open[j] = {"slot": slot, "left": len(self.batches[j]), "samples": [None] * len(self.batches[j])}
+                    rec = self._open[j]
+                sample = self._sample(self.batches[j][n])
+                if rec["slot"] is None:  # pinned samples: copied from where they lie
+                    rec["samples"][n] = sample
+                else:
+                    for k, v in sample.items():
+                        rec["slot"][k][n].copy_(v)
+                with self._filled_cv:
+                    rec["left"] -= 1
+                    if rec["left"] == 0:
+                        del self._open[j]
+                        self._filled[j] = ("direct", rec["samples"], len(rec["samples"])) if rec["slot"] is None else ("slot", rec["slot"], len(rec["samples"]))
+                        self._filled_cv.notify_all()
+        except _Stop:
+            pass
+        except BaseException as e:  # noqa: BLE001 -- surfaces in the consumer
+            self._fail(e)
+
+    def _process_source(self):
+        """stage 1 with DataLoader worker processes: batches arrive collated in shared memory, one thread stages them."""
+        from torch.utils.data import DataLoader, Subset
+        try:
+            flat = [i for b in self.batches for i in b]
+            dl = DataLoader(Subset(self.dataset, flat), batch_size=self.batch_size, shuffle=False, num_workers=self.workers,
+                            collate_fn=lambda s: {k: torch.stack([x[k] for x in s]) for k in s[0]}, prefetch_factor=2)
+            for j, cpu in enumerate(dl):
+                n = len(self.batches[j])
+                if self.cuda:
+                    slot, busy = _get(self._free_host, self._stop)
+                    if busy is not None:
+                        busy.synchronize()
+                    for k, v in cpu.items():
+                        slot[k][:n].copy_(v)
+                else:
+                    slot = cpu
+                with self._filled_cv:
+                    self._filled[j] = ("slot", slot, n)
+                    self._filled_cv.notify_all()
+        except _Stop:
+            pass
+        except BaseException as e:  # noqa: BLE001
+            self._fail(e)
+
+    # ------------------------------------------------------------------ stage 2: host batches -> device batches, in order
+    def _copier(self):
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)
+            for j in range(len(self.batches)):
+                with self._filled_cv:
+                    while j not in self._filled:
+                        if self._stop.is_set():
+                            raise _Stop
+                        self._filled_cv.wait(0.1)
+                    kind, src, n = self._filled.pop(j)
+                if not self.cuda:  # CPU consumer: the host batch itself is what it gets; handed back on release
+                    back = None if self.processes else (lambda src=src: self._free_host.put((src, None)))
+                    _put(self._ready, ({k: v[:n] for k, v in src.items()}, None, back), self._stop)
+                    continue
+                dev, released = _get(self._free_dev, self._stop)
+                with torch.cuda.stream(self._copy_stream):
+                    if released is not None:
+                        self._copy_stream.wait_event(released)  # the consumer's last kernel that read this device batch
+                    if kind == "slot":
+                        for k, v in src.items():
+                            dev[k][:n].copy_(v[:n], non_blocking=True)
+                            self.stats["bytes"] += v[:n].numel() * v.element_size()
+                    else:
+                        for s, sample in enumerate(src):
+                            for k, v in sample.items():
+                                dev[k][s].copy_(v, non_blocking=True)
+                                self.stats["bytes"] += v.numel() * v.element_size()
+                        self.stats["direct"] += 1
+                    done = torch.cuda.Event()
+                    done.record(self._copy_stream)
+                if kind == "slot":
+                    self._free_host.put((src, done))
+                _put(self._ready, ({k: v[:n] for k, v in dev.items()}, done, dev), self._stop)  # dev: handed back with an event
+        except _Stop:
+            pass
+        except BaseException as e:  # noqa: BLE001
+            self._fail(e)
+
+    def _fail(self, e):
+        self._error = e
+        self._stop.set()
+
+    # ------------------------------------------------------------------ stage 3: the consumer
+    def _start(self):
+        self._stop.clear()
+        self._error = None
+        self._next, self._next_lock = 0, threading.Lock()
+        self._tasks, self._open = [(j, n) for j, ids in enumerate(self.batches) for n in range(len(ids))], {}
+        self._filled, self._filled_cv = {}, threading.Condition()
+        first = self.dataset[self.batches[0][0]]  # defines keys, shapes and dtypes
+        self._first = (self.batches[0][0], first)
+        self._direct = self.cuda and not self.processes and all(v.is_pinned() for v in first.values())
+        no_host_ring = self._direct or (self.processes and not self.cuda)
+        self._free_host = queue.Queue() if no_host_ring else self._ring(first, self.depth + self.workers, pin_memory=self.cuda)
+        self._free_dev = self._ring(first, self.depth, device=self.device) if self.cuda else queue.Queue()
+        self._ready = queue.Queue(maxsize=self.depth)
+        self._copy_stream = torch.cuda.Stream(self.device) if self.cuda else None
+        targets = [self._process_source] if self.processes else [self._worker] * self.workers
+        self._threads = [threading.Thread(target=t, daemon=True) for t in targets + [self._copier]]
+        for t in self._threads:
+            t.start()
+
+    def _take(self):
+        """Next device batch; the compute stream is made to wait for its copy."""
+        try:
+            batch, done, dev = _get(self._ready, self._stop)
+        except _Stop:
+            raise RuntimeError("input pipeline failed") from self._error
+        if done is not None:
+            torch.cuda.current_stream(self.device).wait_event(done)
+        self.stats["batches"] += 1
+        return batch, dev
+
+    def _release(self, dev):
+        if callable(dev):
+            dev()
+        elif dev is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))  # everything the consumer launched on this batch so far
+            self._free_dev.put((dev, ev))
+
+    def close(self):
+        self._stop.set()
+        for t in self._threads:
+            t.join(timeout=10)
+        self._threads = []
+
+    def pairs(self):
+        """Yields (batch j, batch j+1 or None) in shard order.  Batch j is handed back to the ring when the consumer asks for
+        the next pair: consume it (launch everything that reads it) before that."""
+        if not self.batches:
+            return
+        self._start()
+        try:
+            cur = self._take()
+            for j in range(len(self.batches)):
+                nxt = self._take() if j + 1 < len(self.batches) else None
+                yield cur[0], (nxt[0] if nxt is not None else None)
+                self._release(cur[1])
+                cur = nxt
+        finally:
+            self.close()
+
+    def __iter__(self):
+        for batch, _ in self.pairs():
+            yield batch

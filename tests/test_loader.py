@@ -1,0 +1,121 @@
+"""Input pipeline of the sharded evaluation (rpeflow_amd/loader.py; reference: DataLoader(num_workers=8) + copy_to_device,
+eval_withocc.py:25-29, 56): batch order and contents must not depend on workers, threads vs processes, or the device ring."""
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from rpeflow_amd import evaluate as E
+from rpeflow_amd.loader import InputPipeline
+from rpeflow_amd.synthetic import SyntheticPairs
+
+
+class Tiny(torch.utils.data.Dataset):
+    """Sample i is recognisable from its contents; loading takes a (seeded) random while so workers finish out of order."""
+
+    def __init__(self, n, delay=0.0, fail_at=None):
+        self.n, self.delay, self.fail_at = n, delay, fail_at
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if self.delay:
+            time.sleep(self.delay * ((i * 7919) % 5) / 4)
+        if i == self.fail_at:
+            raise ValueError("sample %d is broken" % i)
+        return {"a": torch.full((3, 5), float(i)), "b": torch.tensor([i, 2 * i], dtype=torch.int64), "c": torch.full((4,), i % 251, dtype=torch.uint8)}
+
+
+def check(batches, indices, batch_size):
+    want = [indices[s:s + batch_size] for s in range(0, len(indices), batch_size)]
+    assert len(batches) == len(want)
+    for got, ids in zip(batches, want):
+        assert got["a"].shape == (len(ids), 3, 5) and got["b"].dtype == torch.int64 and got["c"].dtype == torch.uint8
+        assert got["a"][:, 0, 0].tolist() == [float(i) for i in ids]
+        assert got["b"][:, 1].tolist() == [2 * i for i in ids]
+
+
+@pytest.mark.parametrize("workers,processes", [(1, False), (4, False), (2, True)])
+def test_order_and_contents_do_not_depend_on_the_workers(workers, processes):
+    indices = list(range(1, 40, 3))  # 13 samples: a short last batch
+    pipe = InputPipeline(Tiny(64, delay=0.004), indices, 4, "cpu", workers=workers, processes=processes)
+    got = [{k: v.clone() for k, v in b.items()} for b in pipe]
+    check(got, indices, 4)
+    assert pipe.stats["batches"] == 4
+
+
+def test_pairs_hands_out_the_next_batch_early_and_recycles_slots():
+    indices = list(range(30))
+    pipe = InputPipeline(Tiny(30), indices, 4, "cpu", workers=3)
+    seen, previous_next = [], None
+    for batch, upcoming in pipe.pairs():
+        if previous_next is not None:  # what was announced is what arrives, the very same tensors
+            assert batch["a"] is previous_next["a"]
+        seen.append({k: v.clone() for k, v in batch.items()})
+        previous_next = upcoming
+    assert previous_next is None
+    check(seen, indices, 4)  # 8 batches through a ring of depth + workers = 6 host slots: slots were reused
+
+
+def test_a_failing_sample_surfaces_in_the_consumer():
+    pipe = InputPipeline(Tiny(20, fail_at=9), list(range(20)), 4, "cpu", workers=2)
+    with pytest.raises(RuntimeError) as info:
+        list(pipe)
+    assert isinstance(info.value.__cause__, ValueError)
+
+
+def test_leaving_the_loop_early_stops_the_threads():
+    before = threading.active_count()
+    pipe = InputPipeline(Tiny(400, delay=0.001), list(range(400)), 4, "cpu", workers=4)
+    for n, _ in enumerate(pipe):
+        if n == 2:
+            break
+    assert threading.active_count() == before
+
+
+def test_empty_shard():
+    assert list(InputPipeline(Tiny(4), [], 4, "cpu")) == []
+
+
+def test_cached_synthetic_set_repeats_its_distinct_samples():
+    data = SyntheticPairs(7, H=24, W=40, N=512, distinct=3, cache=True)
+    assert data.prepare(threads=2) >= 0 and len(data.cache) == 3
+    assert data[0]["pcs"] is data[3]["pcs"] and torch.equal(data[1]["images"], data[4]["images"])
+    fresh = SyntheticPairs(7, H=24, W=40, N=512)
+    assert torch.equal(data[5]["event_voxel"], fresh[2]["event_voxel"])  # 5 % 3 == 2: the generator's sample 2
+
+
+def test_evaluate_is_independent_of_the_pipeline():
+    from tests.test_evaluate import fake_model
+    data = SyntheticPairs(9, H=24, W=40, N=512)
+    ref = E.new_accumulator("cpu")
+    for s in range(0, 9, 2):
+        batch = E.collate([data[i] for i in range(s, min(s + 2, 9))])
+        E.accumulate(ref, fake_model(batch), batch)
+    for workers, processes in ((1, False), (3, False), (2, True)):
+        stats = {}
+        _, acc = E.evaluate(fake_model, data, 2, "cpu", workers=workers, processes=processes, stats=stats)
+        assert np.array_equal(acc.numpy(), ref.numpy())
+        assert stats["batches"] == 5 and stats["shard"] == 9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pin", [False, True])
+def test_device_ring_delivers_the_samples(pin):
+    """Pinned ring + copy stream (and the no-staging path for pinned samples): 12 batches through 3 device slots."""
+    data = SyntheticPairs(23, H=64, W=96, N=1024, distinct=5, cache=True, pin=pin)
+    pipe = InputPipeline(data, list(range(23)), 2, "cuda:0", workers=3)
+    n = 0
+    for batch, upcoming in pipe.pairs():
+        ids = list(range(2 * n, min(2 * n + 2, 23)))
+        for k in ("images", "event_voxel", "pcs", "flow_2d"):
+            want = torch.stack([data[i][k] for i in ids])
+            assert batch[k].device.type == "cuda" and torch.equal(batch[k].cpu(), want), (n, k)
+        if upcoming is not None:
+            assert torch.equal(upcoming["pcs"][0].cpu(), data[2 * n + 2]["pcs"])
+        (batch["event_voxel"] * 2).sum()  # consumer work on the compute stream before the slot goes back
+        n += 1
+    assert n == 12 and pipe.stats["batches"] == 12 and (pipe.stats["direct"] == 12) == pin
