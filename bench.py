@@ -139,17 +139,7 @@ def pmc_traffic(suffix):
     return None
 
 
-def usable_cores():
-    """Cores this process may really use: affinity mask, capped by a cgroup CPU quota if there is one
-    (os.cpu_count() reports the host's cores even inside a quota-limited container)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
-    except (OSError, ValueError):
-        pass
-    return n
+usable_cores = runtime.usable_cores  # affinity mask capped by the cgroup CPU quota (the GPU box grants 16 of 256 cores)
 
 
 def make_batch(B, device, first_seed=1000, H=H, W=W, dsec=False):
@@ -241,7 +231,7 @@ def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist,
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    stats = {}
+    stats = {"timeline": bool(os.environ.get("RPE_EVAL_TIMELINE"))}  # diagnostic: per-batch device times (adds 3 event records a batch)
     t0 = time.perf_counter()
     metrics, _ = E.evaluate(model, data, batch_size, dev, rank, world, forward=forward, workers=workers, stats=stats)  # ends on the host: finalize() reads the sums
     mine_dt = time.perf_counter() - t0
@@ -264,6 +254,7 @@ def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist,
         "collective": "one SUM all-reduce of float64[12] (%s)" % (backend if dist is not None else "single rank: none"),
         "metrics": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in metrics.items() if k != "counts"},
         "samples": metrics["counts"]["3d"] / NPTS,
+        **({"timeline_ms": stats["timeline_ms"]} if "timeline_ms" in stats else {}),
     }
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 3
+#define RPE_ABI_VERSION 4
 
 #define RPE_EINVAL (-1)       /* bad size / null pointer */
 #define RPE_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
@@ -333,6 +333,21 @@ int rpe_events_to_voxel(const int *pixel_sorted, const double *t_sorted, const i
  *   scale / shift may be NULL (1 / 0).  act: 0 none, 1 relu, 2 leaky_relu(slope).                              */
 int rpe_channel_affine_act(float *y, const float *scale, const float *shift, int B, int C, int64_t P,
                            int act, float slope, rpe_stream_t stream);
+
+/* ---- evaluation metric sums (eval_withocc.py:65-108, eval_noocc.py:57-99) ----------------------------------
+ * The caller of the hot path: per batch, the twelve sums the reference's Evaluator keeps (there: a Python loop over
+ * samples with ~12 .item() host syncs each).  acc[12] float64, ADDED to:
+ *   [0..3]  2-D: #valid pixels, sum EPE, #(EPE < 1 px), #(EPE > 3 and EPE/|gt| > 0.05)
+ *   [4..7]  3-D: #valid points, sum EPE, #(EPE < 0.05), #(EPE < 0.1)
+ *   [8..11] the 3-D group again over valid points with occ_mask == 0 (occ_mask NULL: untouched)
+ * flow2d [B,2,HW], target2d [B,c2,HW] (c2 = 3: channel 2 is the validity mask, > 0 valid), flow3d [B,3,N], target3d
+ * [B,c3,N] (c3 = 4: channel 3 is the mask), occ_mask [B,N] or NULL; all contiguous fp32.  EPE = sqrt(sum diff^2) in fp32,
+ * NaN EPEs are invalid; sums in float64, per-block partials in `workspace` (rpe_eval_workspace_doubles doubles) added in
+ * a fixed order: no atomics.                                                                                       */
+int rpe_eval_workspace_doubles(int64_t n_pixels, int64_t n_points);
+int rpe_eval_accumulate(const float *flow2d, const float *target2d, int target2d_channels, int B, int64_t HW,
+                        const float *flow3d, const float *target3d, int target3d_channels, int64_t N, const float *occ_mask,
+                        double *workspace, double *acc, rpe_stream_t stream);
 
 /* ---- diagnostics -------------------------------------------------------------
  * Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation

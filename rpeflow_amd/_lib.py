@@ -68,12 +68,14 @@ _PROTOTYPES = {
                         _c_float, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr],
     "rpe_ids_forward": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int, _c_int,
                         _c_float, _c_float, _c_float, _c_float, _c_float, _c_ptr, _c_ptr],
+    "rpe_eval_workspace_doubles": [_c_i64, _c_i64],
+    "rpe_eval_accumulate": [_c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_ptr, _c_ptr, _c_int, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     "rpe_ids_flow_inverse": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int,
                              _c_float, _c_float, _c_float, _c_float, _c_float, _c_ptr, _c_ptr],
 }
 
 _lib = None
-ABI_VERSION = 3  # RPE_ABI_VERSION of include/rpeflow_hip.h
+ABI_VERSION = 4  # RPE_ABI_VERSION of include/rpeflow_hip.h
 KNN_TIES = {"torch": 3, "set": 1, "index": 0}  # RPE_KNN_TIES_* (how equal distances are resolved)
 
 

@@ -2,6 +2,7 @@
 
 One object per csrc/*.hip (compiled in parallel, only when the source or a header changed), then one link."""
 import glob
+import hashlib
 import os
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
@@ -39,28 +40,56 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _hipcc():
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _command(src):
+    return [_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-I", INCLUDE, "-I", SRC_DIR, "-c", src, "-o", _obj(src)]
+
+
+def _stamp(src):
+    """Hash of the compiler path and the full command line an object was (or would be) built with: an object compiled
+    with other flags (-ffp-contract=off, -amdgpu-mfma-vgpr-form: the bit-exact kernels depend on them) or by another
+    hipcc is stale even if it is newer than its source."""
+    return hashlib.sha256("\0".join(_command(src)).encode()).hexdigest()
+
+
+def _stamp_matches(src):
+    path = _obj(src) + ".cmd"
+    return os.path.exists(path) and open(path).read().strip() == _stamp(src)
+
+
+def _obj_stale(src, hdrs):
+    return _stale(_obj(src), [src] + hdrs) or not _stamp_matches(src)
+
+
 def needs_build():
-    return _stale(LIB, sources() + headers())
+    return _stale(LIB, sources() + headers()) or any(_obj_stale(s, headers()) for s in sources())
 
 
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdrs = headers()
-    todo = [s for s in sources() if force or _stale(_obj(s), [s] + hdrs)]
+    todo = [s for s in sources() if force or _obj_stale(s, hdrs)]
 
     def compile_one(src):
-        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-I", INCLUDE, "-I", SRC_DIR, "-c", src, "-o", _obj(src)]
+        cmd = _command(src)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(_obj(src) + ".cmd", "w") as f:
+            f.write(_stamp(src) + "\n")
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as pool:
         list(pool.map(compile_one, todo))
     for stale in set(glob.glob(os.path.join(OBJ_DIR, "*.o"))) - {_obj(s) for s in sources()}:
         os.remove(stale)  # object of a source file that no longer exists
+        if os.path.exists(stale + ".cmd"):
+            os.remove(stale + ".cmd")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in sources()]
     if verbose:
         print(" ".join(cmd), flush=True)

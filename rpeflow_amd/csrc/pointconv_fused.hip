@@ -331,12 +331,9 @@ template <int MT, int WM, int NT, int WN, int KS = 1>
 int launch_fused(PcArgs a, int B, int nsplit, hipStream_t st) {
     constexpr int BM = 16 * MT * WM;
     constexpr int smem = KS * BM * 256 * 4 + BM * 16 * 4;
-    static bool configured = false;  // idempotent attribute: a race only repeats the call
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)pointconv_fused_kernel<MT, WM, NT, WN, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    // per launch: the attribute belongs to the CURRENT device (a process may drive several GPUs), as knn / fps / correlation set theirs
+    hipError_t e = hipFuncSetAttribute((const void *)pointconv_fused_kernel<MT, WM, NT, WN, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
     a.tiles = (a.Q + BM - 1) / BM;
     a.nsplit = nsplit;
     const int64_t nwg = (int64_t)a.tiles * nsplit * B;

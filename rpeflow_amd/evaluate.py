@@ -29,11 +29,40 @@ def new_accumulator(device):
     return torch.zeros(len(FIELDS), dtype=torch.float64, device=device)
 
 
+_WORKSPACE = {}
+
+
+def _accumulate_device(acc, outputs, inputs):
+    """The same sums in one pass + a fixed-order reduction on the device (csrc/eval.hip, rpe_eval_accumulate): two
+    launches instead of ~45 tensor ops over the full-resolution maps between two replays of the forward."""
+    from . import _lib
+    f32 = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+    f2p, f3p, f2t, f3t = f32(outputs["flow_2d"]), f32(outputs["flow_3d"]), f32(inputs["flow_2d"]), f32(inputs["flow_3d"])
+    occ = f32(inputs["occ_mask_3d"]) if "occ_mask_3d" in inputs else None
+    B, HW, N = f2p.shape[0], f2p.shape[2] * f2p.shape[3], f3p.shape[2]
+    assert f2p.shape[1] == 2 and f3p.shape[1] == 3 and f2t.shape[0] == B and f3t.shape[0] == B and f3t.shape[2] == N
+    lib = _lib.lib()
+    need = lib.rpe_eval_workspace_doubles(B * HW, B * N)
+    key = (acc.device, torch.cuda.current_stream(acc.device).cuda_stream)
+    work = _WORKSPACE.get(key)
+    if work is None or work.numel() < need:
+        work = _WORKSPACE[key] = torch.empty(need, dtype=torch.float64, device=acc.device)
+    with torch.cuda.device(acc.device):
+        rc = lib.rpe_eval_accumulate(f2p.data_ptr(), f2t.data_ptr(), f2t.shape[1], B, HW, f3p.data_ptr(), f3t.data_ptr(), f3t.shape[1], N,
+                                     occ.data_ptr() if occ is not None else None, work.data_ptr(), acc.data_ptr(), _lib.stream_of(acc))
+    _lib.check(rc, "eval_accumulate")
+    return acc
+
+
 @torch.no_grad()
 def accumulate(acc, outputs, inputs):
     """Adds one batch to ``acc``.  Per-sample arithmetic of eval_withocc.py:65-108: EPE maps
     sqrt(sum diff^2) in fp32; masks from the extra target channel (if any) and not-NaN; Fl =
-    epe > 3 and epe/|gt| > 0.05; the non-occluded group only where inputs carry occ_mask_3d."""
+    epe > 3 and epe/|gt| > 0.05; the non-occluded group only where inputs carry occ_mask_3d.
+    Device accumulators go through the HIP kernel (no tensor-op fallback on the GPU); the tensor-op form below is the
+    host-side statement of the same sums for CPU tensors (the gloo tests, the accumulator goldens)."""
+    if acc.is_cuda:
+        return _accumulate_device(acc, outputs, inputs)
     f2p, f3p = outputs["flow_2d"].float(), outputs["flow_3d"].float()
     f2t, f3t = inputs["flow_2d"].float(), inputs["flow_3d"].float()
     m2 = f2t[:, 2] > 0 if f2t.shape[1] > 2 else torch.ones_like(f2t[:, 0], dtype=torch.bool)
@@ -171,16 +200,10 @@ class GraphedForward:
 
 def default_workers():
     """Loader threads per rank: the cores this process may use (affinity, cgroup quota), shared by the ranks of the node,
-    minus the main thread; at most 4 (a batch is ~0.2 GB of memcpy: two threads keep up with one GPU)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
-    except (OSError, ValueError):
-        pass
+    minus the main and the copy thread; at most 4 (a batch is 0.2 GB of memcpy: two threads keep up with one GPU)."""
+    from .runtime import usable_cores
     local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    return max(1, min(4, n // max(1, local) - 1))
+    return max(1, min(4, usable_cores() // max(1, local) - 1))
 
 
 @torch.no_grad()
@@ -201,13 +224,26 @@ def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=Non
     if graph and forward is None:
         forward = GraphedForward(model)
     pipe = InputPipeline(dataset, mine, batch_size, device, workers=default_workers() if workers is None else workers, processes=processes)
+    marks = [] if (stats is not None and stats.get("timeline") and torch.device(device).type == "cuda") else None
+    mark = (lambda: marks.append(torch.cuda.Event(enable_timing=True)) or marks[-1].record()) if marks is not None else (lambda: None)
     for batch, upcoming in pipe.pairs():  # ``upcoming`` is resident already: its sampling runs inside this batch's replay
-        accumulate(acc, forward(batch, upcoming) if graph else model(batch), batch)
+        mark()
+        out = forward(batch, upcoming) if graph else model(batch)
+        mark()
+        accumulate(acc, out, batch)
+        mark()
     if world_size > 1:
         import torch.distributed as dist
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # the one collective of the evaluation
     if stats is not None:
         stats.update(pipe.stats, shard=len(mine), workers=pipe.workers)
+        if marks:  # device time per batch: the forward (input copies into the graph's buffers + replay), the metric sums, and
+            torch.cuda.synchronize()  # the gap before the next batch's first launch (host-side stalls, waits for an H2D copy)
+            ms = lambda a, b: a.elapsed_time(b)
+            n = len(marks) // 3
+            stats["timeline_ms"] = {"forward": round(sum(ms(marks[3 * i], marks[3 * i + 1]) for i in range(n)) / n, 3),
+                                    "accumulate": round(sum(ms(marks[3 * i + 1], marks[3 * i + 2]) for i in range(n)) / n, 3),
+                                    "gap": round(sum(ms(marks[3 * i + 2], marks[3 * i + 3]) for i in range(n - 1)) / max(1, n - 1), 3)}
     return finalize(acc), acc
 
 

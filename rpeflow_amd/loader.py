@@ -24,6 +24,7 @@ Batch order and contents never depend on the number of workers (tests/test_loade
 import queue
 import threading
 
+import numpy as np
 import torch
 
 
@@ -47,6 +48,17 @@ def _get(q, stop):
         except queue.Empty:
             pass
     raise _Stop
+
+
+def _memcpy(dst, src):
+    """One thread, one memcpy, GIL released.  (Tensor.copy_ would fan a 42 MB copy out over the calling thread's whole
+    OpenMP team -- 128 threads on the GPU box, whose container grants 16 cores: with four loader threads doing that at
+    once the CFS quota throttled every thread of the process, the main one included, and the staging ring filled at 5-10
+    GB/s instead of 40.)"""
+    if src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous() and src.device.type == "cpu":
+        np.copyto(dst.numpy(), src.numpy())
+    else:
+        dst.copy_(src)
 
 
 class InputPipeline:
@@ -93,7 +105,7 @@ class InputPipeline:
                     rec["samples"][n] = sample
                 else:
                     for k, v in sample.items():
-                        rec["slot"][k][n].copy_(v)
+                        _memcpy(rec["slot"][k][n], v)
                 with self._filled_cv:
                     rec["left"] -= 1
                     if rec["left"] == 0:
@@ -119,7 +131,7 @@ class InputPipeline:
                     if busy is not None:
                         busy.synchronize()
                     for k, v in cpu.items():
-                        slot[k][:n].copy_(v)
+                        _memcpy(slot[k][:n], v)
                 else:
                     slot = cpu
                 with self._filled_cv:

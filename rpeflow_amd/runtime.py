@@ -12,6 +12,19 @@ import os
 GRAPH_QUEUES = "3"
 
 
+def usable_cores():
+    """Cores this process may really use: affinity mask, capped by a cgroup CPU quota if there is one (os.cpu_count()
+    reports the host's cores even inside a quota-limited container: 256 on the GPU box, which grants 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def configure():
     """Idempotent; an explicit setting in the environment wins.  Returns what is in effect (bench.py prints it in ``config``).
     The MIOpen convolution solvers are left at the library's defaults everywhere -- tests, bench and evaluation alike.
@@ -20,5 +33,9 @@ def configure():
     from the reference's EPEs, both inside the 1e-4 bound (tests/test_model.py; seeding the user find-db with one run's
     search results was tried and does not remove the second set)."""
     os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", GRAPH_QUEUES)
+    # PyTorch sizes its OpenMP teams by the HOST's core count; inside a CPU quota that oversubscribes every host-side
+    # tensor op (collate, Tensor.copy_) and gets the whole process throttled.  Read when OpenMP initialises.
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # multi-process GPU work on this driver needs dmabuf IPC
-    return {"DEBUG_HIP_FORCE_GRAPH_QUEUES": os.environ["DEBUG_HIP_FORCE_GRAPH_QUEUES"], "miopen_solvers": "library defaults"}
+    return {"DEBUG_HIP_FORCE_GRAPH_QUEUES": os.environ["DEBUG_HIP_FORCE_GRAPH_QUEUES"], "OMP_NUM_THREADS": os.environ["OMP_NUM_THREADS"],
+            "miopen_solvers": "library defaults"}

@@ -54,6 +54,12 @@ def _act(kind):
     raise NotImplementedError("Unknown activation function: %s" % kind)
 
 
+def _inference_only(*tensors):
+    """The fused paths work on detached parameter copies and build no autograd graph: they may only run when nothing
+    would be differentiated -- grad mode off, or neither the input nor a parameter requires grad."""
+    return not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in tensors)
+
+
 def affine_epilogue(owner, bias, norm, act):
     """(scale, shift, act) of the per-channel epilogue y = act(scale*x + shift) that a bias add, eval-mode BatchNorm
     and the activation amount to -- or None when that does not apply (training BN, InstanceNorm).  Cached on ``owner``
@@ -98,8 +104,8 @@ class _ConvNormRelu(nn.Module):
         return affine_epilogue(self, self.conv_fn.bias, self.norm_fn, self.relu_fn)
 
     def forward(self, x):
-        epi = self._epilogue() if x.is_cuda else None
-        if epi is None:
+        epi = self._epilogue() if x.is_cuda and _inference_only(x, *self.parameters()) else None
+        if epi is None:  # the library path, differentiable
             return self.relu_fn(self.norm_fn(self.conv_fn(x)))
         # convolution without its bias (MIOpen / hipBLASLt), then bias + BatchNorm + activation in ONE in-place kernel
         from .restormer_ops import channel_affine_act_
@@ -116,7 +122,7 @@ class Conv1dNormRelu(_ConvNormRelu):
     dims = 1
 
     def forward(self, x):
-        if x.is_cuda and x.dim() == 3:
+        if x.is_cuda and x.dim() == 3 and _inference_only(x, *self.parameters()):
             y = fused_mlp1d(x, [self])  # one launch instead of GEMM + epilogue (None: a shape the kernel is not built for)
             if y is not None:
                 return y
@@ -148,7 +154,7 @@ class MLP1d(_MLP):
 
     def forward(self, x, rows_xyz=None):
         """``rows_xyz`` [B,3,N]: return the result as PointConv rows [xyz | y | 0] (rpeflow_amd.pointconv.PackedRows)."""
-        if x.is_cuda and x.dim() == 3 and len(self.convs) == 2:
+        if x.is_cuda and x.dim() == 3 and len(self.convs) == 2 and _inference_only(x, *self.parameters()):
             y = fused_mlp1d(x, list(self.convs), rows_xyz=rows_xyz)  # both layers in one launch
             if y is not None:
                 return y
@@ -399,7 +405,8 @@ def _mlp_pack(blocks):
     first = blocks[0]
     tensors = [t for blk in blocks for t in (*blk.parameters(), *blk.buffers())]
     key = (len(blocks),) + tuple((t.data_ptr(), t._version) for t in tensors)
-    cache = getattr(first, "_mlp_cache", None)
+    slot = "_mlp_cache%d" % len(blocks)  # one slot per chain length: a two-layer miss and a one-layer hit do not evict each other
+    cache = getattr(first, slot, None)
     if cache is not None and cache[0] == key:
         return cache[1]
     packed = None
@@ -441,7 +448,7 @@ def _mlp_pack(blocks):
             if len(blocks) == 2:
                 packed.update(w2=pack_w(convs[1], tiles[1], tiles[0]), ss2=pack_ss(epis[1], tiles[1], convs[1].out_channels),
                               act2=_ACT_CODE[epis[1][2]])
-    first._mlp_cache = (key, packed)
+    setattr(first, slot, (key, packed))
     return packed
 
 

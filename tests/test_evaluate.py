@@ -164,3 +164,36 @@ def test_graph_replayed_evaluation_matches_eager():
     # threshold hit counts: the library convs may pick another solver under capture (~1e-5 on the flow), which can
     # move a few points of a random-weight model across a threshold
     np.testing.assert_allclose(a_g[hits], a_e[hits], atol=16, rtol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dsec,B,H,W,N", [(False, 3, 24, 40, 517), (True, 2, 31, 33, 1000), (False, 4, 544, 960, 8192), (True, 3, 480, 640, 8192)])
+def test_device_accumulate_kernel_equals_the_tensor_form(dsec, B, H, W, N):
+    """rpe_eval_accumulate (csrc/eval.hip) against the host-side tensor statement of eval_withocc.py:65-108 on the same
+    batch: counts and threshold hits exactly, EPE sums to float64 re-association; NaN predictions, masked targets,
+    zero-length ground-truth vectors (epe / |gt| = inf) and occlusion masks included; twice into the same accumulator."""
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    t2 = torch.randn(B, 2, H, W, generator=g) * 5.0
+    t2[:, :, ::7, ::5] = 0.0                                                 # |gt| = 0
+    t3 = torch.randn(B, 3, N, generator=g) * 0.2
+    inputs = {"flow_2d": torch.cat([t2, (torch.rand(B, 1, H, W, generator=g) < 0.8).float()], 1), "flow_3d": t3}
+    if dsec:
+        inputs["flow_3d"] = torch.cat([t3, (torch.rand(B, 1, N, generator=g) < 0.9).float()], 1)
+    else:
+        inputs["occ_mask_3d"] = (torch.rand(B, N, generator=g) < 0.2).float()
+    out = {"flow_2d": t2 + torch.randn(B, 2, H, W, generator=g) * torch.tensor([0.3, 4.0]).view(1, 2, 1, 1),
+           "flow_3d": t3 + torch.randn(B, 3, N, generator=g) * 0.05}
+    out["flow_2d"][:, 0, 3::11, 2::13] = float("nan")
+    out["flow_3d"][:, 2, ::97] = float("nan")
+    ref = E.new_accumulator("cpu")
+    E.accumulate(ref, out, inputs)
+    E.accumulate(ref, out, inputs)
+    acc = E.new_accumulator("cuda:0")
+    d = lambda t: {k: v.to("cuda:0") for k, v in t.items()}
+    E.accumulate(acc, d(out), d(inputs))
+    E.accumulate(acc, {k: v.to("cuda:0").transpose(0, 1).contiguous().transpose(0, 1) for k, v in out.items()}, d(inputs))  # strided predictions
+    got, want = acc.cpu().numpy(), ref.numpy()
+    hits = [0, 2, 3, 4, 6, 7, 8, 10, 11]
+    assert np.array_equal(got[hits], want[hits]), (got, want)
+    np.testing.assert_allclose(got[[1, 5, 9]], want[[1, 5, 9]], rtol=1e-12)
+    assert want[3] > 0 and want[2] > 0 and (dsec or want[8] > 0)
