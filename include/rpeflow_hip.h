@@ -81,6 +81,23 @@ typedef struct rpe_knn_job {
 } rpe_knn_job;
 int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, int tie_mode, rpe_stream_t stream);
 
+/* The same search on spatially ordered point sets (k >= 2; csrc/knn_grid.h).  rpe_knn_grid_build puts a set [B,N,D] into
+ * Morton-cell order: `sorted` [B][D+1][Npad] (coordinates, then |p|^2; Npad = N rounded up to 64), `perm` [B][Npad] (original
+ * index of every sorted position), `boxes` [B][Npad/64 + 1][8] (bounding box of every 64-point step); buffer sizes PER
+ * BATCH ELEMENT from rpe_knn_grid_sizes.  rpe_knn_grid_search then returns exactly rpe_knn's idx / dist for the ORIGINAL
+ * arrays (which it still takes: equal distances are resolved on them) while computing distances only to the steps
+ * whose box can hold a neighbour.  One built set serves every search on that cloud; the queries are a built set too (the
+ * cloud's own for a self search).  rpe_knn_grid_supported: 1 if (B, M, Q, D, k, tie_mode) is a case the kernel takes
+ * (2 <= k, k + 1 <= 32, 64 k <= M <= 16384), else use rpe_knn.                                                        */
+int rpe_knn_grid_sizes(int N, int D, int64_t *sorted_floats, int64_t *perm_ints, int64_t *box_floats);
+int rpe_knn_grid_build(const float *pts, int64_t sb, int64_t sn, int64_t sd, int B, int N, int D, float *sorted, int32_t *perm,
+                       float *boxes, rpe_stream_t stream);
+int rpe_knn_grid_supported(int B, int M, int Q, int D, int k, int tie_mode);
+int rpe_knn_grid_search(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,
+                        int64_t q_sn, int64_t q_sd, int B, int M, int Q, int D, int k, int tie_mode,
+                        const float *in_sorted, const int32_t *in_perm, const float *in_boxes, const float *q_sorted,
+                        const int32_t *q_perm, int64_t *idx, float *dist, rpe_stream_t stream);
+
 /* ---- squared_distance (wrapper.py:40-52) ------------------------------------
  * out[b][i][j] = distance above between xyz1[b][i] and xyz2[b][j]; out contiguous. */
 int rpe_squared_distance(const float *xyz1, int64_t a_sb, int64_t a_sn, int64_t a_sd,

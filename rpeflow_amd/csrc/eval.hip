@@ -103,13 +103,14 @@ __global__ __launch_bounds__(kThreads) void eval_partial_kernel(const float *__r
     }
 }
 
-// acc[j] += sum over blocks of partial[block][j], blocks in order
-__global__ __launch_bounds__(RPE_WAVE) void eval_reduce_kernel(const double *__restrict__ partial, int blocks, double *__restrict__ acc) {
-    const int j = threadIdx.x;
-    if (j >= kSums) return;
+// acc[j] += sum over blocks of partial[block][j] in a fixed order: 16 lanes per sum take every 16th block, then a butterfly
+__global__ __launch_bounds__(kSums * 16) void eval_reduce_kernel(const double *__restrict__ partial, int blocks, double *__restrict__ acc) {
+    const int j = threadIdx.x >> 4, l = threadIdx.x & 15;
     double s = 0.0;
-    for (int b = 0; b < blocks; ++b) s += partial[(int64_t)b * kSums + j];
-    acc[j] += s;
+    for (int b = l; b < blocks; b += 16) s += partial[(int64_t)b * kSums + j];
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (l == 0) acc[j] += s;
 }
 
 }  // namespace
@@ -134,6 +135,6 @@ RPE_API int rpe_eval_accumulate(const float *flow2d, const float *target2d, int 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(eval_partial_kernel, dim3((unsigned)(g2 + g3)), dim3(kThreads), 0, st, flow2d, target2d, target2d_channels, HW, n2,
                        flow3d, target3d, target3d_channels, N, n3, occ_mask, (int)g2, workspace);
-    hipLaunchKernelGGL(eval_reduce_kernel, dim3(1), dim3(RPE_WAVE), 0, st, workspace, (int)(g2 + g3), acc);
+    hipLaunchKernelGGL(eval_reduce_kernel, dim3(1), dim3(kSums * 16), 0, st, workspace, (int)(g2 + g3), acc);
     return rpe_launch_status();
 }

@@ -1036,6 +1036,8 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_kernel(Knn
     if (exact_ties) drain_ties<D>(&tq, J, b, k, lane, wave);
 }
 
+#include "knn_grid.h"
+
 // ---- k == 1 on large clouds, many queries: the same matrix sweep, a running (minimum, index) per lane ------------------------
 // A lane sees its query's points in index order (register 4 b + r = point 16 b + 4 g + r of the step), so a strict '<'
 // keeps the first index inside the lane; the four lanes of a query then merge by (distance, index).  5 matrix + ~50 vector
@@ -1304,5 +1306,58 @@ RPE_API int rpe_squared_distance(const float *xyz1, int64_t a_sb, int64_t a_sn, 
         hipLaunchKernelGGL(sqdist_kernel<2>, grid, block, 0, st, xyz1, a_sb, a_sn, a_sd, xyz2, b_sb, b_sn, b_sd, N1, N2, out);
     else
         hipLaunchKernelGGL(sqdist_kernel<1>, grid, block, 0, st, xyz1, a_sb, a_sn, a_sd, xyz2, b_sb, b_sn, b_sd, N1, N2, out);
+    return rpe_launch_status();
+}
+
+/* ---- spatially ordered clouds (knn_grid.h) --------------------------------------------------------------------------- */
+RPE_API int rpe_knn_grid_sizes(int N, int D, int64_t *sorted_floats, int64_t *perm_ints, int64_t *box_floats) {
+    if (N < 1 || D < 1 || D > 3 || !sorted_floats || !perm_ints || !box_floats) return RPE_EINVAL;
+    const int64_t npad = ((int64_t)N + 63) & ~63ll;
+    *sorted_floats = (D + 1) * npad;
+    *perm_ints = npad;
+    *box_floats = (npad / 64 + 1) * kGridBoxFloats;
+    return 0;
+}
+
+RPE_API int rpe_knn_grid_build(const float *pts, int64_t sb, int64_t sn, int64_t sd, int B, int N, int D, float *sorted, int32_t *perm,
+                               float *boxes, rpe_stream_t stream) {
+    if (!pts || !sorted || !perm || !boxes || B < 0 || N < 1 || D < 1 || D > 3) return RPE_EINVAL;
+    if (B > 65535) return RPE_EUNSUPPORTED;
+    if (B == 0) return 0;
+    GridBuildJobs jobs;
+    jobs.job[0] = GridBuildJob{pts, sb, sn, sd, N, sorted, perm, boxes};
+    dim3 grid(B, 1), block(kGridBuildThreads);
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 3) hipLaunchKernelGGL(knn_grid_build_kernel<3>, grid, block, 0, st, jobs);
+    else if (D == 2) hipLaunchKernelGGL(knn_grid_build_kernel<2>, grid, block, 0, st, jobs);
+    else hipLaunchKernelGGL(knn_grid_build_kernel<1>, grid, block, 0, st, jobs);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_knn_grid_supported(int B, int M, int Q, int D, int k, int tie_mode) {
+    const int kk = (tie_mode != RPE_KNN_TIES_INDEX && k < M && k < RPE_WAVE) ? k + 1 : k;
+    return D >= 1 && D <= 3 && k >= 2 && kk <= 32 && M >= 64 * k && M >= 256 && M <= kGridMaxM && Q >= 1 && B >= 1 && B <= 65535;
+}
+
+RPE_API int rpe_knn_grid_search(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,
+                                int64_t q_sn, int64_t q_sd, int B, int M, int Q, int D, int k, int tie_mode,
+                                const float *in_sorted, const int32_t *in_perm, const float *in_boxes, const float *q_sorted,
+                                const int32_t *q_perm, int64_t *idx, float *dist, rpe_stream_t stream) {
+    if (!input || !query || !idx || !in_sorted || !in_perm || !in_boxes || !q_sorted || !q_perm) return RPE_EINVAL;
+    if (tie_mode != RPE_KNN_TIES_TORCH && tie_mode != RPE_KNN_TIES_SET && tie_mode != RPE_KNN_TIES_INDEX) return RPE_EINVAL;
+    if (B < 0 || M <= 0 || Q < 0 || k < 1 || k > M) return RPE_EINVAL;
+    if (B == 0 || Q == 0) return 0;
+    if (!rpe_knn_grid_supported(B, M, Q, D, k, tie_mode)) return RPE_EUNSUPPORTED;
+    GridJobs jobs;
+    jobs.job[0].j = rpe_knn_job{input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, M, Q, idx, dist};
+    jobs.job[0].in = rpe_grid_set{in_sorted, in_perm, in_boxes};
+    jobs.job[0].q = rpe_grid_set{q_sorted, q_perm, nullptr};
+    const int per_block = kWavesPerBlock * kMq;
+    dim3 grid((Q + per_block - 1) / per_block, B, 1), block(kWavesPerBlock * RPE_WAVE);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = sizeof(GridBlockLds);
+    if (D == 3) hipLaunchKernelGGL(knn_grid_kernel<3>, grid, block, lds, st, jobs, k, tie_mode);
+    else if (D == 2) hipLaunchKernelGGL(knn_grid_kernel<2>, grid, block, lds, st, jobs, k, tie_mode);
+    else hipLaunchKernelGGL(knn_grid_kernel<1>, grid, block, lds, st, jobs, k, tie_mode);
     return rpe_launch_status();
 }

@@ -128,10 +128,41 @@ def k_nearest_neighbor(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int,
     return k_nearest_neighbor_ties(input_xyz, query_xyz, k, cpp_impl=cpp_impl, ties="torch")
 
 
-def k_nearest_neighbor_ties(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cpp_impl=True, ties="torch"):
+class GridSet:
+    """A point set [B,N,D] in Morton-cell order (rpe_knn_grid_build, csrc/knn_grid.h): the spatial order
+    k_nearest_neighbor's grid kernel searches in.  One built set serves every search on that cloud -- as the cloud or as
+    the queries; ``points`` is the channel-last view it was built from (kept: equal distances are resolved on it)."""
+
+    def __init__(self, points):
+        B, N, D = points.shape
+        npad = (N + 63) // 64 * 64
+        self.points, self.shape = points, (B, N, D)
+        self.sorted = torch.empty((B, D + 1, npad), dtype=torch.float32, device=points.device)
+        self.perm = torch.empty((B, npad), dtype=torch.int32, device=points.device)
+        self.boxes = torch.empty((B, npad // 64 + 1, 8), dtype=torch.float32, device=points.device)
+        with torch.cuda.device(points.device):
+            rc = _lib.lib().rpe_knn_grid_build(_ptr(points), *points.stride(), B, N, D, _ptr(self.sorted), _ptr(self.perm),
+                                               _ptr(self.boxes), _lib.stream_of(points))
+        _lib.check(rc, "knn_grid_build")
+
+
+def _same_view(a, b):
+    return a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
+
+
+# the grid kernel's regime (measured against the sweeping kernels, B = 4 / 8): k >= 2 searches of clouds from 1024 points with
+# at least 16384 queries a launch -- where rpe_knn would run the matrix-pipe sweep
+_GRID_MIN_M, _GRID_MIN_QUERIES = 1024, 16384
+
+
+def k_nearest_neighbor_ties(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cpp_impl=True, ties="torch", algo="auto",
+                            input_grid=None, query_grid=None, return_distances=False):
     """k_nearest_neighbor with the treatment of EQUAL distances chosen per call (no global state): "torch" -- as above;
     "set" -- the reference's neighbour SET, equal distances inside it in index order (cheaper); "index" -- lowest index
-    first (RPE_KNN_TIES_* of include/rpeflow_hip.h)."""
+    first (RPE_KNN_TIES_* of include/rpeflow_hip.h).
+    ``algo``: "auto" | "grid" (spatially ordered sets, csrc/knn_grid.h; raises where the kernel does not apply) | "sweep"
+    (every query against every point); identical results either way.  ``input_grid`` / ``query_grid``: GridSet of the
+    cloud / the queries when the caller holds one (a cloud is searched several times per pyramid level)."""
     _as_points(input_xyz, "k_nearest_neighbor", "input_xyz")
     _as_points(query_xyz, "k_nearest_neighbor", "query_xyz")
     if input_xyz.shape[1] <= 3:  # channel_first to channel_last (a view; the kernel takes strides)
@@ -148,11 +179,25 @@ def k_nearest_neighbor_ties(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k:
     if k > M:
         raise RuntimeError("selected index k out of range")  # what the fallback's topk raises
     idx = torch.empty((B, Q, k), dtype=torch.int64, device=input_xyz.device)
+    dist = torch.empty((B, Q, k), dtype=torch.float32, device=input_xyz.device) if return_distances else None
+    lib, mode = _lib.lib(), _lib.KNN_TIES[ties]
+    grid_ok = B > 0 and Q > 0 and bool(lib.rpe_knn_grid_supported(B, M, Q, D, int(k), mode))
+    if algo == "grid" and not grid_ok:
+        raise RuntimeError("k_nearest_neighbor: the grid kernel takes 2 <= k <= 31 (30 with tie handling), 64 k <= M <= 16384")
+    use_grid = grid_ok and (algo == "grid" or (algo == "auto" and (input_grid is not None or (M >= _GRID_MIN_M and B * Q >= _GRID_MIN_QUERIES))))
     with torch.cuda.device(input_xyz.device):
-        rc = _lib.lib().rpe_knn(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(),
-                                B, M, Q, D, int(k), _lib.KNN_TIES[ties], _ptr(idx), _NULL, _lib.stream_of(input_xyz))
+        if use_grid:
+            gi = input_grid if input_grid is not None else GridSet(input_xyz)
+            gq = query_grid if query_grid is not None else (gi if _same_view(input_xyz, query_xyz) else GridSet(query_xyz))
+            assert gi.shape == (B, M, D) and gq.shape == (B, Q, D), "GridSet built from another point set"
+            rc = lib.rpe_knn_grid_search(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(), B, M, Q, D, int(k), mode,
+                                         _ptr(gi.sorted), _ptr(gi.perm), _ptr(gi.boxes), _ptr(gq.sorted), _ptr(gq.perm), _ptr(idx),
+                                         _ptr(dist) if dist is not None else _NULL, _lib.stream_of(input_xyz))
+        else:
+            rc = lib.rpe_knn(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(),
+                             B, M, Q, D, int(k), mode, _ptr(idx), _ptr(dist) if dist is not None else _NULL, _lib.stream_of(input_xyz))
     _lib.check(rc, "k_nearest_neighbor")
-    return idx
+    return (idx, dist) if return_distances else idx
 
 
 def k_nearest_neighbor_multi(pairs, k: int, ties="torch"):
@@ -183,21 +228,10 @@ def k_nearest_neighbor_multi(pairs, k: int, ties="torch"):
     return outs
 
 
-def k_nearest_neighbor_with_distances(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, ties="torch"):
+def k_nearest_neighbor_with_distances(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, ties="torch", algo="auto"):
     """k_nearest_neighbor plus the sorted squared distances the kernel selected on
     (what ``squared_distance(query, input).topk(k, largest=False).values`` holds)."""
-    if input_xyz.shape[1] <= 3:
-        input_xyz, query_xyz = input_xyz.transpose(1, 2), query_xyz.transpose(1, 2)
-    _lib.require_gpu(input_xyz, query_xyz, op="k_nearest_neighbor")
-    B, M, D = input_xyz.shape
-    Q = query_xyz.shape[1]
-    idx = torch.empty((B, Q, k), dtype=torch.int64, device=input_xyz.device)
-    dist = torch.empty((B, Q, k), dtype=torch.float32, device=input_xyz.device)
-    with torch.cuda.device(input_xyz.device):
-        rc = _lib.lib().rpe_knn(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(),
-                                B, M, Q, D, int(k), _lib.KNN_TIES[ties], _ptr(idx), _ptr(dist), _lib.stream_of(input_xyz))
-    _lib.check(rc, "k_nearest_neighbor")
-    return idx, dist
+    return k_nearest_neighbor_ties(input_xyz, query_xyz, k, ties=ties, algo=algo, return_distances=True)
 
 
 def _correlation2d_algo(input1, input2, max_displacement, algo, leaky_slope=0.0):

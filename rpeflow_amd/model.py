@@ -19,7 +19,7 @@ from .csrc import correlation2d as native_correlation2d
 from .csrc.wrapper import _correlation2d_algo as correlation2d_fused_leaky
 from .hotpath import native_ops
 from .pwc3d_core import FlowEstimator3D as NativeFlowEstimator3D
-from .utils import Conv1dNormRelu, Conv2dNormRelu, mesh_grid, resize_frames, upsample2x_pair
+from .utils import Conv1dNormRelu, Conv2dNormRelu, conv_module, mesh_grid, resize_frames, upsample2x_pair
 from .utils import backwarp_2d as native_backwarp_2d
 
 
@@ -132,7 +132,8 @@ class _GatedFeedForward(nn.Module):
     def forward(self, x):
         if x.is_cuda:  # depth-wise conv + gelu gate in one kernel
             from .restormer_ops import dwconv3
-            return self.project_out(dwconv3([self.project_in(x)], self.dwconv.weight, self.dwconv.bias, gate=True))
+            hidden = dwconv3([conv_module(self.project_in, x)], self.dwconv.weight, self.dwconv.bias, gate=True)
+            return conv_module(self.project_out, hidden)
         a, b = self.dwconv(self.project_in(x)).chunk(2, dim=1)
         return self.project_out(F.gelu(a) * b)
 
@@ -704,7 +705,7 @@ class RPEFlow_core(nn.Module):
 
             def chain_3d():
                 flow_feat_3d = self.estimator_feat_fuser_3d(xy1, flow_feat_2d_raw, flow_feat_3d_raw)
-                flow_3d = last_flow_3d + self.conv_last_3d(flow_feat_3d)
+                flow_3d = last_flow_3d + conv_module(self.conv_last_3d, flow_feat_3d)
                 _stamp("side L%d stage3 done" % level)
                 flows_3d.append(flow_3d)
                 flow_feats_3d.append(flow_feat_3d)
@@ -725,7 +726,8 @@ class RPEFlow_core(nn.Module):
             hoisted = nxt
 
         flows_2d = [f.float() for f in flows_2d][::-1]
-        flows_2d[0] = convex_upsample(flows_2d[0], self.up_mask_head_2d(flow_feats_2d[-1]), scale_factor=4)
+        mask = self.up_mask_head_2d[1](self.up_mask_head_2d[0](flow_feats_2d[-1]))
+        flows_2d[0] = convex_upsample(flows_2d[0], conv_module(self.up_mask_head_2d[2], mask), scale_factor=4)
         br.join(list(out_s1) + flows_3d + flow_feats_3d)
         flows_3d = [f.float() for f in flows_3d][::-1]
         flows_3d_up = [out_s1[0]]

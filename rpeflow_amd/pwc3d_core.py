@@ -198,5 +198,6 @@ class FlowEstimator3D(nn.Module):
         feat = self.point_conv2.forward(xyz, rows, knn_indices)
         feat = self.mlp(feat)
         if self.conv_last is not None:
-            return feat, self.conv_last(feat)
+            from .utils import conv_module
+            return feat, conv_module(self.conv_last, feat)
         return feat

@@ -60,6 +60,42 @@ def _inference_only(*tensors):
     return not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in tensors)
 
 
+def pointwise_conv(x, weight, bias=None, stride=1):
+    """A 1x1 convolution (Conv1d / Conv2d, groups 1, no padding) as ONE strided-batched GEMM: y[b] = W @ x[b] over [B,C,P]
+    (rocBLAS / hipBLASLt through torch.matmul; stride s reads every s-th pixel first).
+
+    Why not the convolution call: PyTorch hands convolutions to MIOpen's find mode, which TIMES its candidate solvers the
+    first time a process meets a shape and keeps the winner.  For most of this model's ~110 1x1 shapes the winner is this very
+    GEMM (GemmFwd1x1_0_1); about one fresh process in ten instead lands on ConvAsmImplicitGemmGTCDynamicFwdXdlopsNHWC for a
+    3-D GDFN projection (8 x 255 -> 96 over 1024 points, 4 x 64 -> 340 over 4096), and that run's EPE2D is 7.6e-5 off the
+    reference instead of 6-8e-6 (profiles/r03_solver_lottery.json: ten fresh-database processes, solver per convolution).
+    The library's heuristic GEMM selection involves no timing: same kernels in every process."""
+    if stride != 1:
+        x = x[(slice(None), slice(None)) + (slice(None, None, stride),) * (x.dim() - 2)]
+    B, C = x.shape[0], x.shape[1]
+    spatial = x.shape[2:]
+    xf = x.reshape(B, C, -1)  # (a strided view is copied here: the subsampled pixels, nothing else)
+    w = weight.reshape(weight.shape[0], C)
+    if bias is None:
+        y = torch.matmul(w, xf)
+    else:
+        y = torch.baddbmm(bias.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), xf)
+    return y.reshape((B, w.shape[0]) + tuple(spatial))
+
+
+def is_pointwise(conv):
+    """A Conv1d / Conv2d module that pointwise_conv computes: 1x1 kernel, one group, no padding, equal strides."""
+    return (all(k == 1 for k in conv.kernel_size) and conv.groups == 1 and all(p == 0 for p in conv.padding)
+            and len(set(conv.stride)) == 1 and isinstance(conv.padding, tuple))
+
+
+def conv_module(conv, x):
+    """conv(x) for an nn.Conv1d / nn.Conv2d; 1x1 convolutions on the GPU outside autograd go through pointwise_conv."""
+    if x.is_cuda and is_pointwise(conv) and _inference_only(x, *conv.parameters()):
+        return pointwise_conv(x, conv.weight, conv.bias, conv.stride[0])
+    return conv(x)
+
+
 def affine_epilogue(owner, bias, norm, act):
     """(scale, shift, act) of the per-channel epilogue y = act(scale*x + shift) that a bias add, eval-mode BatchNorm
     and the activation amount to -- or None when that does not apply (training BN, InstanceNorm).  Cached on ``owner``
@@ -110,8 +146,11 @@ class _ConvNormRelu(nn.Module):
         # convolution without its bias (MIOpen / hipBLASLt), then bias + BatchNorm + activation in ONE in-place kernel
         from .restormer_ops import channel_affine_act_
         c = self.conv_fn
-        conv = torch.nn.functional.conv1d if self.dims == 1 else torch.nn.functional.conv2d
-        y = conv(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        if is_pointwise(c):
+            y = pointwise_conv(x, c.weight, None, c.stride[0])  # deterministic GEMM instead of MIOpen's timed choice
+        else:
+            conv = torch.nn.functional.conv1d if self.dims == 1 else torch.nn.functional.conv2d
+            y = conv(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
         scale, shift, kind = epi
         if scale is None and shift is None and kind is None:
             return y

