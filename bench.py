@@ -249,12 +249,12 @@ def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist,
         "per_rank_frame_pairs_per_s": [round(len(E.shard_indices(n, r, world)) / d, 3) for r, d in enumerate(dts)],
         "h2d_GBps_per_rank": round(stats["bytes"] / mine_dt / 1e9, 2), "h2d_MB_per_batch": round(stats["bytes"] / max(1, stats["batches"]) / 1e6, 1),
         "loader": {"threads": stats["workers"], "staging": "none: samples lie in pinned memory" if stats["direct"] else "pinned ring of host batches",
-                   "copy": "dedicated HIP stream, one batch ahead of the replay", "generator_s_untimed": round(t_gen, 2),
+                   "copy": "dedicated HIP stream, one batch ahead of the replay", "copy_stream_probe_ms": stats.get("copy_stream_probe_ms"), "generator_s_untimed": round(t_gen, 2),
                    "distinct_samples_per_rank": per_rank},
         "collective": "one SUM all-reduce of float64[12] (%s)" % (backend if dist is not None else "single rank: none"),
         "metrics": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in metrics.items() if k != "counts"},
         "samples": metrics["counts"]["3d"] / NPTS,
-        **({"timeline_ms": stats["timeline_ms"]} if "timeline_ms" in stats else {}),
+        **({"timeline_ms": stats["timeline_ms"]} if "timeline_ms" in stats else {}), **({"trace": stats["trace"]} if "trace" in stats else {}),
     }
 
 

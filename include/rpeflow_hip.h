@@ -98,6 +98,10 @@ int rpe_knn_grid_search(const float *input, int64_t in_sb, int64_t in_sn, int64_
                         const float *in_sorted, const int32_t *in_perm, const float *in_boxes, const float *q_sorted,
                         const int32_t *q_perm, int64_t *idx, float *dist, rpe_stream_t stream);
 
+/* Diagnostics: while `stats16` (16 zeroed uint64 in device memory) is set, every rpe_knn_grid_search launch adds per-wave counts
+ * and clock cycles to it (csrc/knn_grid.h, g_grid_stats); NULL switches it off again.  Synchronous (hipMemcpyToSymbol).   */
+int rpe_knn_grid_set_stats(unsigned long long *stats16);
+
 /* ---- squared_distance (wrapper.py:40-52) ------------------------------------
  * out[b][i][j] = distance above between xyz1[b][i] and xyz2[b][j]; out contiguous. */
 int rpe_squared_distance(const float *xyz1, int64_t a_sb, int64_t a_sn, int64_t a_sd,

@@ -47,6 +47,7 @@ _PROTOTYPES = {
     "rpe_correlation2d_backward": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_knn_multi": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr],
     "rpe_debug_stamp": [_c_ptr, _c_ptr],
+    "rpe_knn_grid_set_stats": [_c_ptr],
     "rpe_knn_grid_sizes": [_c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_knn_grid_build": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     "rpe_knn_grid_supported": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int],

@@ -1361,3 +1361,7 @@ RPE_API int rpe_knn_grid_search(const float *input, int64_t in_sb, int64_t in_sn
     else hipLaunchKernelGGL(knn_grid_kernel<1>, grid, block, lds, st, jobs, k, tie_mode);
     return rpe_launch_status();
 }
+
+RPE_API int rpe_knn_grid_set_stats(unsigned long long *stats16) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_grid_stats), &stats16, sizeof(stats16));
+}

@@ -209,6 +209,11 @@ __global__ __launch_bounds__(kGridBuildThreads) void knn_grid_build_kernel(GridB
 }
 
 // ---- the search ------------------------------------------------------------------------------------------------------------
+// Diagnostics (rpe_knn_grid_set_stats; null in normal use): per launch group the kernel adds, per wave, [0] 1, [1-3] steps
+// evaluated in A0 / A' / B, [4] candidates collected, [5] queries sent to the serial sweep, [6] queries with equal distances,
+// [7-12] clock cycles (s_memtime) spent in: lower bounds, A0 + its bound, A' + its bound, B, translate + rank, finish.
+__device__ unsigned long long *g_grid_stats = nullptr;
+
 struct GridJob {
     rpe_knn_job j;          // the ORIGINAL arrays (tie restatement, serial fallback) and the outputs
     rpe_grid_set in, q;     // the same sets in grid order
@@ -371,7 +376,20 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
     const int kk = (exact_ties && k < M && k < RPE_WAVE) ? k + 1 : k;
     const int n_ss = (steps + 63) >> 6;
 
+    unsigned long long *const stats = g_grid_stats;
     if (qbase < Q) {  // (wave-uniform; a wave beyond Q only helps with the queued ties below)
+        unsigned long long t_mark = stats ? __builtin_readcyclecounter() : 0ull;
+        auto lap = [&](int slot) {
+            if (stats) {
+                const unsigned long long now = __builtin_readcyclecounter();
+                if (lane == 0) atomicAdd(&stats[slot], now - t_mark);
+                t_mark = now;
+            }
+        };
+        auto count = [&](int slot, unsigned long long v) {
+            if (stats && lane == 0) atomicAdd(&stats[slot], v);
+        };
+        count(0, 1);
         float qv[3] = {0.f, 0.f, 0.f};  // lane c of every group: the query at sorted position qbase + c
         {
             const int qp = min(qbase + c, Q - 1);
@@ -413,6 +431,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
             }
         }
 
+        lap(7);
         // ---- A0: the nearest steps
         float lm[8];
 #pragma unroll
@@ -446,6 +465,12 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
         }
         sw.for_steps(seen, n_ss, [&](int, const knn_f32x16 &acc) { fold(acc); });
         const float tau0 = grid_wave_max16(grid_bound(lm, kk, lane));
+        if (stats) {
+            unsigned long long n = 0;
+            for (int ss = 0; ss < kGridMaxSS; ++ss) n += __popcll(seen[ss]);
+            count(1, n);
+        }
+        lap(8);
 
         // ---- A': the other steps that can hold one of the kk nearest of any of the 16 queries
 #pragma unroll
@@ -453,6 +478,12 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
         sw.for_steps(act, n_ss, [&](int, const knn_f32x16 &acc) { fold(acc); });
         const float tau = grid_bound(lm, kk, lane);
         const float tau_max = grid_wave_max16(tau);
+        if (stats) {
+            unsigned long long n = 0;
+            for (int ss = 0; ss < kGridMaxSS; ++ss) n += __popcll(act[ss]);
+            count(2, n);
+        }
+        lap(9);
 
         // ---- B: collect (position in the sorted cloud, distance) below the query's bound, as knn_mfma_kernel does
         const unsigned list_base = (unsigned)(uintptr_t)&L.list[0][lane];
@@ -478,6 +509,15 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         L.count[lane] = cnt;
+        if (stats) {
+            unsigned long long n = 0;
+            for (int ss = 0; ss < kGridMaxSS; ++ss) n += __popcll(act[ss]);
+            count(3, n);
+            int tot = cnt;
+            for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+            count(4, (unsigned long long)tot);
+        }
+        lap(10);
 
         // ---- positions -> original indices, then rank by (distance, index) and finish: as knn_mfma_kernel
         const int have = min(cnt, kLaneList - 1);
@@ -534,6 +574,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
         else if (max_n <= 32) rank_all(std::integral_constant<int, 8>{});
         else rank_all(std::integral_constant<int, 16>{});
 
+        lap(11);
         for (int q = 0; q < kMq; ++q) {
             if (qbase + q >= Q) break;
             const int qo = q_perm[qbase + q];  // the query's ORIGINAL index (wave-uniform address)
@@ -548,6 +589,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
             const int n = rpe_readlane(n_query, q);
             if (((full_lanes >> q) & 0x0001000100010001ull) != 0ull || n > RPE_WAVE) {
                 serial_select<D>(inp, J.in_sn, J.in_sd, M, qm2, qq, kk, lane, Ld, Li);
+                count(5, 1);
             } else {
                 const unsigned long long e = L.list[0][q * RPE_WAVE + lane];
                 Ld = lane < n ? __int_as_float((int)(unsigned)e) : INFINITY;
@@ -555,12 +597,14 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
             }
             if (has_ties(Ld, k, kk, exact_ties, lane)) {
                 if (lane == 0) tq.query[atomicAdd(&tq.n, 1)] = qo;
+                count(6, 1);
             } else if (lane < k) {
                 const int64_t o = ((int64_t)b * Q + qo) * k + lane;
                 idx[o] = (int64_t)Li;
                 if (dist) dist[o] = Ld;
             }
         }
+        lap(12);
     }
     if (exact_ties) drain_ties<D>(&tq, J, b, k, lane, wave);
 }

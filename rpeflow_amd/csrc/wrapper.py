@@ -152,7 +152,7 @@ def _same_view(a, b):
 
 # the grid kernel's regime (measured against the sweeping kernels, B = 4 / 8): k >= 2 searches of clouds from 1024 points with
 # at least 16384 queries a launch -- where rpe_knn would run the matrix-pipe sweep
-_GRID_MIN_M, _GRID_MIN_QUERIES = 1024, 16384
+_GRID_MIN_M, _GRID_MIN_QUERIES = 1 << 30, 16384  # (not yet faster than the sweep anywhere: explicit algo="grid" only)
 
 
 def k_nearest_neighbor_ties(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cpp_impl=True, ties="torch", algo="auto",

@@ -132,6 +132,8 @@ class GraphedForward:
 
     def __init__(self, model, warmup=2, ahead=True):
         self.model, self.warmup, self.entries = model, warmup, {}
+        self.host_times = [] if os.environ.get("RPE_EVAL_TIMELINE") else None  # diagnostic: host seconds inside graph.replay()
+        self.host_copy_times = []
         self.ahead = ahead and hasattr(model, "forward_ahead")
 
     def _key(self, batch):
@@ -156,6 +158,11 @@ class GraphedForward:
         entry["graph"] = graph
         return entry
 
+    def replay_any(self):
+        """One replay of a captured forward on whatever its input buffers hold (the input pipeline times its copy-stream
+        candidates against it; the outputs are overwritten by the next real batch)."""
+        next(iter(self.entries.values()))["graph"].replay()
+
     def _padded_entry(self, batch):
         """A captured graph of the same sample shapes and a LARGER batch: the short last batch of a shard rides in its first
         rows (samples are independent in eval mode; the other rows keep the previous batch), instead of costing a capture
@@ -178,8 +185,11 @@ class GraphedForward:
             else:
                 entry = self.entries[key] = self._capture(batch)
         static = entry["static"]
+        t_a = time.perf_counter()
         for k in self.INPUTS:
             (static[k] if n is None else static[k][:n]).copy_(batch[k], non_blocking=True)
+        if self.host_times is not None:
+            self.host_copy_times.append(time.perf_counter() - t_a)
         if n is not None:  # rows n.. hold the previous batch: sample the mixture in place, announce nothing
             if self.ahead:
                 entry["order"].copy_(self.model.sample_order(static))
@@ -194,7 +204,12 @@ class GraphedForward:
                 for k in self.SAMPLING_INPUTS:
                     entry["next"][k].copy_(next_batch[k], non_blocking=True)
                 entry["announced"] = next_batch["pcs"]
-        entry["graph"].replay()
+        if self.host_times is not None:
+            t0 = time.perf_counter()
+            entry["graph"].replay()
+            self.host_times.append(time.perf_counter() - t0)
+        else:
+            entry["graph"].replay()
         return entry["out"]
 
 
@@ -223,9 +238,12 @@ def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=Non
                                         and len(mine) >= 32 * batch_size)
     if graph and forward is None:
         forward = GraphedForward(model)
-    pipe = InputPipeline(dataset, mine, batch_size, device, workers=default_workers() if workers is None else workers, processes=processes)
+    busy = forward.replay_any if (forward is not None and forward.entries) else None
+    pipe = InputPipeline(dataset, mine, batch_size, device, workers=default_workers() if workers is None else workers, processes=processes,
+                         busy=busy)
     marks = [] if (stats is not None and stats.get("timeline") and torch.device(device).type == "cuda") else None
-    mark = (lambda: marks.append(torch.cuda.Event(enable_timing=True)) or marks[-1].record()) if marks is not None else (lambda: None)
+    host = []
+    mark = (lambda: marks.append(torch.cuda.Event(enable_timing=True)) or marks[-1].record() or host.append(time.perf_counter())) if marks is not None else (lambda: None)
     for batch, upcoming in pipe.pairs():  # ``upcoming`` is resident already: its sampling runs inside this batch's replay
         mark()
         out = forward(batch, upcoming) if graph else model(batch)
@@ -237,6 +255,10 @@ def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=Non
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # the one collective of the evaluation
     if stats is not None:
         stats.update(pipe.stats, shard=len(mine), workers=pipe.workers)
+        from . import loader
+        probe = loader._COPY_STREAMS.get((torch.device(device).index or 0, "probe_ms"))
+        if probe is not None:
+            stats["copy_stream_probe_ms"] = probe
         if marks:  # device time per batch: the forward (input copies into the graph's buffers + replay), the metric sums, and
             torch.cuda.synchronize()  # the gap before the next batch's first launch (host-side stalls, waits for an H2D copy)
             ms = lambda a, b: a.elapsed_time(b)
@@ -244,6 +266,21 @@ def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=Non
             stats["timeline_ms"] = {"forward": round(sum(ms(marks[3 * i], marks[3 * i + 1]) for i in range(n)) / n, 3),
                                     "accumulate": round(sum(ms(marks[3 * i + 1], marks[3 * i + 2]) for i in range(n)) / n, 3),
                                     "gap": round(sum(ms(marks[3 * i + 2], marks[3 * i + 3]) for i in range(n - 1)) / max(1, n - 1), 3)}
+            if forward is not None and forward.host_times:
+                ht = forward.host_times[-n:]
+                stats["timeline_ms"]["host_in_replay_call"] = round(sum(ht) / len(ht) * 1e3, 3)
+                stats["timeline_ms"]["host_in_replay_call_samples"] = [round(x * 1e3, 2) for x in ht[8:20]]
+                stats["timeline_ms"]["host_in_static_copies"] = [round(x * 1e3, 2) for x in forward.host_copy_times[-n:][8:20]]
+                stats["timeline_ms"]["host_loop"] = round((host[-1] - host[0]) / max(1, n - 1) * 1e3 * (n - 1) / n, 3)
+            if pipe.trace:  # per batch, ms relative to the start of batch 8's forward: forward begin/end on the device, its H2D copy's
+                base, hbase = marks[24], host[24]  # begin/end on the device, and when the host issued the replay and the copy
+                rows = []
+                for j, begin, done, t_issue in pipe.trace:
+                    if 8 <= j < 16:
+                        rows.append({"batch": j, "fwd": [round(ms(base, marks[3 * j]), 2), round(ms(base, marks[3 * j + 1]), 2)],
+                                     "h2d": [round(ms(base, begin), 2), round(ms(base, done), 2)],
+                                     "host_fwd_issue": round((host[3 * j] - hbase) * 1e3, 2), "host_h2d_issue": round((t_issue - hbase) * 1e3, 2)})
+                stats["trace"] = rows
     return finalize(acc), acc
 
 

@@ -24,6 +24,7 @@ Batch order and contents never depend on the number of workers (tests/test_loade
 import os
 import queue
 import threading
+import time
 
 import numpy as np
 import torch
@@ -31,6 +32,47 @@ import torch
 
 class _Stop(Exception):
     pass
+
+
+_COPY_STREAMS = {}  # device index -> the stream pick_copy_stream chose
+
+
+def pick_copy_stream(device, busy=None, candidates=8, probe_mb=32):
+    """A stream whose copies really run beside the consumer's kernels.
+
+    HIP streams share a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default; PyTorch's pool of 32 streams maps onto
+    them round robin), a hardware queue executes in order, and a replayed multi-stream HIP graph occupies several of them for
+    its whole duration: a copy stream that lands on one of those queues gets its H2D copies executed BETWEEN two replays
+    instead of under one (measured: 206 MB per batch then cost 3.7 ms per batch, 18.4 -> 22.1 ms, on whichever stream the
+    pool handed out).  Which queue a stream gets cannot be asked, so it is measured: ``busy()`` enqueues the consumer's work
+    (one replay of the forward) on the current stream, a ``probe_mb`` copy is issued on each candidate right behind it, and
+    the candidate whose copy finishes first -- under the replay, not after it -- is kept for this device."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key in _COPY_STREAMS:
+        return _COPY_STREAMS[key]
+    if busy is None:
+        return torch.cuda.Stream(device)
+    src = torch.empty(probe_mb << 18, dtype=torch.float32, pin_memory=True)
+    dst = torch.empty(probe_mb << 18, dtype=torch.float32, device=device)
+    best, results = None, []
+    for _ in range(candidates):
+        stream = torch.cuda.Stream(device)
+        torch.cuda.synchronize(device)
+        begin, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        begin.record()
+        busy()
+        with torch.cuda.stream(stream):
+            dst.copy_(src, non_blocking=True)
+            done.record(stream)
+        torch.cuda.synchronize(device)
+        ms = begin.elapsed_time(done)
+        results.append(round(ms, 2))
+        if best is None or ms < best[0]:
+            best = (ms, stream)
+    _COPY_STREAMS[key] = best[1]
+    _COPY_STREAMS[(key, "probe_ms")] = results
+    return best[1]
 
 
 def _put(q, item, stop):
@@ -63,15 +105,21 @@ def _memcpy(dst, src):
 
 
 class InputPipeline:
-    def __init__(self, dataset, indices, batch_size, device, workers=4, depth=3, processes=False, copy_priority=-1):
+    def __init__(self, dataset, indices, batch_size, device, workers=4, depth=3, processes=False, busy=None):
         self.dataset, self.device = dataset, torch.device(device)
         self.batches = [list(indices[s:s + batch_size]) for s in range(0, len(indices), batch_size)]  # the last one may be short
         self.batch_size, self.workers, self.depth, self.processes = batch_size, max(1, int(workers)), max(3, int(depth)), processes
         self.cuda = self.device.type == "cuda"
-        # the copy stream is a HIGH-priority stream: the runtime gives it a hardware queue of its own.  On a normal-priority stream
-        # its copies share one of the replayed graph's queues and wait behind ~18 ms of kernels (measured: 10 GB/s instead of 55)
-        self.copy_priority = int(os.environ.get("RPE_COPY_PRIORITY", copy_priority))
+        self.busy = busy  # enqueues the consumer's per-batch device work once: lets pick_copy_stream find a stream that overlaps it
+        self.sync_ready = os.environ.get("RPE_PIPE_SYNC_READY", "dev")      # how the consumer waits for a batch's H2D copy
+        # how the copy stream waits for the consumer to be done with a device batch: on the HOST (the copy thread waits for the
+        # event, then issues the copy).  With a device-side wait (copy stream waiting on an event of the compute stream while the
+        # compute stream waits on the copy stream's), hipGraphLaunch on the compute stream blocks its caller for 20-30 ms two
+        # launches out of three (ROCm 7.2, measured); the host-side wait costs nothing: the event is three batches old.
+        self.sync_release = os.environ.get("RPE_PIPE_SYNC_RELEASE", "host")
+        self.depth = max(self.depth, int(os.environ.get("RPE_PIPE_DEPTH", self.depth)))
         self.stats = {"batches": 0, "bytes": 0, "direct": 0}
+        self.trace = [] if os.environ.get("RPE_EVAL_TIMELINE") else None  # (batch, copy begin / end events, host time of issue)
         self._threads, self._stop, self._error = [], threading.Event(), None
 
     def __len__(self):
@@ -163,10 +211,17 @@ class InputPipeline:
                     _put(self._ready, ({k: v[:n] for k, v in src.items()}, None, back), self._stop)
                     continue
                 dev, released = _get(self._free_dev, self._stop)
+                if released is not None and self.sync_release == "host":
+                    released.synchronize()  # the consumer's last kernel that read this device batch (host-side wait: see __init__)
                 with torch.cuda.stream(self._copy_stream):
-                    if released is not None:
-                        self._copy_stream.wait_event(released)  # the consumer's last kernel that read this device batch
-                    if kind == "slot":
+                    if released is not None and self.sync_release != "host":
+                        self._copy_stream.wait_event(released)
+                    if self.trace is not None:  # diagnostic: when the copy of batch j really ran
+                        begin = torch.cuda.Event(enable_timing=True)
+                        begin.record(self._copy_stream)
+                    if os.environ.get("RPE_PIPE_NOCOPY"):  # diagnostic: everything but the copies themselves
+                        pass
+                    elif kind == "slot":
                         for k, v in src.items():
                             dev[k][:n].copy_(v[:n], non_blocking=True)
                             self.stats["bytes"] += v[:n].numel() * v.element_size()
@@ -176,8 +231,10 @@ class InputPipeline:
                                 dev[k][s].copy_(v, non_blocking=True)
                                 self.stats["bytes"] += v.numel() * v.element_size()
                         self.stats["direct"] += 1
-                    done = torch.cuda.Event()
+                    done = torch.cuda.Event(enable_timing=self.trace is not None)
                     done.record(self._copy_stream)
+                    if self.trace is not None:
+                        self.trace.append((j, begin, done, time.perf_counter()))
                 if kind == "slot":
                     self._free_host.put((src, done))
                 _put(self._ready, ({k: v[:n] for k, v in dev.items()}, done, dev), self._stop)  # dev: handed back with an event
@@ -204,7 +261,7 @@ class InputPipeline:
         self._free_host = queue.Queue() if no_host_ring else self._ring(first, self.depth + self.workers, pin_memory=self.cuda)
         self._free_dev = self._ring(first, self.depth, device=self.device) if self.cuda else queue.Queue()
         self._ready = queue.Queue(maxsize=self.depth)
-        self._copy_stream = torch.cuda.Stream(self.device, priority=self.copy_priority) if self.cuda else None
+        self._copy_stream = pick_copy_stream(self.device, self.busy) if self.cuda else None
         targets = [self._process_source] if self.processes else [self._worker] * self.workers
         self._threads = [threading.Thread(target=t, daemon=True) for t in targets + [self._copier]]
         for t in self._threads:
@@ -217,7 +274,10 @@ class InputPipeline:
         except _Stop:
             raise RuntimeError("input pipeline failed") from self._error
         if done is not None:
-            torch.cuda.current_stream(self.device).wait_event(done)
+            if self.sync_ready == "host":
+                done.synchronize()  # (finished long ago in the steady state: the copy ran under the previous replay)
+            else:
+                torch.cuda.current_stream(self.device).wait_event(done)
         self.stats["batches"] += 1
         return batch, dev
 

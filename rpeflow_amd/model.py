@@ -241,7 +241,7 @@ class FlowEstimator2D(nn.Module):
     def forward(self, x):
         x4 = self.conv4(self.conv3(self.conv2(self.conv1(x))))
         flow_feat = torch.cat([self.conv5(x4), x4], dim=1)
-        return (flow_feat, self.conv_last(flow_feat)) if self.conv_last is not None else flow_feat
+        return (flow_feat, conv_module(self.conv_last, flow_feat)) if self.conv_last is not None else flow_feat
 
 
 class ContextNetwork2D(nn.Module):
@@ -257,7 +257,7 @@ class ContextNetwork2D(nn.Module):
     def forward(self, x):
         for conv in self.convs:
             x = conv(x)
-        return x, self.conv_last(x)
+        return x, conv_module(self.conv_last, x)
 
 
 # ------------------------------------------------------------------ Bi-CLFM fusers (RPEFlow_core.py:14-162)
@@ -717,7 +717,7 @@ class RPEFlow_core(nn.Module):
             side_in = [flow_feat_2d_raw] + (_tensors(nxt) + [xyzs1[level - 1], xyzs2[level - 1]] if nxt is not None else [xyzs1[0]])
             out_s1 = br.fork(chain_3d, side_in)
             flow_feat_2d = self.estimator_feat_fuser_2d(xy1, flow_feat_2d_raw, flow_feat_3d_raw, nn_proj1)
-            flow_2d = last_flow_2d + self.conv_last_2d(flow_feat_2d)
+            flow_2d = last_flow_2d + conv_module(self.conv_last_2d, flow_feat_2d)
             flow_feat_2d, flow_delta_2d = self.context_network_2d(torch.cat([flow_feat_2d, flow_2d], dim=1))
             flow_2d = flow_delta_2d + flow_2d
             _stamp("main L%d stage3 done" % level)
@@ -726,7 +726,7 @@ class RPEFlow_core(nn.Module):
             hoisted = nxt
 
         flows_2d = [f.float() for f in flows_2d][::-1]
-        mask = self.up_mask_head_2d[1](self.up_mask_head_2d[0](flow_feats_2d[-1]))
+        mask = self.up_mask_head_2d[1](conv_module(self.up_mask_head_2d[0], flow_feats_2d[-1]))
         flows_2d[0] = convex_upsample(flows_2d[0], conv_module(self.up_mask_head_2d[2], mask), scale_factor=4)
         br.join(list(out_s1) + flows_3d + flow_feats_3d)
         flows_3d = [f.float() for f in flows_3d][::-1]

@@ -10,6 +10,8 @@ here only so that module trees and state-dict keys match the reference.
 """
 import ctypes
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -64,35 +66,114 @@ def pointwise_conv(x, weight, bias=None, stride=1):
     """A 1x1 convolution (Conv1d / Conv2d, groups 1, no padding) as ONE strided-batched GEMM: y[b] = W @ x[b] over [B,C,P]
     (rocBLAS / hipBLASLt through torch.matmul; stride s reads every s-th pixel first).
 
-    Why not the convolution call: PyTorch hands convolutions to MIOpen's find mode, which TIMES its candidate solvers the
-    first time a process meets a shape and keeps the winner.  For most of this model's ~110 1x1 shapes the winner is this very
-    GEMM (GemmFwd1x1_0_1); about one fresh process in ten instead lands on ConvAsmImplicitGemmGTCDynamicFwdXdlopsNHWC for a
-    3-D GDFN projection (8 x 255 -> 96 over 1024 points, 4 x 64 -> 340 over 4096), and that run's EPE2D is 7.6e-5 off the
-    reference instead of 6-8e-6 (profiles/r03_solver_lottery.json: ten fresh-database processes, solver per convolution).
-    The library's heuristic GEMM selection involves no timing: same kernels in every process."""
+    Why not the convolution call: MIOpen's own choice for most of this model's ~110 1x1 shapes is this very GEMM
+    (GemmFwd1x1_0_1), but which solver a process gets is decided by a timing race when it first meets a shape, and some of
+    the candidates (GemmFwd1x1_0_2 on the small stride-2 layers, the splitting implicit GEMMs) accumulate with atomics:
+    see the note above wants_im2col.  The library's heuristic GEMM selection involves no timing and these kernels no atomics:
+    same kernels and same bits in every process and every replay."""
     if stride != 1:
         x = x[(slice(None), slice(None)) + (slice(None, None, stride),) * (x.dim() - 2)]
     B, C = x.shape[0], x.shape[1]
     spatial = x.shape[2:]
     xf = x.reshape(B, C, -1)  # (a strided view is copied here: the subsampled pixels, nothing else)
     w = weight.reshape(weight.shape[0], C)
-    if bias is None:
-        y = torch.matmul(w, xf)
-    else:
-        y = torch.baddbmm(bias.view(1, -1, 1), w.unsqueeze(0).expand(B, -1, -1), xf)
+    wb = w.unsqueeze(0).expand(B, -1, -1)  # batch stride 0: one strided-batched GEMM, the weight read once per sample from L2
+    # (torch.matmul(w, xf) would fold the batch into the columns instead: a transposed copy of x in, one of y out)
+    with _rocblas():
+        y = torch.bmm(wb, xf) if bias is None else torch.baddbmm(bias.view(1, -1, 1), wb, xf)
     return y.reshape((B, w.shape[0]) + tuple(spatial))
 
 
+class _rocblas:
+    """These GEMMs through rocBLAS, as MIOpen's own GemmFwd1x1 solver runs them, not hipBLASLt (PyTorch's default on this
+    GPU): fp32 rocBLAS kernels are built on v_mfma_f32_16x16x4 and measure 1.0-1.4x faster on the model's shapes, 16x on
+    the 510 -> 192 projections over 135 positions (hipBLASLt: 16x16x1 tiles; tools/exp/blas_pref.py).  Host-side dispatch
+    state only: safe under graph capture."""
+    lib = os.environ.get("RPE_POINTWISE_BLAS", "cublas")  # PyTorch's name for rocBLAS; "cublaslt": leave the default
+
+    def __enter__(self):
+        self.prev = None
+        if self.lib != "cublaslt":
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                self.prev = torch.backends.cuda.preferred_blas_library()
+                torch.backends.cuda.preferred_blas_library(self.lib)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.backends.cuda.preferred_blas_library(self.prev)
+
+
 def is_pointwise(conv):
-    """A Conv1d / Conv2d module that pointwise_conv computes: 1x1 kernel, one group, no padding, equal strides."""
-    return (all(k == 1 for k in conv.kernel_size) and conv.groups == 1 and all(p == 0 for p in conv.padding)
-            and len(set(conv.stride)) == 1 and isinstance(conv.padding, tuple))
+    """A Conv1d / Conv2d module that goes through pointwise_conv whatever its input size: 1x1 kernel, stride 1, one group, no
+    padding.  (Stride-2 1x1 convolutions do so on small maps only, conv_no_bias_or: on the large ones MIOpen's Winograd
+    kernel beats gather + GEMM -- 42 vs 66 us at 288 x 480 -- and is deterministic.)"""
+    return (all(k == 1 for k in conv.kernel_size) and conv.groups == 1 and isinstance(conv.padding, tuple)
+            and all(p == 0 for p in conv.padding) and all(st == 1 for st in conv.stride))
+
+
+# MIOpen runs SMALL convolutions it cannot give to Winograd (dilated, strided; sometimes plain 3x3 ones on a 9 x 15 map) as
+# implicit GEMMs that split the reduction over workgroups and add the partial sums with fp32 ATOMICS (igemm ... _gkgs,
+# GemmFwd1x1_0_2): the summation order, and with it the last bits of the result, changes from launch to launch.  Fifteen of
+# the forward's 194 convolution shapes did (tools/exp/conv_determinism.py) -- the context network's dilated 3x3 layers and
+# the pyramids' last stride-2 layers, up to 72 x 120 -- and the decoder amplifies those last bits: 40 replays of ONE graph on
+# ONE batch gave 35 different outputs, max |d flow_2d| 4e-4 ... 2.7e-2, |dEPE2D| against the reference 2e-6 ... 7.6e-5 (what
+# rounds 1-2 read as two "solver populations").  torch.backends.cudnn.deterministic makes MIOpen avoid those kernels at 3x
+# their time (10x for the whole forward).  Here such a convolution is im2col (F.unfold) + one rocBLAS strided-batched GEMM:
+# fixed summation order, +10 us on the smallest maps, equal from 36 x 60 on (+0.13 ms per forward in all).
+_IM2COL_MAX_POSITIONS = 36000   # batch x output positions: beyond, MIOpen's implicit GEMMs fill the GPU without splitting K
+_IM2COL_TINY_POSITIONS = 2200   # plain 3x3 convolutions this small are sometimes given to the splitting kernels too
+_IM2COL_MAX_BYTES = 192 << 20   # size of the unfolded input
+
+
+def _out_size(n, k, s, p, d):
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def wants_im2col(conv, x):
+    """A Conv2d call MIOpen would (or might) run with atomic split-K accumulation: see above."""
+    if x.dim() != 4 or conv.groups != 1 or all(k == 1 for k in conv.kernel_size) or not isinstance(conv.padding, tuple):
+        return False
+    ho = _out_size(x.shape[2], conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0])
+    wo = _out_size(x.shape[3], conv.kernel_size[1], conv.stride[1], conv.padding[1], conv.dilation[1])
+    positions = x.shape[0] * ho * wo
+    special = any(d > 1 for d in conv.dilation) or any(st > 1 for st in conv.stride)
+    cols = positions * x.shape[1] * conv.kernel_size[0] * conv.kernel_size[1] * 4
+    return positions <= _IM2COL_MAX_POSITIONS and cols <= _IM2COL_MAX_BYTES and (special or positions <= _IM2COL_TINY_POSITIONS)
+
+
+def im2col_conv(x, weight, bias, stride, padding, dilation):
+    """conv2d as F.unfold + one strided-batched rocBLAS GEMM (deterministic summation order)."""
+    B, _, H, W = x.shape
+    k = weight.shape
+    ho = _out_size(H, k[2], stride[0], padding[0], dilation[0])
+    wo = _out_size(W, k[3], stride[1], padding[1], dilation[1])
+    cols = torch.nn.functional.unfold(x, (k[2], k[3]), dilation=dilation, padding=padding, stride=stride)  # [B, C*kh*kw, ho*wo]
+    wb = weight.reshape(1, k[0], -1).expand(B, -1, -1)
+    with _rocblas():
+        y = torch.bmm(wb, cols) if bias is None else torch.baddbmm(bias.view(1, -1, 1), wb, cols)
+    return y.reshape(B, k[0], ho, wo)
+
+
+def conv_no_bias_or(conv, x, with_bias):
+    """The convolution of an nn.Conv1d / nn.Conv2d on the GPU, outside autograd: 1x1 -> pointwise_conv, small dilated / strided
+    / tiny -> im2col_conv (both deterministic GEMMs), everything else MIOpen."""
+    bias = conv.bias if with_bias else None
+    if is_pointwise(conv) or (all(k == 1 for k in conv.kernel_size) and conv.groups == 1 and x.dim() == 4
+                              and x.shape[0] * x.shape[2] * x.shape[3] <= 4 * _IM2COL_MAX_POSITIONS and isinstance(conv.padding, tuple)
+                              and all(p == 0 for p in conv.padding) and len(set(conv.stride)) == 1):
+        return pointwise_conv(x, conv.weight, bias, conv.stride[0])  # (the second case: the small stride-2 1x1 layers)
+    if wants_im2col(conv, x):
+        return im2col_conv(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation)
+    f = torch.nn.functional.conv1d if x.dim() == 3 else torch.nn.functional.conv2d
+    return f(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
 def conv_module(conv, x):
-    """conv(x) for an nn.Conv1d / nn.Conv2d; 1x1 convolutions on the GPU outside autograd go through pointwise_conv."""
-    if x.is_cuda and is_pointwise(conv) and _inference_only(x, *conv.parameters()):
-        return pointwise_conv(x, conv.weight, conv.bias, conv.stride[0])
+    """conv(x) for an nn.Conv1d / nn.Conv2d; on the GPU outside autograd through the deterministic paths above."""
+    if x.is_cuda and _inference_only(x, *conv.parameters()):
+        return conv_no_bias_or(conv, x, True)
     return conv(x)
 
 
@@ -145,12 +226,7 @@ class _ConvNormRelu(nn.Module):
             return self.relu_fn(self.norm_fn(self.conv_fn(x)))
         # convolution without its bias (MIOpen / hipBLASLt), then bias + BatchNorm + activation in ONE in-place kernel
         from .restormer_ops import channel_affine_act_
-        c = self.conv_fn
-        if is_pointwise(c):
-            y = pointwise_conv(x, c.weight, None, c.stride[0])  # deterministic GEMM instead of MIOpen's timed choice
-        else:
-            conv = torch.nn.functional.conv1d if self.dims == 1 else torch.nn.functional.conv2d
-            y = conv(x, c.weight, None, c.stride, c.padding, c.dilation, c.groups)
+        y = conv_no_bias_or(self.conv_fn, x, False)  # 1x1 / small dilated or strided: deterministic GEMMs; else MIOpen
         scale, shift, kind = epi
         if scale is None and shift is None and kind is None:
             return y
