@@ -82,7 +82,7 @@ typedef struct rpe_knn_job {
 int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, int tie_mode, rpe_stream_t stream);
 
 /* The same search on spatially ordered point sets (k >= 2; csrc/knn_grid.h).  rpe_knn_grid_build puts a set [B,N,D] into
- * Morton-cell order: `sorted` [B][D+1][Npad] (coordinates, then |p|^2; Npad = N rounded up to 64), `perm` [B][Npad] (original
+ * Morton-cell order: `sorted` [B][Npad/64][4][64] (one 1-KiB record per 64 points: coordinate rows, then |p|^2; Npad = N rounded up to 64; layout in csrc/knn_grid.h), `perm` [B][Npad] (original
  * index of every sorted position), `boxes` [B][Npad/64 + 1][8] (bounding box of every 64-point step); buffer sizes PER
  * BATCH ELEMENT from rpe_knn_grid_sizes.  rpe_knn_grid_search then returns exactly rpe_knn's idx / dist for the ORIGINAL
  * arrays (which it still takes: equal distances are resolved on them) while computing distances only to the steps

@@ -1313,7 +1313,7 @@ RPE_API int rpe_squared_distance(const float *xyz1, int64_t a_sb, int64_t a_sn, 
 RPE_API int rpe_knn_grid_sizes(int N, int D, int64_t *sorted_floats, int64_t *perm_ints, int64_t *box_floats) {
     if (N < 1 || D < 1 || D > 3 || !sorted_floats || !perm_ints || !box_floats) return RPE_EINVAL;
     const int64_t npad = ((int64_t)N + 63) & ~63ll;
-    *sorted_floats = (D + 1) * npad;
+    *sorted_floats = 4 * npad;
     *perm_ints = npad;
     *box_floats = (npad / 64 + 1) * kGridBoxFloats;
     return 0;

@@ -30,16 +30,27 @@
 //                  the sorted cloud), translate positions to original indices, rank by (distance, index), finish_query.
 // Steps travel global -> LDS by LDS-DMA into a wave-private 4-slot ring, two steps ahead, counted vmcnt; no block barrier.
 
+#ifndef RPE_KNN_GRID_PROBE
+#define RPE_KNN_GRID_PROBE 0
+#endif
 constexpr int kGridCells = 4096;          // 12 Morton bits: 4 per dimension (D = 3), 6 (D = 2), 12 (D = 1)
 constexpr int kGridBuildThreads = 1024;
 constexpr int kGridMaxSS = 4;             // lower bounds live in registers, one step per lane and register: M <= 64 * 64 * 4
 constexpr int kGridMaxM = 64 * 64 * kGridMaxSS;
 constexpr int kGridBoxFloats = 8;         // min xyz, max xyz, max |p|^2, pad
-constexpr int kGridSlots = 4;             // ring depth in steps
-constexpr int kGridSlotFloats = 4 * kRow; // three coordinate rows (kRow: bank spread of the A fragments) + the |p|^2 row
+constexpr int kGridSlots = 8;             // ring depth in steps
+constexpr int kGridLead = 6;              // a step is requested this many steps before it is used (~2.5 k cycles of L2 latency against ~0.5 k of work per step)
+constexpr int kGridSlotFloats = 256;      // a step in memory and in LDS alike: three coordinate rows of 64 + the |p|^2 row (layout below)
+
+// A step (64 consecutive points of the sorted set) is ONE 1-KiB record [4][64]: rows 0-2 the coordinates, row 3 |p|^2 (+inf in
+// the padding).  Coordinate row g is rotated by 16 g floats -- point i sits at ((i + 16 g) & 63) -- so that the A-fragment
+// reads of the distance tiles (lane (g, c) reads point 16 j + c of row g) fall into different LDS banks for g = 0, 1, 2
+// without padding, and the record is the unit of the LDS-DMA: one global_load_lds_dwordx4 per step and wave.  (Four dword
+// DMAs per step, as the first version issued them, ran at one instruction per ~90 cycles and CU: 2900 cycles a step.)
+__device__ __forceinline__ int grid_at(int row, int i) { return row * 64 + ((i + 16 * row) & 63); }
 
 struct rpe_grid_set {  // one point set in grid order (rpe_knn_grid_build)
-    const float *sorted;   // [B][D + 1][Npad]: coordinates, then |p|^2 (+inf in the padding)
+    const float *sorted;   // [B][Npad / 64][4][64]: the step records
     const int *perm;       // [B][Npad]: original index of sorted position
     const float *boxes;    // [B][Npad / 64 + 1][8]: per step; the last entry is the whole set
 };
@@ -83,7 +94,7 @@ __global__ __launch_bounds__(kGridBuildThreads) void knn_grid_build_kernel(GridB
     const GridBuildJob &J = jobs.job[blockIdx.y];
     const int b = blockIdx.x, N = J.N, Npad = (N + 63) & ~63, steps = Npad >> 6;
     const float *pts = J.pts + (int64_t)b * J.sb;
-    float *sorted = J.sorted + (int64_t)b * (D + 1) * Npad;
+    float *sorted = J.sorted + (int64_t)b * 4 * Npad;
     int *perm = J.perm + (int64_t)b * Npad;
     float *boxes = J.boxes + (int64_t)b * (steps + 1) * kGridBoxFloats;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -180,9 +191,10 @@ __global__ __launch_bounds__(kGridBuildThreads) void knn_grid_build_kernel(GridB
         float p[3] = {0.f, 0.f, 0.f};
         if (valid) load_point<D>(pts, J.sn, J.sd, i, p);
         const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;
+        float *rec = sorted + (int64_t)(pos >> 6) * kGridSlotFloats;
 #pragma unroll
-        for (int d = 0; d < D; ++d) sorted[(int64_t)d * Npad + pos] = p[d];
-        sorted[(int64_t)D * Npad + pos] = pp;
+        for (int d = 0; d < 3; ++d) rec[grid_at(d, pos & 63)] = p[d];  // (missing dimensions: zero)
+        rec[3 * 64 + (pos & 63)] = pp;
         if (!valid) perm[pos] = 0;
         float bl[3], bh[3], bp = valid ? pp : 0.f;
 #pragma unroll
@@ -224,12 +236,13 @@ struct GridJobs {
 
 struct GridWaveLds {
     float ring[kGridSlots][kGridSlotFloats];
+    float ones[16];              // the constant k-slot of the distance product (directly behind the ring: GridSweep::init)
+    int steps[kGridMaxSS * 64];  // the steps of the current pass, in order
     int count[RPE_WAVE];
     unsigned long long list[kLaneList][RPE_WAVE];  // as MfmaBlockLds::list
 };
 struct GridBlockLds {
     GridWaveLds w[kWavesPerBlock];
-    float ones[kRow];
 };
 
 // bitonic sort, ascending, of the 32 values {v[i] of lanes c, 16 + c, 32 + c, 48 + c}: element e = 8 g + i, all 16 c at once
@@ -287,62 +300,63 @@ __device__ __forceinline__ float grid_wave_max16(float v) {  // max over the 16 
 
 template <int D>
 struct GridSweep {
-    const float *sorted;  // this cloud: [D + 1][Mpad]
-    int Mpad, lane;
+    const float *sorted;  // this cloud's step records
+    int lane;
     float *ring;          // this wave's [kGridSlots][kGridSlotFloats]
-    const float *ones;
     float qb;
-    int aoff;
-    // exactly D + 1 DMAs per request: the counted waits below rely on it
-    __device__ __forceinline__ void request(int step, int slot) const {
-        const float *src = sorted + (int64_t)step * RPE_WAVE + lane;
-        float *dst = ring + slot * kGridSlotFloats;
+    int a_off[4];         // floats: where lane (g, c) finds its A operand of tile j in a record (g == 3: the row of ones behind the ring)
+    __device__ __forceinline__ void init(int lane_, float *ring_, int ones_off) {
+        lane = lane_, ring = ring_;
+        const int g = lane >> 4, c = lane & 15;
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-            __builtin_amdgcn_global_load_lds((knn_glb_void_t *)(src + (int64_t)d * Mpad), (knn_lds_void_t *)(dst + d * kRow), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((knn_glb_void_t *)(src + (int64_t)D * Mpad), (knn_lds_void_t *)(dst + 3 * kRow), 4, 0, 0);
+        for (int j = 0; j < 4; ++j) a_off[j] = g < D ? grid_at(g, 16 * j + c) : ones_off + c;
+    }
+    // ONE DMA per request: the counted waits below rely on it
+    __device__ __forceinline__ void request(int step, int slot) const {
+#if RPE_KNN_GRID_PROBE == 1  // timing only: no DMA at all (stale LDS contents)
+        return;
+#endif
+        const float *src = sorted + (int64_t)step * kGridSlotFloats + 4 * lane;
+        __builtin_amdgcn_global_load_lds((knn_glb_void_t *)src, (knn_lds_void_t *)(ring + slot * kGridSlotFloats), 16, 0, 0);
     }
     // distances of the 64 points in `slot` to the 16 queries: register 4 b + r of lane (g, c) = point 16 b + 4 g + r, query c
     __device__ __forceinline__ knn_f32x16 step(int slot) const {
         const float *s = ring + slot * kGridSlotFloats;
-        const float pp = s[3 * kRow + lane];  // (+inf in the padding: those distances are +inf)
-        const float *ap = aoff >= 0 ? s + aoff : ones + (lane & 15);
+        const float pp = s[3 * 64 + lane];  // (+inf in the padding: those distances are +inf)
+        const float *one_or = D > (lane >> 4) ? s : ring;  // lanes of the constant k-slot read the ones behind the ring, whatever the slot
         const knn_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        const knn_f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], qb, zero, 0, 0, 0);
-        const knn_f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[16], qb, zero, 0, 0, 0);
-        const knn_f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[32], qb, zero, 0, 0, 0);
-        const knn_f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[48], qb, zero, 0, 0, 0);
+        const knn_f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(one_or[a_off[0]], qb, zero, 0, 0, 0);
+        const knn_f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(one_or[a_off[1]], qb, zero, 0, 0, 0);
+        const knn_f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(one_or[a_off[2]], qb, zero, 0, 0, 0);
+        const knn_f32x4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(one_or[a_off[3]], qb, zero, 0, 0, 0);
         const knn_f32x8 d01 = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
         const knn_f32x8 d23 = __builtin_shufflevector(d2, d3, 0, 1, 2, 3, 4, 5, 6, 7);
         const knn_f32x16 acc = __builtin_shufflevector(d01, d23, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
         return __builtin_amdgcn_mfma_f32_16x16x1f32(pp, 1.0f, acc, 0, 0, 0);
     }
-    // f(step id, distances) for every step whose bit is set in mask[0 .. n_ss): two steps requested ahead; when the list
-    // runs out the requests repeat the last step, so every round waits for exactly vmcnt(2 (D + 1))
+    // f(step id, distances) for every step whose bit is set in mask[0 .. n_ss), in order.  The list goes to LDS first; step
+    // n + kGridLead is requested before step n is used, and when the list runs out the requests repeat its last entry, so
+    // every round waits for exactly vmcnt(kGridLead).
     template <class F>
-    __device__ __forceinline__ void for_steps(const unsigned long long (&mask)[kGridMaxSS], int n_ss, F &&f) const {
-        unsigned long long m[kGridMaxSS];
+    __device__ __forceinline__ void for_steps(const unsigned long long (&mask)[kGridMaxSS], int n_ss, int *list, F &&f) const {
+        int total = 0;
 #pragma unroll
-        for (int i = 0; i < kGridMaxSS; ++i) m[i] = i < n_ss ? mask[i] : 0ull;
-        int ss = 0;
-        auto next = [&]() -> int {
-            while (ss < n_ss && m[ss] == 0ull) ++ss;
-            if (ss >= n_ss) return -1;
-            const int bit = __builtin_ctzll(m[ss]);
-            m[ss] &= m[ss] - 1;
-            return ss * 64 + bit;
-        };
-        int s0 = next();
-        if (s0 < 0) return;
-        int s1 = next(), n = 0;
-        request(s0, 0);
-        request(s1 < 0 ? s0 : s1, 1);
-        while (s0 >= 0) {
-            const int s2 = next();
-            request(s2 < 0 ? s0 : s2, (n + 2) & (kGridSlots - 1));
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D + 1)) : "memory");
-            f(s0, step(n & (kGridSlots - 1)));
-            s0 = s1, s1 = s2, ++n;
+        for (int ss = 0; ss < kGridMaxSS; ++ss) {
+            const unsigned long long m = ss < n_ss ? mask[ss] : 0ull;
+            if ((m >> lane) & 1ull) list[total + __popcll(m & ((1ull << lane) - 1ull))] = ss * 64 + lane;
+            total += __popcll(m);
+        }
+        if (total == 0) return;
+        const int last = total - 1;
+#pragma unroll
+        for (int i = 0; i < kGridLead; ++i) request(rpe_uniform(list[min(i, last)]), i);
+        for (int n = 0; n < total; ++n) {
+            request(rpe_uniform(list[min(n + kGridLead, last)]), (n + kGridLead) & (kGridSlots - 1));
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGridLead) : "memory");
+#if RPE_KNN_GRID_PROBE == 2  // timing only: the DMAs and the waits without the distance tiles
+            continue;
+#endif
+            f(rpe_uniform(list[n]), step(n & (kGridSlots - 1)));
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing requests land before the ring is reused
     }
@@ -361,14 +375,14 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
     if ((int)blockIdx.x * kWavesPerBlock * kMq >= Q) return;  // (block-uniform)
     const int qbase = (blockIdx.x * kWavesPerBlock + wave) * kMq;  // position in the sorted query set
     const float *inp = J.input + (int64_t)b * J.in_sb;
-    const float *in_sorted = G.in.sorted + (int64_t)b * (D + 1) * Mpad;
+    const float *in_sorted = G.in.sorted + (int64_t)b * 4 * Mpad;
     const int *in_perm = G.in.perm + (int64_t)b * Mpad;
     const float *in_boxes = G.in.boxes + (int64_t)b * (steps + 1) * kGridBoxFloats;
-    const float *q_sorted = G.q.sorted + (int64_t)b * (D + 1) * Qpad;
+    const float *q_sorted = G.q.sorted + (int64_t)b * 4 * Qpad;
     const int *q_perm = G.q.perm + (int64_t)b * Qpad;
     int64_t *__restrict__ idx = J.idx;
     float *__restrict__ dist = J.dist;
-    if (threadIdx.x < kRow) lds.ones[threadIdx.x] = 1.0f;
+    if ((threadIdx.x & 63) < 16) lds.w[threadIdx.x >> 6].ones[threadIdx.x & 63] = 1.0f;
     __shared__ TieQueue tq;
     if (threadIdx.x == 0) tq.n = 0;
     __syncthreads();
@@ -377,7 +391,13 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
     const int n_ss = (steps + 63) >> 6;
 
     unsigned long long *const stats = g_grid_stats;
+#if RPE_KNN_GRID_PROBE == 3  // timing only: everything twice, the statistics of the SECOND pass (warm instruction cache, TLB, L2)
+    for (int rep = 0; rep < 2; ++rep)
+#endif
     if (qbase < Q) {  // (wave-uniform; a wave beyond Q only helps with the queued ties below)
+#if RPE_KNN_GRID_PROBE == 3
+        unsigned long long *const stats = rep == 1 ? g_grid_stats : nullptr;
+#endif
         unsigned long long t_mark = stats ? __builtin_readcyclecounter() : 0ull;
         auto lap = [&](int slot) {
             if (stats) {
@@ -394,13 +414,13 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
         {
             const int qp = min(qbase + c, Q - 1);
 #pragma unroll
-            for (int d = 0; d < D; ++d) qv[d] = q_sorted[(int64_t)d * Qpad + qp];
+            for (int d = 0; d < D; ++d) qv[d] = q_sorted[(int64_t)(qp >> 6) * kGridSlotFloats + grid_at(d, qp & 63)];
         }
         const float qq_own = rpe_sqnorm<D>(qv);
         GridSweep<D> sw;
-        sw.sorted = in_sorted, sw.Mpad = Mpad, sw.lane = lane, sw.ring = &L.ring[0][0], sw.ones = lds.ones;
+        sw.sorted = in_sorted;
+        sw.init(lane, &L.ring[0][0], kGridSlots * kGridSlotFloats);
         sw.qb = g == 0 ? -2.0f * qv[0] : g == 1 ? -2.0f * qv[1] : g == 2 ? -2.0f * qv[2] : qq_own;
-        sw.aoff = g < D ? g * kRow + c : -1;
 
         // ---- box of the wave's queries; safe lower bound of every step (lane l: steps l, l + 64, ...)
         float qlo[3], qhi[3];
@@ -463,7 +483,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
 #pragma unroll
             for (int t = 0; t < kGridMaxSS; ++t) seen[t] |= t == ss ? 1ull << l : 0ull;
         }
-        sw.for_steps(seen, n_ss, [&](int, const knn_f32x16 &acc) { fold(acc); });
+        sw.for_steps(seen, n_ss, L.steps, [&](int, const knn_f32x16 &acc) { fold(acc); });
         const float tau0 = grid_wave_max16(grid_bound(lm, kk, lane));
         if (stats) {
             unsigned long long n = 0;
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
         // ---- A': the other steps that can hold one of the kk nearest of any of the 16 queries
 #pragma unroll
         for (int ss = 0; ss < kGridMaxSS; ++ss) act[ss] = ss < n_ss ? (__ballot(slb[ss] < tau0) & ~seen[ss]) : 0ull;
-        sw.for_steps(act, n_ss, [&](int, const knn_f32x16 &acc) { fold(acc); });
+        sw.for_steps(act, n_ss, L.steps, [&](int, const knn_f32x16 &acc) { fold(acc); });
         const float tau = grid_bound(lm, kk, lane);
         const float tau_max = grid_wave_max16(tau);
         if (stats) {
@@ -490,7 +510,7 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
         int cnt = 0;
 #pragma unroll
         for (int ss = 0; ss < kGridMaxSS; ++ss) act[ss] = ss < n_ss ? __ballot(slb[ss] < tau_max) : 0ull;
-        sw.for_steps(act, n_ss, [&](int st, const knn_f32x16 &acc) {
+        sw.for_steps(act, n_ss, L.steps, [&](int st, const knn_f32x16 &acc) {
             const int base = st * RPE_WAVE + 4 * g;
             float m4[4];
 #pragma unroll
@@ -575,9 +595,10 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_grid_kernel(Gri
         else rank_all(std::integral_constant<int, 16>{});
 
         lap(11);
+        const int qo_all = q_perm[min(qbase + c, Q - 1)];  // the queries' ORIGINAL indices: one load, not one per query
         for (int q = 0; q < kMq; ++q) {
             if (qbase + q >= Q) break;
-            const int qo = q_perm[qbase + q];  // the query's ORIGINAL index (wave-uniform address)
+            const int qo = rpe_readlane(qo_all, q);
             float qc[3], qm2[3];
 #pragma unroll
             for (int d = 0; d < 3; ++d) qc[d] = rpe_readlane(qv[d], q);

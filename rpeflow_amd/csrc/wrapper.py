@@ -137,7 +137,7 @@ class GridSet:
         B, N, D = points.shape
         npad = (N + 63) // 64 * 64
         self.points, self.shape = points, (B, N, D)
-        self.sorted = torch.empty((B, D + 1, npad), dtype=torch.float32, device=points.device)
+        self.sorted = torch.empty((B, npad // 64, 4, 64), dtype=torch.float32, device=points.device)  # step records, csrc/knn_grid.h
         self.perm = torch.empty((B, npad), dtype=torch.int32, device=points.device)
         self.boxes = torch.empty((B, npad // 64 + 1, 8), dtype=torch.float32, device=points.device)
         with torch.cuda.device(points.device):

@@ -97,18 +97,20 @@ def test_grid_build_is_a_permutation_with_boxes():
     gs = W.GridSet(dev(pts))
     perm, srt, boxes = gs.perm.cpu().numpy(), gs.sorted.cpu().numpy(), gs.boxes.cpu().numpy()
     npad = (N + 63) // 64 * 64
-    assert srt.shape == (B, 4, npad) and perm.shape == (B, npad) and boxes.shape == (B, npad // 64 + 1, 8)
+    assert srt.shape == (B, npad // 64, 4, 64) and perm.shape == (B, npad) and boxes.shape == (B, npad // 64 + 1, 8)
+    rot = lambda row, g: np.roll(row, -16 * g, axis=-1)  # coordinate row g is stored rotated by 16 g: undo
+    flat = np.stack([rot(srt[:, :, 0], 0), rot(srt[:, :, 1], 1), rot(srt[:, :, 2], 2), srt[:, :, 3]], 1).reshape(B, 4, npad)
     for b in range(B):
         assert np.array_equal(np.sort(perm[b, :N]), np.arange(N))
-        assert np.array_equal(srt[b, :3, :N], pts[b, perm[b, :N]].T)
+        assert np.array_equal(flat[b, :3, :N], pts[b, perm[b, :N]].T)
         sq = pts[b, perm[b, :N]]
         pp = (sq[:, 0] * sq[:, 0] + sq[:, 1] * sq[:, 1]) + sq[:, 2] * sq[:, 2]
-        assert np.array_equal(srt[b, 3, :N].view(np.uint32), pp.astype(np.float32).view(np.uint32))
-        assert np.isinf(srt[b, 3, N:]).all() and (srt[b, :3, N:] == 0).all()
+        assert np.array_equal(flat[b, 3, :N].view(np.uint32), pp.astype(np.float32).view(np.uint32))
+        assert np.isinf(flat[b, 3, N:]).all() and (flat[b, :3, N:] == 0).all()
         for s in range(npad // 64):
-            chunk = srt[b, :3, 64 * s:min(64 * s + 64, N)]
+            chunk = flat[b, :3, 64 * s:min(64 * s + 64, N)]
             assert (boxes[b, s, :3] <= chunk.min(1)).all() and (boxes[b, s, 3:6] >= chunk.max(1)).all()
-            assert boxes[b, s, 6] >= srt[b, 3, 64 * s:min(64 * s + 64, N)].max()
+            assert boxes[b, s, 6] >= flat[b, 3, 64 * s:min(64 * s + 64, N)].max()
         assert np.array_equal(boxes[b, -1, :3], pts[b].min(0)) and np.array_equal(boxes[b, -1, 3:6], pts[b].max(0))
         spread_sorted = np.prod(boxes[b, :-1, 3:6] - boxes[b, :-1, :3], axis=1).mean()
         spread_input = np.mean([np.prod(np.ptp(pts[b, 64 * s:64 * s + 64], axis=0)) for s in range(N // 64)])
