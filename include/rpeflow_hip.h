@@ -157,6 +157,12 @@ int rpe_gather_channel_first(const float *data, int64_t sb, int64_t sc, int64_t 
 int rpe_gather_channel_last(const float *data, int64_t sb, int64_t sn, int64_t sc, const int64_t *idx,
                             int B, int C, int N, int I, float *out, rpe_stream_t stream);
 
+/* rpe_im2col: cols [B, C*kh*kw, Ho*Wo] = torch.nn.functional.unfold(x [B,C,H,W], (kh,kw), dilation, padding, stride) for the whole
+ * batch in one launch: the input side of the small convolutions that run as one deterministic GEMM instead of MIOpen's
+ * atomically accumulating split-K kernels (rpeflow_amd/utils.py, wants_im2col).                                    */
+int rpe_im2col(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+               float *cols, rpe_stream_t stream);
+
 /* ---- knn_interpolation after its KNN (models/utils.py:148-154) ------------------
  * w_j = 1/max(||in_xyz[:,knn_j] - q_xyz||_2, 1e-8), normalised over the k neighbours;
  * out[b][c][q] = sum_j (scale*feat[b][c][knn_j]) * w_j.  scale = -1 gives backwarp_3d's
@@ -354,6 +360,11 @@ int rpe_events_to_voxel(const int *pixel_sorted, const double *t_sorted, const i
  *   scale / shift may be NULL (1 / 0).  act: 0 none, 1 relu, 2 leaky_relu(slope).                              */
 int rpe_channel_affine_act(float *y, const float *scale, const float *shift, int B, int C, int64_t P,
                            int act, float slope, rpe_stream_t stream);
+/* rpe_channel_affine_add_act: y = act(scale[c]*y + shift[c] + zscale[c]*z) IN PLACE on y, z [B,C,P] -- the tail of the 2-D
+ *   pyramid's residual block, act(BN(conv1(.)) + BN(down0(x))) (pwc2d_core.py:6-25), over the two raw convolution outputs in
+ *   one pass.  scale / shift / zscale may be NULL (1 / 0 / 1); shift carries both branches' shifts.                */
+int rpe_channel_affine_add_act(float *y, const float *scale, const float *shift, const float *z, const float *zscale, int B, int C,
+                               int64_t P, int act, float slope, rpe_stream_t stream);
 
 /* ---- evaluation metric sums (eval_withocc.py:65-108, eval_noocc.py:57-99) ----------------------------------
  * The caller of the hot path: per batch, the twelve sums the reference's Evaluator keeps (there: a Python loop over

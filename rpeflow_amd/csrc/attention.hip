@@ -9,9 +9,9 @@
 //                        G_ij / (max(|q_i|,eps) max(|k_j|,eps)), equals the reference's normalise-then-multiply up to
 //                        fp32 rounding.  Positions are split over workgroups; partial sums are written per workgroup
 //                        and added in a fixed order by the next kernel (deterministic, no atomics).
-//   attn_softmax_project_kernel  sums the partials, scales by the norms and the temperature, softmax over j (one wave per
-//                        row), and folds the 1x1 project_out convolution in: M[b] = W_o blockdiag_h(attn_h)  (C x C), so
-//                        that the caller finishes the block with ONE batched GEMM  out = residual + M[b] v[b].
+//   attn_softmax_kernel  sums the partials, scales by the norms and the temperature, softmax over j (one wave per row).
+//   attn_project_kernel  folds the 1x1 project_out convolution in: M[b] = W_o blockdiag_h(attn_h)  (C x C), so that the
+//                        caller finishes the block with ONE batched GEMM  out = residual + M[b] v[b].
 #include <math.h>
 
 #include "common.h"
@@ -149,55 +149,60 @@ __global__ __launch_bounds__(256) void attn_gram_kernel(const float *__restrict_
         for (int i = threadIdx.x; i < c; i += 256) np[heads * c + i] = norms[16 + i];
 }
 
-// softmax + project_out in ONE launch.  Every block first rebuilds its sample's attention matrix in LDS -- one wave per row
-// (b, h, i) at a time: the gram partials and squared norms summed in a fixed order, scaled by the norms and the temperature,
-// softmax over j -- then computes its slice of M[b][o][h*c + j] = sum_i W_o[o][h*c + i] * attn[b][h][i][j].
-// grid (B, slices of M's elements), 256 threads; dynamic LDS: attn[b] (C*c floats).  (Two kernels until round 3: the
-// softmax is ~C*c*S additions per sample, repeating it per slice costs less than the dispatch gap of a second launch.)
-__global__ __launch_bounds__(256) void attn_softmax_project_kernel(const float *__restrict__ gpart, const float *__restrict__ npart, int S,
-                                                                   const float *__restrict__ temperature, int heads, int c, float eps,
-                                                                   const float *__restrict__ w_out, float *__restrict__ m_out) {
-    extern __shared__ float attn[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, C = heads * c, b = blockIdx.x;
+// One wave per attention row (b, h, i): sums the partials in a fixed order, scales by the norms and the temperature,
+// softmax over j.  grid (ceil(B*C / 4)), 256 threads; attn_out [B][C][c].
+__global__ __launch_bounds__(256) void attn_softmax_kernel(const float *__restrict__ gpart, const float *__restrict__ npart, int S,
+                                                           const float *__restrict__ temperature, int B, int heads, int c, float eps,
+                                                           float *__restrict__ attn_out) {
+    const int lane = threadIdx.x & 63, C = heads * c;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * C) return;
+    const int b = r / C, hi = r - b * C, h = hi / c, i = hi - h * c;
+    const float *gp = gpart + ((int64_t)b * heads + h) * S * c * c + i * c;
     const float *np = npart + (int64_t)b * S * 2 * C;
-    for (int hi = wave; hi < C; hi += 4) {
-        const int h = hi / c, i = hi - h * c;
-        const float *gp = gpart + ((int64_t)b * heads + h) * S * c * c + i * c;
-        float nq = 0.f;
-        for (int t = 0; t < S; ++t) nq += np[(int64_t)t * 2 * C + hi];
-        nq = fmaxf(sqrtf(nq), eps);
-        const float temp = temperature[h];
-        float v[2];  // c <= 96 < 128: columns lane and lane + 64
-        float mx = -INFINITY;
+    float nq = 0.f;
+    for (int t = 0; t < S; ++t) nq += np[(int64_t)t * 2 * C + hi];
+    nq = fmaxf(sqrtf(nq), eps);
+    const float temp = temperature[h];
+    float v[2];  // c <= 96 < 128: columns lane and lane + 64
+    float mx = -INFINITY;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int j = lane + 64 * u;
-            v[u] = -INFINITY;
-            if (j < c) {
-                float g = 0.f, nk = 0.f;
-                for (int t = 0; t < S; ++t) {
-                    g += gp[(int64_t)t * c * c + j];
-                    nk += np[(int64_t)t * 2 * C + C + h * c + j];
-                }
-                v[u] = g / (nq * fmaxf(sqrtf(nk), eps)) * temp;
+    for (int u = 0; u < 2; ++u) {
+        const int j = lane + 64 * u;
+        v[u] = -INFINITY;
+        if (j < c) {
+            float g = 0.f, nk = 0.f;
+            for (int t = 0; t < S; ++t) {
+                g += gp[(int64_t)t * c * c + j];
+                nk += np[(int64_t)t * 2 * C + C + h * c + j];
             }
-            mx = fmaxf(mx, v[u]);
+            v[u] = g / (nq * fmaxf(sqrtf(nk), eps)) * temp;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float sum = 0.f;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            v[u] = lane + 64 * u < c ? expf(v[u] - mx) : 0.f;
-            sum += v[u];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (lane + 64 * u < c) attn[hi * c + lane + 64 * u] = v[u] * inv;
+        mx = fmaxf(mx, v[u]);
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        v[u] = lane + 64 * u < c ? expf(v[u] - mx) : 0.f;
+        sum += v[u];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (lane + 64 * u < c) attn_out[(int64_t)r * c + lane + 64 * u] = v[u] * inv;
+}
+
+// M[b][o][h*c + j] = sum_i W_o[o][h*c + i] * attn[b][h][i][j].  grid (B, slices of M's elements), 256 threads;
+// dynamic LDS: attn[b] (C*c floats).
+__global__ __launch_bounds__(256) void attn_project_kernel(const float *__restrict__ attn_in, const float *__restrict__ w_out, int heads,
+                                                           int c, float *__restrict__ m_out) {
+    extern __shared__ float attn[];
+    const int C = heads * c, b = blockIdx.x;
+    for (int o = threadIdx.x; o < C * c; o += 256) attn[o] = attn_in[(int64_t)b * C * c + o];
     __syncthreads();
     float *mb = m_out + (int64_t)b * C * C;
     const int per = (C * C + gridDim.y - 1) / gridDim.y;
@@ -240,7 +245,7 @@ RPE_API int rpe_channel_attention_matrix(const float *q, const float *k, int64_t
     if (B == 0) return 0;
     if (c > 96 || heads > 65535 || B > 65535) return RPE_EUNSUPPORTED;
     const int C = heads * c, S = attn_chunks(P);
-    if ((size_t)C * c * sizeof(float) > 64 * 1024) return RPE_EUNSUPPORTED;  // attn[b] lives in LDS in attn_softmax_project_kernel
+    if ((size_t)C * c * sizeof(float) > 64 * 1024) return RPE_EUNSUPPORTED;  // attn[b] staged in LDS by attn_project_kernel
     float *gpart = workspace, *npart = workspace + (int64_t)B * heads * S * c * c;
     const bool vec = P % 4 == 0 && batch_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
@@ -256,7 +261,8 @@ RPE_API int rpe_channel_attention_matrix(const float *q, const float *k, int64_t
         default: rc = launch_gram<6>(vec, grid, st, q, k, batch_stride, heads, c, P, gpart, npart); break;
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_softmax_project_kernel, dim3(B, C >= 64 ? 8 : 2), dim3(256), (size_t)C * c * sizeof(float), st, gpart, npart, S,
-                       temperature, heads, c, eps, w_out, m_out);
+    float *attn = npart + (int64_t)B * S * 2 * C;
+    hipLaunchKernelGGL(attn_softmax_kernel, dim3((B * C + 3) / 4), dim3(256), 0, st, gpart, npart, S, temperature, B, heads, c, eps, attn);
+    hipLaunchKernelGGL(attn_project_kernel, dim3(B, C >= 64 ? 16 : 4), dim3(256), (size_t)C * c * sizeof(float), st, attn, w_out, heads, c, m_out);
     return rpe_launch_status();
 }

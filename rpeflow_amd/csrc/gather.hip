@@ -301,6 +301,51 @@ int channel_split(int C, long items, int B) {
 
 }  // namespace
 
+namespace {
+// cols[b][(c*kh + i)*kw + j][oy*Wo + ox] = x[b][c][oy*sh - ph + i*dh][ox*sw - pw + j*dw] (0 outside): torch.nn.functional.unfold
+// for the whole batch in one launch (ATen's im2col runs one kernel per sample).  A thread writes four consecutive output
+// positions (one 16-byte store when Ho*Wo is a multiple of 4); lanes run along the positions, so for stride 1 the reads
+// of a wave are contiguous row pieces of x.
+__global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x, int C, int H, int W, int kh, int kw, int sh, int sw, int ph,
+                                                     int pw, int dh, int dw, int Ho, int Wo, float *__restrict__ cols) {
+    const int64_t P = (int64_t)Ho * Wo;
+    const int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int row = blockIdx.y, b = blockIdx.z;  // row = (c*kh + i)*kw + j
+    if (p0 >= P) return;
+    const int j = row % kw, i = (row / kw) % kh, c = row / (kw * kh);
+    const float *plane = x + ((int64_t)b * C + c) * H * W;
+    int oy = (int)(p0 / Wo), ox = (int)(p0 - (int64_t)oy * Wo);
+    float v[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int y = oy * sh - ph + i * dh, xx = ox * sw - pw + j * dw;
+        v[t] = (p0 + t < P && y >= 0 && y < H && xx >= 0 && xx < W) ? plane[(int64_t)y * W + xx] : 0.f;
+        if (++ox == Wo) ox = 0, ++oy;
+    }
+    float *out = cols + ((int64_t)b * C * kh * kw + row) * P + p0;
+    if (p0 + 4 <= P && (P & 3) == 0) {
+        *reinterpret_cast<float4 *>(out) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (p0 + t < P) out[t] = v[t];
+    }
+}
+}  // namespace
+
+RPE_API int rpe_im2col(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                       float *cols, rpe_stream_t stream) {
+    if (!x || !cols || B < 0 || C < 1 || H < 1 || W < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || dh < 1 || dw < 1)
+        return RPE_EINVAL;
+    const int Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
+    if (Ho < 1 || Wo < 1) return RPE_EINVAL;
+    if (B == 0) return 0;
+    if (B > 65535 || (int64_t)C * kh * kw > 65535) return RPE_EUNSUPPORTED;
+    dim3 grid((unsigned)(((int64_t)Ho * Wo + 1023) / 1024), (unsigned)(C * kh * kw), (unsigned)B);
+    hipLaunchKernelGGL(im2col_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo, cols);
+    return rpe_launch_status();
+}
+
 RPE_API int rpe_gather_channel_first(const float *data, int64_t sb, int64_t sc, int64_t sn, const int64_t *idx, int B, int C,
                                      int N, int I, float *out, rpe_stream_t stream) {
     if (!data || !idx || !out || B < 0 || C < 0 || N <= 0 || I < 0) return RPE_EINVAL;

@@ -209,6 +209,32 @@ __global__ __launch_bounds__(256) void affine_act_kernel(float *__restrict__ y, 
     }
 }
 
+// y[b][c][p] = act(scale[c] * y + shift[c] + zscale[c] * z[b][c][p]), in place on y: the tail of a residual block --
+// act(BN(conv1(..)) + BN(down0(x))), pwc2d_core.py:6-25 -- as one pass over the two raw convolution outputs instead of two
+// epilogue passes, an add and the activation (shift = both branches' shifts, summed by the caller).
+__global__ __launch_bounds__(256) void affine_add_act_kernel(float *__restrict__ y, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, const float *__restrict__ z,
+                                                             const float *__restrict__ zscale, int C, int64_t P, int act, float slope) {
+    const int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int c = blockIdx.y, b = blockIdx.z;
+    if (p >= P) return;
+    const float a = scale ? scale[c] : 1.0f, s = shift ? shift[c] : 0.0f, za = zscale ? zscale[c] : 1.0f;
+    float *row = y + ((int64_t)b * C + c) * P + p;
+    const float *zrow = z + ((int64_t)b * C + c) * P + p;
+    auto f = [&](float v, float w) {
+        v = (a * v + s) + za * w;
+        return act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v >= 0.f ? v : v * slope) : v);
+    };
+    if (p + 4 <= P && (((reinterpret_cast<uintptr_t>(row) | reinterpret_cast<uintptr_t>(zrow)) & 15) == 0)) {
+        float4 v = *reinterpret_cast<float4 *>(row);
+        const float4 w = *reinterpret_cast<const float4 *>(zrow);
+        v.x = f(v.x, w.x); v.y = f(v.y, w.y); v.z = f(v.z, w.z); v.w = f(v.w, w.w);
+        *reinterpret_cast<float4 *>(row) = v;
+    } else {
+        for (int i = 0; i < 4 && p + i < P; ++i) row[i] = f(row[i], zrow[i]);
+    }
+}
+
 // RAFT-style convex up-sampling (models/utils.py:201-214, the last step of RPEFlow_core.forward :424): every fine pixel
 // (h*s+i, w*s+j) is a softmax-weighted combination (9 weights from mask channels k*s*s + i*s + j) of the 3x3
 // coarse neighbourhood of s*flow.  One thread per coarse pixel walks its s*s fine pixels: the mask planes are read
@@ -349,5 +375,15 @@ RPE_API int rpe_channel_affine_act(float *y, const float *scale, const float *sh
     if (B > 65535 || C > 65535) return RPE_EUNSUPPORTED;
     dim3 grid((unsigned)((P + 1023) / 1024), C, B), block(256);
     hipLaunchKernelGGL(affine_act_kernel, grid, block, 0, (hipStream_t)stream, y, scale, shift, C, P, act, slope);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_channel_affine_add_act(float *y, const float *scale, const float *shift, const float *z, const float *zscale, int B,
+                                       int C, int64_t P, int act, float slope, rpe_stream_t stream) {
+    if (!y || !z || B < 0 || C < 1 || P < 0 || act < 0 || act > 2) return RPE_EINVAL;
+    if (B == 0 || P == 0) return 0;
+    if (B > 65535 || C > 65535) return RPE_EUNSUPPORTED;
+    dim3 grid((unsigned)((P + 1023) / 1024), C, B), block(256);
+    hipLaunchKernelGGL(affine_add_act_kernel, grid, block, 0, (hipStream_t)stream, y, scale, shift, z, zscale, C, P, act, slope);
     return rpe_launch_status();
 }

@@ -129,13 +129,15 @@ class _GatedFeedForward(nn.Module):
         self.dwconv = conv(hidden * 2, hidden * 2, kernel_size=3, stride=1, padding=1, groups=hidden * 2, bias=bias)
         self.project_out = conv(hidden, dim, kernel_size=1, bias=bias)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """project_out(gelu(a) * b) (+ residual, added by project_out's GEMM)."""
         if x.is_cuda:  # depth-wise conv + gelu gate in one kernel
             from .restormer_ops import dwconv3
             hidden = dwconv3([conv_module(self.project_in, x)], self.dwconv.weight, self.dwconv.bias, gate=True)
-            return conv_module(self.project_out, hidden)
+            return conv_module(self.project_out, hidden, residual=residual)
         a, b = self.dwconv(self.project_in(x)).chunk(2, dim=1)
-        return self.project_out(F.gelu(a) * b)
+        out = self.project_out(F.gelu(a) * b)
+        return out if residual is None else residual + out
 
 
 class _CrossTransformerBlock(nn.Module):
@@ -159,7 +161,7 @@ class _CrossTransformerBlock(nn.Module):
         else:
             nxo, nyo = self.norm1x(x), self.norm1y(y)
         x = self.attn(nxo, nyo, residual=x)
-        return x + self.ffn(self.norm2(x))
+        return self.ffn(self.norm2(x), residual=x)
 
 
 class CrossTransformerBlock2D(_CrossTransformerBlock):
@@ -210,7 +212,21 @@ class ResidualBlock(nn.Module):
         self.relu = nn.LeakyReLU(negative_slope=0.1, inplace=True)
 
     def forward(self, x):
-        return self.relu(self.conv1(self.conv0(x)) + self.down0(x))
+        from .utils import _inference_only, conv_no_bias_or
+        epi1 = self.conv1._epilogue() if x.is_cuda and _inference_only(x, *self.parameters()) else None
+        epi0 = self.down0._epilogue() if epi1 is not None else None
+        if epi1 is None or epi0 is None or epi1[2] is not None or epi0[2] is not None:
+            return self.relu(self.conv1(self.conv0(x)) + self.down0(x))
+        # both branches' bias / BatchNorm, the sum and the activation in ONE pass over the two raw convolution outputs
+        from .restormer_ops import channel_affine_add_act_
+        raw1 = conv_no_bias_or(self.conv1.conv_fn, self.conv0(x), False).contiguous()
+        raw0 = conv_no_bias_or(self.down0.conv_fn, x, False).contiguous()
+        key = tuple(id(t) for t in (epi1[1], epi0[1]))
+        if getattr(self, "_shift_key", None) != key:
+            shifts = [t for t in (epi1[1], epi0[1]) if t is not None]
+            self._shift_sum = (shifts[0] + shifts[1]) if len(shifts) == 2 else (shifts[0] if shifts else None)
+            self._shift_key = key
+        return channel_affine_add_act_(raw1, epi1[0], self._shift_sum, raw0, epi0[0], "leaky_relu", 0.1)
 
 
 class FeaturePyramid2D(nn.Module):
@@ -705,7 +721,7 @@ class RPEFlow_core(nn.Module):
 
             def chain_3d():
                 flow_feat_3d = self.estimator_feat_fuser_3d(xy1, flow_feat_2d_raw, flow_feat_3d_raw)
-                flow_3d = last_flow_3d + conv_module(self.conv_last_3d, flow_feat_3d)
+                flow_3d = conv_module(self.conv_last_3d, flow_feat_3d, residual=last_flow_3d)
                 _stamp("side L%d stage3 done" % level)
                 flows_3d.append(flow_3d)
                 flow_feats_3d.append(flow_feat_3d)

@@ -83,6 +83,20 @@ def channel_affine_act_(y, scale, shift, act, slope=0.1):
     return y
 
 
+def channel_affine_add_act_(y, scale, shift, z, zscale, act, slope=0.1):
+    """In place on y: y = act(scale[c]*y + shift[c] + zscale[c]*z); y, z contiguous [B,C,...] of one shape."""
+    _lib.require_gpu(y, z, op="channel_affine_add_act")
+    assert y.is_contiguous() and z.is_contiguous() and y.shape == z.shape and y.dtype == torch.float32 and z.dtype == torch.float32
+    B, C = y.shape[:2]
+    P = y.numel() // (B * C)
+    code = {None: 0, "relu": 1, "leaky_relu": 2}[act]
+    with torch.cuda.device(y.device):
+        rc = _lib.lib().rpe_channel_affine_add_act(_ptr(y), _ptr(scale), _ptr(shift), _ptr(z), _ptr(zscale), B, C, P, code, float(slope),
+                                                   _lib.stream_of(y))
+    _lib.check(rc, "channel_affine_add_act")
+    return y
+
+
 def channel_attention_matrix(qkv, heads, temperature, w_out, eps=1e-12):
     """qkv [B,3C,...] contiguous (q | k | v along channels).  Returns M [B,C,C] with
     project_out(softmax(normalize(q) normalize(k)^T * temperature) v) == M @ v  (restormer_arch.py:184-203)."""

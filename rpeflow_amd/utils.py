@@ -62,7 +62,7 @@ def _inference_only(*tensors):
     return not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in tensors)
 
 
-def pointwise_conv(x, weight, bias=None, stride=1):
+def pointwise_conv(x, weight, bias=None, stride=1, residual=None):
     """A 1x1 convolution (Conv1d / Conv2d, groups 1, no padding) as ONE strided-batched GEMM: y[b] = W @ x[b] over [B,C,P]
     (rocBLAS / hipBLASLt through torch.matmul; stride s reads every s-th pixel first).
 
@@ -79,8 +79,11 @@ def pointwise_conv(x, weight, bias=None, stride=1):
     w = weight.reshape(weight.shape[0], C)
     wb = w.unsqueeze(0).expand(B, -1, -1)  # batch stride 0: one strided-batched GEMM, the weight read once per sample from L2
     # (torch.matmul(w, xf) would fold the batch into the columns instead: a transposed copy of x in, one of y out)
+    add = None if residual is None else residual.reshape(B, w.shape[0], -1)  # ``residual`` [B,Cout,...]: added by the GEMM itself (beta = 1)
+    if bias is not None:
+        add = bias.view(1, -1, 1) if add is None else add + bias.view(1, -1, 1)
     with _rocblas():
-        y = torch.bmm(wb, xf) if bias is None else torch.baddbmm(bias.view(1, -1, 1), wb, xf)
+        y = torch.bmm(wb, xf) if add is None else torch.baddbmm(add, wb, xf)
     return y.reshape((B, w.shape[0]) + tuple(spatial))
 
 
@@ -123,7 +126,7 @@ def is_pointwise(conv):
 # their time (10x for the whole forward).  Here such a convolution is im2col (F.unfold) + one rocBLAS strided-batched GEMM:
 # fixed summation order, +10 us on the smallest maps, equal from 36 x 60 on (+0.13 ms per forward in all).
 _IM2COL_MAX_POSITIONS = 36000   # batch x output positions: beyond, MIOpen's implicit GEMMs fill the GPU without splitting K
-_IM2COL_TINY_POSITIONS = 2200   # plain 3x3 convolutions this small are sometimes given to the splitting kernels too
+_IM2COL_TINY_POSITIONS = 600    # plain 3x3 convolutions this small (9 x 15, batch 4) are sometimes given to the splitting kernels too
 _IM2COL_MAX_BYTES = 192 << 20   # size of the unfolded input
 
 
@@ -149,7 +152,13 @@ def im2col_conv(x, weight, bias, stride, padding, dilation):
     k = weight.shape
     ho = _out_size(H, k[2], stride[0], padding[0], dilation[0])
     wo = _out_size(W, k[3], stride[1], padding[1], dilation[1])
-    cols = torch.nn.functional.unfold(x, (k[2], k[3]), dilation=dilation, padding=padding, stride=stride)  # [B, C*kh*kw, ho*wo]
+    if x.is_cuda:  # [B, C*kh*kw, ho*wo] in one launch (F.unfold: one per sample)
+        x = _f32(x)
+        cols = torch.empty((B, k[1] * k[2] * k[3], ho * wo), dtype=torch.float32, device=x.device)
+        _launch(x, "im2col", _lib.lib().rpe_im2col, _ptr(x), B, k[1], H, W, k[2], k[3], stride[0], stride[1], padding[0], padding[1],
+                dilation[0], dilation[1], _ptr(cols))
+    else:
+        cols = torch.nn.functional.unfold(x, (k[2], k[3]), dilation=dilation, padding=padding, stride=stride)
     wb = weight.reshape(1, k[0], -1).expand(B, -1, -1)
     with _rocblas():
         y = torch.bmm(wb, cols) if bias is None else torch.baddbmm(bias.view(1, -1, 1), wb, cols)
@@ -170,11 +179,16 @@ def conv_no_bias_or(conv, x, with_bias):
     return f(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
-def conv_module(conv, x):
-    """conv(x) for an nn.Conv1d / nn.Conv2d; on the GPU outside autograd through the deterministic paths above."""
+def conv_module(conv, x, residual=None):
+    """conv(x) (+ residual) for an nn.Conv1d / nn.Conv2d; on the GPU outside autograd through the deterministic paths above,
+    a 1x1 convolution adding the residual inside its GEMM."""
     if x.is_cuda and _inference_only(x, *conv.parameters()):
-        return conv_no_bias_or(conv, x, True)
-    return conv(x)
+        if residual is not None and is_pointwise(conv):
+            return pointwise_conv(x, conv.weight, conv.bias, 1, residual=residual)
+        y = conv_no_bias_or(conv, x, True)
+    else:
+        y = conv(x)
+    return y if residual is None else residual + y
 
 
 def affine_epilogue(owner, bias, norm, act):

@@ -163,3 +163,59 @@ def test_mutual_attention_with_bias():
         mg = m.to(DEV)
         got, got_r = mg(x.to(DEV), y.to(DEV)).cpu(), mg(x.to(DEV), y.to(DEV), residual=r.to(DEV)).cpu()
     assert (got - ref).abs().max() < 5e-5 and (got_r - (r + ref)).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("norm", ["batch_norm", None])
+@pytest.mark.parametrize("cin,cout,H,W", [(16, 32, 36, 60), (3, 16, 64, 96), (128, 192, 18, 30), (7, 9, 5, 7)])
+def test_residual_block_tail_in_one_pass(norm, cin, cout, H, W):
+    """ResidualBlock (pwc2d_core.py:6-25): act(BN(conv1(conv0 x)) + BN(down0 x)) with both branches' epilogues, the sum and the
+    activation in one kernel (rpe_channel_affine_add_act) against the plain module chain on the CPU; small maps take the
+    deterministic GEMM forms of the convolutions (rpeflow_amd.utils.conv_no_bias_or)."""
+    from rpeflow_amd.model import ResidualBlock
+    torch.manual_seed(cin + H)
+    m = ResidualBlock(cin, cout, norm=norm).eval()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+    x = torch.randn(2, cin, H, W)
+    with torch.no_grad():
+        ref = m(x)
+        got = m.to(DEV)(x.to(DEV)).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_feed_forward_adds_its_residual_in_the_gemm():
+    """_GatedFeedForward(x, residual=r) == r + _GatedFeedForward(x): project_out's GEMM carries the add (beta = 1)."""
+    from rpeflow_amd.model import _GatedFeedForward
+    torch.manual_seed(3)
+    for dims, shape in ((2, (2, 32, 18, 30)), (1, (3, 64, 500))):
+        ffn = _GatedFeedForward(shape[1], 2.66, False, dims).to(DEV).eval()
+        x, r = torch.randn(shape, device=DEV), torch.randn(shape, device=DEV)
+        with torch.no_grad():
+            plain, fused = ffn(x), ffn(x, residual=r)
+            cpu = ffn.cpu()(x.cpu())
+        assert (fused - (r + plain)).abs().max() < 1e-5
+        assert (plain.cpu() - cpu).abs().max() < 2e-5 * max(1.0, float(cpu.abs().max()))
+
+
+@pytest.mark.parametrize("k,s,p,d,H,W,n", [(3, 1, 2, 2, 9, 15, 4), (3, 1, 8, 8, 18, 30, 4), (3, 2, 1, 1, 18, 30, 8), (3, 1, 4, 4, 72, 120, 4), (1, 2, 0, 1, 18, 30, 8),
+                                           (3, 1, 1, 1, 9, 15, 4)])
+def test_small_convolutions_are_deterministic_gemms(k, s, p, d, H, W, n):
+    """The shapes MIOpen runs with atomic split-K accumulation (tools/exp/conv_determinism.py) go through im2col / gather + one
+    rocBLAS GEMM instead: equal to the library convolution to fp32 rounding, and bit-identical from call to call."""
+    from rpeflow_amd.utils import conv_module, wants_im2col
+    torch.manual_seed(k * 100 + d)
+    conv = torch.nn.Conv2d(128, 96, k, s, p, d).to(DEV)
+    x = torch.randn(n, 128, H, W, device=DEV)
+    assert k == 1 or wants_im2col(conv, x)
+    with torch.no_grad():
+        outs = [conv_module(conv, x).clone() for _ in range(6)]
+        ref = conv(x)
+    assert all(torch.equal(o, outs[0]) for o in outs[1:])
+    assert (outs[0] - ref).abs().max() < 1e-4
+    big = torch.randn(4, 128, 144, 240, device=DEV)
+    assert not wants_im2col(torch.nn.Conv2d(128, 96, 3, 1, 2, 2), big)  # large maps: MIOpen's non-splitting kernels

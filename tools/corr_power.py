@@ -80,6 +80,7 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--seconds", type=float, default=3.0)
     p.add_argument("--out", default=None)
+    p.add_argument("--source", choices=["sysfs", "smi"], default="sysfs")
     args = p.parse_args()
     dev = torch.device("cuda", 0)
     H, W, C = 544, 960, 256
@@ -97,6 +98,9 @@ def main():
             ops.correlation2d(a, b, 4)
         torch.cuda.synchronize()
         sampler = Sampler()
+        if args.source == "smi":
+            sampler.power_path = sampler.clock_path = None
+            sampler.period = 0.2
         sampler.start()
         t0 = time.perf_counter()
         n = 0
