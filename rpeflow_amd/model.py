@@ -129,12 +129,12 @@ class _GatedFeedForward(nn.Module):
         self.dwconv = conv(hidden * 2, hidden * 2, kernel_size=3, stride=1, padding=1, groups=hidden * 2, bias=bias)
         self.project_out = conv(hidden, dim, kernel_size=1, bias=bias)
 
-    def forward(self, x, residual=None):
-        """project_out(gelu(a) * b) (+ residual, added by project_out's GEMM)."""
+    def forward(self, x, residual=None, inplace=False):
+        """project_out(gelu(a) * b) (+ residual, added by project_out's GEMM; ``inplace``: accumulated into ``residual``)."""
         if x.is_cuda:  # depth-wise conv + gelu gate in one kernel
             from .restormer_ops import dwconv3
             hidden = dwconv3([conv_module(self.project_in, x)], self.dwconv.weight, self.dwconv.bias, gate=True)
-            return conv_module(self.project_out, hidden, residual=residual)
+            return conv_module(self.project_out, hidden, residual=residual, inplace=inplace)
         a, b = self.dwconv(self.project_in(x)).chunk(2, dim=1)
         out = self.project_out(F.gelu(a) * b)
         return out if residual is None else residual + out
@@ -161,7 +161,7 @@ class _CrossTransformerBlock(nn.Module):
         else:
             nxo, nyo = self.norm1x(x), self.norm1y(y)
         x = self.attn(nxo, nyo, residual=x)
-        return self.ffn(self.norm2(x), residual=x)
+        return self.ffn(self.norm2(x), residual=x, inplace=x.is_cuda)  # x is this block's own attention output: the GEMM adds into it
 
 
 class CrossTransformerBlock2D(_CrossTransformerBlock):

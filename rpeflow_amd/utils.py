@@ -62,7 +62,7 @@ def _inference_only(*tensors):
     return not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in tensors)
 
 
-def pointwise_conv(x, weight, bias=None, stride=1, residual=None):
+def pointwise_conv(x, weight, bias=None, stride=1, residual=None, inplace=False):
     """A 1x1 convolution (Conv1d / Conv2d, groups 1, no padding) as ONE strided-batched GEMM: y[b] = W @ x[b] over [B,C,P]
     (rocBLAS / hipBLASLt through torch.matmul; stride s reads every s-th pixel first).
 
@@ -83,7 +83,12 @@ def pointwise_conv(x, weight, bias=None, stride=1, residual=None):
     if bias is not None:
         add = bias.view(1, -1, 1) if add is None else add + bias.view(1, -1, 1)
     with _rocblas():
-        y = torch.bmm(wb, xf) if add is None else torch.baddbmm(add, wb, xf)
+        if add is None:
+            y = torch.bmm(wb, xf)
+        elif inplace and bias is None and residual.is_contiguous():
+            y = add.baddbmm_(wb, xf)  # accumulates into ``residual`` itself: no copy of it in front of the GEMM (the caller owns it)
+        else:
+            y = torch.baddbmm(add, wb, xf)
     return y.reshape((B, w.shape[0]) + tuple(spatial))
 
 
@@ -179,12 +184,12 @@ def conv_no_bias_or(conv, x, with_bias):
     return f(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
-def conv_module(conv, x, residual=None):
+def conv_module(conv, x, residual=None, inplace=False):
     """conv(x) (+ residual) for an nn.Conv1d / nn.Conv2d; on the GPU outside autograd through the deterministic paths above,
-    a 1x1 convolution adding the residual inside its GEMM."""
+    a 1x1 convolution adding the residual inside its GEMM (``inplace``: into the residual tensor itself)."""
     if x.is_cuda and _inference_only(x, *conv.parameters()):
         if residual is not None and is_pointwise(conv):
-            return pointwise_conv(x, conv.weight, conv.bias, 1, residual=residual)
+            return pointwise_conv(x, conv.weight, conv.bias, 1, residual=residual, inplace=inplace)
         y = conv_no_bias_or(conv, x, True)
     else:
         y = conv(x)
