@@ -123,6 +123,7 @@ int rpe_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
 #define RPE_FPS_AUTO 0
 #define RPE_FPS_PLAIN 1
 #define RPE_FPS_PRUNED 2
+#define RPE_FPS_PAIRED 3 /* the pruned kernel emitting two samples per synchronisation round where the sequential rule provably gives them */
 int rpe_fps_algo(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
                  int B, int N, int S, int64_t *idx, int algo, rpe_stream_t stream);
 

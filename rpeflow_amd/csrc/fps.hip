@@ -19,6 +19,9 @@
 
 namespace {
 
+#ifndef RPE_FPS_AUTO_PAIRED
+#define RPE_FPS_AUTO_PAIRED 0  // rpe_fps's pruned choice stays the one-sample kernel: the paired form measures 1.5 % faster only
+#endif
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / RPE_WAVE;  // 16
 
@@ -210,7 +213,17 @@ __device__ unsigned long long g_fps_stats[4];
 // reduction that picks the winner is in flight; the winner's lane then selects its bit.  A skipping wave's iteration
 // is: read 16 partials, reduce, readlane, republish.  The start needs no special case: every valid point begins at
 // 1e10, all waves tie, the lowest original index (0) wins.
-template <int PPT>
+//
+// PAIRED (round 3): two samples per barrier round where that is provably what the sequential rule gives.  Every wave also
+// publishes the SECOND-largest running distance among its points (excluding its candidate).  After the barrier all waves see
+// the winner c1 (value v1, wave w1) and the best candidate of the OTHER waves, c2 (value v2, wave w2).  If (a) no other
+// candidate holds v2, (b) w1's second-largest value is < v2 and (c) c1 does not lower c2's running distance
+// (fl(|c2 - c1|^2) >= v2, rounded as the update rounds it), then after c1's update every point of w1 is <= its old
+// second-largest < v2, every other wave's maximum was < v2 and can only have dropped, and c2 -- the lowest index holding v2
+// in its wave -- still holds v2: c2 IS the next sample, whatever else c1's update does.  Both indices are written and every
+// wave applies both updates (each only if the sample can reach its box) in one recompute.  Otherwise the round emits one
+// sample, as before.  The indices are identical by construction; the GPU tests cross-check PAIRED, PRUNED and PLAIN.
+template <int PPT, bool PAIRED>
 __global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
                                                                int N, int S, int64_t *__restrict__ idx) {
     static_assert(PPT % 2 == 0, "packed path needs an even number of points per thread");
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__re
     constexpr int H = PPT / 2;
     extern __shared__ unsigned long long sortbuf[];
     __shared__ float red[6][kWaves];
-    __shared__ int part[2][5][kWaves];  // [parity][value bits, index, x, y, z][wave]
+    __shared__ int part[2][6][kWaves];  // [parity][value bits, index, x, y, z, second-largest value bits][wave]
     const int tid = threadIdx.x, lane = rpe_lane();
     const int wave = rpe_uniform(tid >> 6);
     const int b = blockIdx.x;
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__re
     }
 
     // the wave's candidate (largest running distance, lowest original index holding it, that point's coordinates)
-    int wmax, widx;
+    int wmax, widx, wsec = -1;
     float wx, wy, wz;
     auto candidate = [&](int tmax) {
         wmax = wave_max_i32(tmax);
@@ -336,6 +349,16 @@ __global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__re
                 wy = rpe_readlane(py[j >> 1][j & 1], l);
                 wz = rpe_readlane(pz[j >> 1][j & 1], l);
             }
+        if (PAIRED) {  // the largest running distance among the wave's OTHER points
+            if (holders != 1) {
+                wsec = wmax;  // another point holds the maximum too (or the wave is empty: -1)
+            } else {
+                int t2 = -1;
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) t2 = max(t2, ((m[j] >> lane) & 1ull) ? -1 : md[j]);
+                wsec = wave_max_i32(t2);
+            }
+        }
     };
     {
         int t = -1;
@@ -345,19 +368,21 @@ __global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__re
     }
     __syncthreads();  // the sort buffer is dead; part[] is a separate array
 
-    for (int s = 0;; ++s) {
-        const int par = s & 1;
+    for (int s = 0, round = 0;; ++round) {
+        const int par = round & 1;
         if (lane == 0) {
             part[par][0][wave] = wmax;
             part[par][1][wave] = widx;
             part[par][2][wave] = __float_as_int(wx);
             part[par][3][wave] = __float_as_int(wy);
             part[par][4][wave] = __float_as_int(wz);
+            if (PAIRED) part[par][5][wave] = wsec;
         }
         __syncthreads();
         const int l16 = lane & (kWaves - 1);
         const int pv = part[par][0][l16], pi = part[par][1][l16];
         const float qx = __int_as_float(part[par][2][l16]), qy = __int_as_float(part[par][3][l16]), qz = __int_as_float(part[par][4][l16]);
+        const int psec = PAIRED ? part[par][5][l16] : 0;
         // lane l: would candidate l, as the next sample, lower any running distance of THIS wave's points?
         const float ex = fmaxf(fmaxf(blo[0] - qx, qx - bhi[0]), 0.f), ey = fmaxf(fmaxf(blo[1] - qy, qy - bhi[1]), 0.f),
                     ez = fmaxf(fmaxf(blo[2] - qz, qz - bhi[2]), 0.f);
@@ -376,29 +401,89 @@ __global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__re
         }
         if (tid == 0) idx[s] = (int64_t)cur;
         if (s == S - 1) break;
-        if ((needmask >> win) & 1ull) {  // wave-uniform
-            const float cx = rpe_readlane(qx, win), cy = rpe_readlane(qy, win), cz = rpe_readlane(qz, win);
-            const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
-            int t = -1;
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
-                const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
-                f32x2 nd = xx + yy;
+        const float cx = rpe_readlane(qx, win), cy = rpe_readlane(qy, win), cz = rpe_readlane(qz, win);
+        bool pair = false;
+        int win2 = 0;
+#ifdef RPE_FPS_PROBE
+        int why = 0;
+#endif
+        float c2x = 0.f, c2y = 0.f, c2z = 0.f;
+        if (PAIRED) {
+            const int pv2 = l16 == win ? -1 : pv;
+            int b2;
+            {
+                int r = row_max16_i32(pv2);
+                asm volatile("s_nop 1\n\tv_readlane_b32 %0, %1, 15" : "=s"(b2) : "v"(r));
+            }
+            const unsigned long long hold2 = __builtin_amdgcn_ballot_w64(pv2 == b2) & 0xffffull;
+#ifdef RPE_FPS_PROBE
+            why = 1;
+#endif
+            if (b2 >= 0 && (hold2 & (hold2 - 1)) == 0ull) {  // a valid runner-up held by exactly one other wave
+                win2 = (int)__builtin_ctzll(hold2);
+                const int sec1 = __builtin_amdgcn_readlane(psec, win);
+                c2x = rpe_readlane(qx, win2), c2y = rpe_readlane(qy, win2), c2z = rpe_readlane(qz, win2);
+                const float dx = c2x - cx, dy = c2y - cy, dz = c2z - cz;  // as the update computes it for the point c2
+                const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                float nd = xx + yy;
                 nd = nd + zz;
-                md[2 * h] = min(md[2 * h], __float_as_int(nd[0]));
-                md[2 * h + 1] = min(md[2 * h + 1], __float_as_int(nd[1]));
-                t = max(t, max(md[2 * h], md[2 * h + 1]));
+                pair = sec1 < b2 && __float_as_int(nd) >= b2;
+#ifdef RPE_FPS_PROBE
+                why = pair ? 0 : (sec1 >= b2 ? 2 : 3);
+#endif
+            }
+        }
+#ifdef RPE_FPS_PROBE
+        if (tid == 0 && s >= 8) { idx[0] += 1; idx[1 + why] += 1; }  // rounds; paired, not unique, second-best too high, c1 reaches c2
+#endif
+        if (pair) {
+            if (tid == 0) idx[s + 1] = (int64_t)__builtin_amdgcn_readlane(pi, win2);
+            if (s + 1 == S - 1) break;
+        }
+        const bool need1 = (needmask >> win) & 1ull, need2 = pair && ((needmask >> win2) & 1ull);  // wave-uniform
+        if (need1 || need2) {
+            // (one of the two may not reach this wave's box: its update would change nothing, so its sample is replaced by the other)
+            const float ax = need1 ? cx : c2x, ay = need1 ? cy : c2y, az = need1 ? cz : c2z;
+            const f32x2 cx2 = {ax, ax}, cy2 = {ay, ay}, cz2 = {az, az};
+            int t = -1;
+            if (need1 && need2) {
+                const f32x2 ex2 = {c2x, c2x}, ey2 = {c2y, c2y}, ez2 = {c2z, c2z};
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
+                    const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                    f32x2 nd = xx + yy;
+                    nd = nd + zz;
+                    const f32x2 fx = px[h] - ex2, fy = py[h] - ey2, fz = pz[h] - ez2;
+                    const f32x2 x2 = fx * fx, y2 = fy * fy, z2 = fz * fz;
+                    f32x2 ne = x2 + y2;
+                    ne = ne + z2;
+                    md[2 * h] = min(md[2 * h], min(__float_as_int(nd[0]), __float_as_int(ne[0])));
+                    md[2 * h + 1] = min(md[2 * h + 1], min(__float_as_int(nd[1]), __float_as_int(ne[1])));
+                    t = max(t, max(md[2 * h], md[2 * h + 1]));
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
+                    const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                    f32x2 nd = xx + yy;
+                    nd = nd + zz;
+                    md[2 * h] = min(md[2 * h], __float_as_int(nd[0]));
+                    md[2 * h + 1] = min(md[2 * h + 1], __float_as_int(nd[1]));
+                    t = max(t, max(md[2 * h], md[2 * h + 1]));
+                }
             }
             candidate(t);
         }
+        s += pair ? 2 : 1;
     }
 }
 
-template <int PPT>
+template <int PPT, bool PAIRED>
 int launch_fps_pruned2(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, hipStream_t st) {
     const size_t shmem = sizeof(unsigned long long) * (size_t)PPT * kThreads;
-    auto kern = fps_pruned2_kernel<PPT>;
+    auto kern = fps_pruned2_kernel<PPT, PAIRED>;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return (int)e;
@@ -427,18 +512,25 @@ int launch_fps_plain(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B
 RPE_API int rpe_fps_algo(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, int algo,
                          rpe_stream_t stream) {
     if (!xyz || !idx || B < 0 || N <= 0 || S < 0 || S > N) return RPE_EINVAL;
-    if (algo != RPE_FPS_AUTO && algo != RPE_FPS_PLAIN && algo != RPE_FPS_PRUNED) return RPE_EINVAL;
+    if (algo != RPE_FPS_AUTO && algo != RPE_FPS_PLAIN && algo != RPE_FPS_PRUNED && algo != RPE_FPS_PAIRED) return RPE_EINVAL;
     if (B == 0 || S == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int ppt = (N + kThreads - 1) / kThreads;
     const bool can_prune = N > kThreads && N <= 16 * kThreads;
-    if (algo == RPE_FPS_PRUNED && !can_prune) return RPE_EUNSUPPORTED;
-    // auto: the Morton sort of the pruned kernel costs ~100 us per launch; it pays from a few thousand samples on
-    if (algo == RPE_FPS_PRUNED || (algo == RPE_FPS_AUTO && can_prune && N >= 8 * kThreads && S >= 2048)) {
-        if (ppt <= 2) return launch_fps_pruned2<2>(xyz, sb, sn, sd, B, N, S, idx, st);
-        if (ppt <= 4) return launch_fps_pruned2<4>(xyz, sb, sn, sd, B, N, S, idx, st);
-        if (ppt <= 8) return launch_fps_pruned2<8>(xyz, sb, sn, sd, B, N, S, idx, st);
-        return launch_fps_pruned2<16>(xyz, sb, sn, sd, B, N, S, idx, st);
+    if ((algo == RPE_FPS_PRUNED || algo == RPE_FPS_PAIRED) && !can_prune) return RPE_EUNSUPPORTED;
+    // auto: the Morton sort of the pruned kernels costs ~100 us per launch; it pays from a few thousand samples on
+    const bool auto_pruned = algo == RPE_FPS_AUTO && can_prune && N >= 8 * kThreads && S >= 2048;
+    if (algo == RPE_FPS_PAIRED || (auto_pruned && RPE_FPS_AUTO_PAIRED)) {
+        if (ppt <= 2) return launch_fps_pruned2<2, true>(xyz, sb, sn, sd, B, N, S, idx, st);
+        if (ppt <= 4) return launch_fps_pruned2<4, true>(xyz, sb, sn, sd, B, N, S, idx, st);
+        if (ppt <= 8) return launch_fps_pruned2<8, true>(xyz, sb, sn, sd, B, N, S, idx, st);
+        return launch_fps_pruned2<16, true>(xyz, sb, sn, sd, B, N, S, idx, st);
+    }
+    if (algo == RPE_FPS_PRUNED || auto_pruned) {
+        if (ppt <= 2) return launch_fps_pruned2<2, false>(xyz, sb, sn, sd, B, N, S, idx, st);
+        if (ppt <= 4) return launch_fps_pruned2<4, false>(xyz, sb, sn, sd, B, N, S, idx, st);
+        if (ppt <= 8) return launch_fps_pruned2<8, false>(xyz, sb, sn, sd, B, N, S, idx, st);
+        return launch_fps_pruned2<16, false>(xyz, sb, sn, sd, B, N, S, idx, st);
     }
     if (ppt <= 2) return launch_fps_plain<2>(xyz, sb, sn, sd, B, N, S, idx, st);
     if (ppt <= 4) return launch_fps_plain<4>(xyz, sb, sn, sd, B, N, S, idx, st);

@@ -191,9 +191,10 @@ def _fps_algo(xyz, S, algo):
     return idx.cpu().numpy()
 
 
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 def test_fps_both_kernels_agree(golden_dir, algo):
-    """The plain kernel and the cluster-skipping kernel give identical samples, whichever one rpe_fps would pick."""
+    """The plain kernel, the cluster-skipping kernel and its paired form (two samples per synchronisation round where the
+    sequential rule provably gives them) return identical samples, whichever one rpe_fps would pick."""
     for name in K.FPS_CASES:
         xyz, S = K.fps_inputs(name)
         got = _fps_algo(xyz, S, algo)
@@ -203,7 +204,30 @@ def test_fps_both_kernels_agree(golden_dir, algo):
     assert np.array_equal(_fps_algo(xyz, 4999, algo), O.furthest_point_sampling(xyz, 4999))
     xyz = I.ids_cloud(I.rng(8301), 1, 700)   # N <= 1024: plain only
     got = _fps_algo(xyz, 300, algo)
-    assert (got is None) if algo == 2 else np.array_equal(got, O.furthest_point_sampling(xyz, 300))
+    assert (got is None) if algo != 1 else np.array_equal(got, O.furthest_point_sampling(xyz, 300))
+
+
+@pytest.mark.parametrize("kind", ["duplicates", "lattice", "clusters", "odd_and_even_lengths"])
+def test_fps_paired_kernel_on_tie_heavy_clouds(kind):
+    """The paired kernel's speculation must hold back wherever equal running distances make the runner-up ambiguous: clouds
+    with every point twice, integer lattices (hundreds of equal distances), two far-apart clusters (the runner-up of one round
+    is usually the winner of the next), and sample counts of both parities (the last round may emit one or two)."""
+    r = I.rng(8400)
+    if kind == "duplicates":
+        base = I.ids_cloud(r, 2, 1500)
+        clouds = [(np.concatenate([base, base], axis=1), 2999)]
+    elif kind == "lattice":
+        clouds = [(r.integers(0, 12, (2, 4000, 3)).astype(np.float32), 3000)]
+    elif kind == "clusters":
+        a = I.unit_cloud(r, 2, 2000)
+        clouds = [(np.concatenate([a, a[:, ::-1] + np.float32(50.0)], axis=1), 3999)]
+    else:
+        xyz = I.ids_cloud(r, 1, 4100)
+        clouds = [(xyz, S) for S in (1, 2, 3, 1000, 1001, 4099)]
+    for xyz, S in clouds:
+        want = O.furthest_point_sampling(xyz, S)
+        for algo in (2, 3):
+            assert np.array_equal(_fps_algo(xyz, S, algo), want), (kind, S, algo)
 
 
 @pytest.mark.parametrize("B,N,S", [(1, 2, 1), (2, 65, 64), (3, 1023, 100), (1, 1025, 1024), (2, 3000, 700), (1, 9000, 50), (1, 20000, 40)])

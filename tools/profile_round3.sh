@@ -45,10 +45,10 @@ for pass in a b c; do
   (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_corr_$pass -- python3 $GRAFT_REPO_ROOT/tools/prof_corr.py 0 6 > /tmp/pmc_corr_$pass.log 2>&1)
   rm -rf /tmp/pmc_fps_$pass
   case $pass in c) C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE";; esac
-  (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_fps_$pass -- python3 $GRAFT_REPO_ROOT/tools/prof_fps.py -1 5 > /tmp/pmc_fps_$pass.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/pmc_fps_$pass -- python3 $GRAFT_REPO_ROOT/tools/prof_fps.py 5 > /tmp/pmc_fps_$pass.log 2>&1)
 done
 python3 tools/pmc_summary.py corr_mfma_dma_kernel $OUT/corr_microbench_pmc.json "correlation2d 1x256x544x960 md=4 fp32 (tools/prof_corr.py 0 6)" /tmp/pmc_corr_a /tmp/pmc_corr_b /tmp/pmc_corr_c
-python3 tools/pmc_summary.py fps_pruned2_kernel $OUT/fps_pmc.json "furthest_point_sampling 8 x 8192 -> 4096 (tools/prof_fps.py -1 5)" /tmp/pmc_fps_a /tmp/pmc_fps_b /tmp/pmc_fps_c
+python3 tools/pmc_summary.py fps_pruned2_kernel $OUT/fps_pmc.json "furthest_point_sampling 8 x 8192 -> 4096 (tools/prof_fps.py 5)" /tmp/pmc_fps_a /tmp/pmc_fps_b /tmp/pmc_fps_c
 # 6. the hot-path sequence alone, eager, kernel stats
 (cd /tmp && rm -rf /tmp/p6 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p6 -- python3 $GRAFT_REPO_ROOT/bench.py --workload hotpath --eager --steps 10 --warmup 2 --no-cpu-baseline --no-corr-microbench > /tmp/p6.log 2>&1)
 cp $(find /tmp/p6 -name "*kernel_stats.csv" | head -1) $OUT/hotpath_kernel_stats.csv
