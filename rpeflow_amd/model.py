@@ -19,7 +19,7 @@ from .csrc import correlation2d as native_correlation2d
 from .csrc.wrapper import _correlation2d_algo as correlation2d_fused_leaky
 from .hotpath import native_ops
 from .pwc3d_core import FlowEstimator3D as NativeFlowEstimator3D
-from .utils import Conv1dNormRelu, Conv2dNormRelu, conv_module, mesh_grid, resize_frames, upsample2x_pair
+from .utils import Conv1dNormRelu, Conv2dNormRelu, conv_module, mesh_grid, resize_frames, run_chain, upsample2x_pair
 from .utils import backwarp_2d as native_backwarp_2d
 
 
@@ -321,7 +321,7 @@ class CorrFeatureFuser2D(nn.Module):
         feat_3d = torch.cat([feat_3d, last_flow_3d_to_2d], dim=1)
         feat_3d_to_2d = self._ops.project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])
         feat_3d_to_2d[:, -2:] -= last_flow_2d  # RPEFlow_core.py:82
-        return self.fuse(feat_2d, self.mlps(torch.cat([feat_3d_to_2d, efeat_2d], dim=1)))
+        return self.fuse(feat_2d, run_chain(self.mlps, torch.cat([feat_3d_to_2d, efeat_2d], dim=1)))
 
 
 class CorrFeatureFuser3D(nn.Module):
@@ -339,7 +339,7 @@ class CorrFeatureFuser3D(nn.Module):
         feat_2d_to_3d = self._ops.grid_sample_wrapper(torch.cat([feat_corr_2d, last_flow_2d_to_3d], dim=1), xy)
         efeat_2d_to_3d = self._ops.grid_sample_wrapper(efeat_2d, xy)
         feat_2d_to_3d[:, -2:] -= last_flow_3d[:, :2]  # RPEFlow_core.py:110
-        return self.fuse(feat_corr_3d, self.mlps(torch.cat([feat_2d_to_3d, efeat_2d_to_3d], dim=1)))
+        return self.fuse(feat_corr_3d, run_chain(self.mlps, torch.cat([feat_2d_to_3d, efeat_2d_to_3d], dim=1)))
 
 
 class DecoderFeatureFuser2D(nn.Module):

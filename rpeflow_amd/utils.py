@@ -266,6 +266,40 @@ class Conv1dNormRelu(_ConvNormRelu):
 class Conv2dNormRelu(_ConvNormRelu):
     dims = 2
 
+    def forward(self, x):
+        y = pointwise_chain([self], x) if x.is_cuda else None
+        return y if y is not None else super().forward(x)
+
+
+_CHAIN_MAX_POSITIONS = int(os.environ.get("RPE_CHAIN_MAX_POSITIONS", 70000))  # batch x positions: up to 72 x 120 x 8 (beyond: GEMM + epilogue)
+
+
+def pointwise_chain(blocks, x):
+    """One or two 1x1 Conv{1,2}dNormRelu blocks on x [B,C,...] in ONE launch of the fused point-wise MLP kernel (GEMM(s), bias,
+    eval-mode BatchNorm and activation together; csrc/mlp_fused.hip) -- or None when that kernel does not apply (widths it is
+    not instantiated for, training, large maps, where a library GEMM plus the epilogue pass is faster)."""
+    if not x.is_cuda or x.dim() < 3 or not _inference_only(x, *[p for b in blocks for p in b.parameters()]):
+        return None
+    B, C = x.shape[0], x.shape[1]
+    P = x.numel() // max(1, B * C)
+    if x.dim() > 3 and (B * P > _CHAIN_MAX_POSITIONS or not x.is_contiguous()):
+        return None
+    y = fused_mlp1d(x.reshape(B, C, P), list(blocks))
+    return None if y is None else y.reshape((B, y.shape[1]) + tuple(x.shape[2:]))
+
+
+def run_chain(seq, x):
+    """nn.Sequential of 1x1 Conv*NormRelu blocks (the fusers' ``mlps``): pairs of layers fused where the kernel has them."""
+    blocks = list(seq)
+    i = 0
+    while i < len(blocks):
+        y = pointwise_chain(blocks[i:i + 2], x) if i + 1 < len(blocks) else None
+        if y is not None:
+            x, i = y, i + 2
+            continue
+        x, i = blocks[i](x), i + 1
+    return x
+
 
 class _MLP(nn.Module):
     """utils.py:65-98: ModuleList ``convs`` of 1x1 ConvNormRelu blocks."""
@@ -545,7 +579,8 @@ def _mlp_pack(blocks):
         return cache[1]
     packed = None
     convs = [blk.conv_fn for blk in blocks]
-    plain = all(c.kernel_size == (1,) and c.stride == (1,) and c.padding == (0,) and c.groups == 1 for c in convs)
+    plain = all(all(k == 1 for k in c.kernel_size) and all(st == 1 for st in c.stride) and isinstance(c.padding, tuple)
+                and all(pd == 0 for pd in c.padding) and c.groups == 1 for c in convs)  # (Conv1d or Conv2d: a 2-D map is its flattened positions)
     epis = [blk._epilogue() for blk in blocks]
     # every workgroup streams all the weights for its 16 points: worth it for the small layers only.  Measured, B = 4,
     # fused vs library GEMM + epilogue launches: 128 -> 128 -> 64 7 vs 14 us, 195 -> 128 -> 128 10 vs 14, 64 -> 64 4 vs 7,
@@ -564,7 +599,7 @@ def _mlp_pack(blocks):
 
             def pack_w(conv, t_out, k_groups):
                 w = torch.zeros((16 * t_out, 16 * k_groups), dtype=torch.float32, device=dev)
-                w[:conv.out_channels, :conv.in_channels] = conv.weight.detach()[:, :, 0].float()
+                w[:conv.out_channels, :conv.in_channels] = conv.weight.detach().reshape(conv.out_channels, conv.in_channels).float()
                 return w.reshape(t_out, 16, k_groups, 4, 4).permute(2, 0, 3, 1, 4).contiguous()  # [g][t][kk][o][s]
 
             def pack_ss(epi, t_out, c_out):
