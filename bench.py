@@ -123,11 +123,22 @@ def knn_microbench(dev, iters=30):
     e.record()
     torch.cuda.synchronize()
     us = s.elapsed_time(e) / iters * 1e3
+    from rpeflow_amd.csrc.wrapper import k_nearest_neighbor_ties
+    for _ in range(5):
+        k_nearest_neighbor_ties(cloud, query, k, ties="index")
+    s.record()
+    for _ in range(iters):
+        k_nearest_neighbor_ties(cloud, query, k, ties="index")
+    e.record()
+    torch.cuda.synchronize()
+    us_index = s.elapsed_time(e) / iters * 1e3
     pairs = B * M * Q
     tflops = pairs * (2 * D + 3) / us / 1e6
     return {"kernel": "knn_mfma_kernel<3> (+ the workgroup's tied queries redone the libstdc++ way)", "bound": "mfma", "achieved": round(tflops, 2),
             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("knn16_pmc.json"),
             "us_per_launch": round(us, 1), "pairs_per_s": round(pairs / us * 1e6), "algorithmic_bytes": 4 * B * D * (M + Q) + 8 * B * Q * k,
+            "us_per_launch_lowest_index_ties": round(us_index, 1),  # the same search without the libstdc++ restatement of equal distances
+            "frac_lowest_index_ties": round(pairs * (2 * D + 3) / us_index / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
             "workload": "k_nearest_neighbor 3-D, 8 x (8192 -> 4096), k = 16, fp32, indices as torch.topk returns them"}
 
 
