@@ -158,6 +158,13 @@ int rpe_gather_channel_first(const float *data, int64_t sb, int64_t sc, int64_t 
 int rpe_gather_channel_last(const float *data, int64_t sb, int64_t sn, int64_t sc, const int64_t *idx,
                             int B, int C, int N, int I, float *out, rpe_stream_t stream);
 
+/* rpe_pointwise_conv: a stride-1 1x1 convolution with its epilogue in one launch (csrc/pointwise.hip; models/utils.py:7-62,
+ * models/restormer_arch.py:88-110):  y[b][o][p] = act(scale[o] * sum_c W[o][c] x[b][c][p] + shift[o]) (+ residual[b][o][p]).
+ * x [B,Cin,P], y / residual [B,Cout,P] contiguous fp32; packed_weight [ceil(Cout/16)][ceil(Cin/4)][64]: entry (ot, kt, 16 k + i)
+ * = W[16 ot + i][4 kt + k], zero outside (the MFMA A-fragment order); scale / shift / residual may be NULL; act 0 none,
+ * 1 relu, 2 leaky_relu(slope).  Meant for the latency-bound layers (below ~0.5 GFLOP); deterministic.                  */
+int rpe_pointwise_conv(const float *x, int B, int Cin, int64_t P, const float *packed_weight, int Cout, const float *scale,
+                       const float *shift, int act, float slope, const float *residual, float *y, rpe_stream_t stream);
 /* rpe_im2col: cols [B, C*kh*kw, Ho*Wo] = torch.nn.functional.unfold(x [B,C,H,W], (kh,kw), dilation, padding, stride) for the whole
  * batch in one launch: the input side of the small convolutions that run as one deterministic GEMM instead of MIOpen's
  * atomically accumulating split-K kernels (rpeflow_amd/utils.py, wants_im2col).                                    */

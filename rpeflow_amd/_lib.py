@@ -56,6 +56,7 @@ _PROTOTYPES = {
                             _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     "rpe_gather_channel_first": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_gather_channel_last": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
+    "rpe_pointwise_conv": [_c_ptr, _c_int, _c_int, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_float, _c_ptr, _c_ptr, _c_ptr],
     "rpe_im2col": [_c_ptr] + [_c_int] * 12 + [_c_ptr, _c_ptr],
     "rpe_knn_interpolate": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                             _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],

@@ -1,0 +1,135 @@
+// 1x1 convolution (Conv1d / Conv2d, stride 1) with its whole epilogue:
+//   y[b][o][p] = act(scale[o] * sum_c W[o][c] x[b][c][p] + shift[o]) (+ residual[b][o][p]).
+//
+// The reference runs these as convolution + bias + BatchNorm + activation (+ a residual add): models/utils.py:7-62,
+// models/restormer_arch.py:88-110, 169-222.  A library GEMM covers the sum only, so every such layer was GEMM + one
+// element-wise pass (affine_act_kernel, 105 launches per forward) or GEMM + a copy of the residual in front of it (baddbmm).
+// Most of these layers are latency-bound (8-15 us whatever the kernel does), so one launch less per layer is worth more than
+// GEMM efficiency; measured on the whole forward that holds up to the largest ones (rpeflow_amd/utils.py, _PW_MAX_FLOPS).
+//
+// fp32 on v_mfma_f32_16x16x4_f32: A = a 16 x 4 piece of W (pre-packed on the host in fragment order: one coalesced 256-byte
+// load per piece), B = 4 channels x 16 positions of x.  A lane loads FOUR consecutive positions of one channel row (one
+// 16-byte load when the row stride allows) and feeds them to four position tiles, so the accumulators of a lane hold four
+// consecutive positions of an output row and the epilogue stores 16 bytes per lane (positions p0 + 4 j + t, t = tile).
+// A wave owns OT output tiles x 64 positions; the four waves of a workgroup take different output tiles of the same 64
+// positions (their x loads hit in L1).  Summation order per output: channels ascending in groups of four -- fixed: the
+// kernel is deterministic.
+#include "common.h"
+
+namespace {
+
+typedef float pw_f32x4 __attribute__((ext_vector_type(4)));
+
+struct PwArgs {
+    const float *x;       // [B][Cin][P]
+    const float *wpk;     // [n_otiles][ktiles][64]: lane (k, i) of piece (ot, kt) = W[16 ot + i][4 kt + k], zero outside
+    const float *scale;   // [Cout] or NULL (1)
+    const float *shift;   // [Cout] or NULL (0)
+    const float *res;     // [B][Cout][P] or NULL
+    float *y;             // [B][Cout][P]
+    int Cin, Cout, ktiles, n_otiles, act;
+    int64_t P;
+    float slope;
+};
+
+template <int OT, bool VEC>
+__global__ __launch_bounds__(256) void pointwise_conv_kernel(PwArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = lane >> 4, j = lane & 15;
+    const int ot0 = (blockIdx.y * 4 + wave) * OT;
+    if (ot0 >= a.n_otiles) return;
+    const int b = blockIdx.z;
+    const int64_t P = a.P, p0 = (int64_t)blockIdx.x * 64 + 4 * j;
+    const float *xb = a.x + (int64_t)b * a.Cin * P;
+    pw_f32x4 acc[OT][4];
+#pragma unroll
+    for (int o = 0; o < OT; ++o)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[o][t] = pw_f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool p_in = p0 < P;
+    // four channel groups per round: all their loads are issued before the first matrix instruction waits for one
+    constexpr int U = 4;
+    for (int kt0 = 0; kt0 < a.ktiles; kt0 += U) {
+        float xv[U][4], av[U][OT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kt = kt0 + u, c = 4 * kt + k;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xv[u][t] = 0.f;
+            if (c < a.Cin && p_in) {
+                const float *row = xb + (int64_t)c * P + p0;
+                if (VEC) {  // P % 4 == 0 and 16-byte aligned base: the four positions are in range together
+                    const float4 v = *reinterpret_cast<const float4 *>(row);
+                    xv[u][0] = v.x, xv[u][1] = v.y, xv[u][2] = v.z, xv[u][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) xv[u][t] = p0 + t < P ? row[t] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < OT; ++o)
+                av[u][o] = (kt < a.ktiles && ot0 + o < a.n_otiles) ? a.wpk[((int64_t)(ot0 + o) * a.ktiles + kt) * 64 + lane] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int o = 0; o < OT; ++o)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[o][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][o], xv[u][t], acc[o][t], 0, 0, 0);
+    }
+    if (!p_in) return;
+    // D layout: lane (g = lane >> 4, j), register r: output 16 ot + 4 g + r, position p0 + t of tile t
+    const int g = k;
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = 16 * (ot0 + o) + 4 * g + r;
+            if (oc >= a.Cout) continue;
+            const float sc = a.scale ? a.scale[oc] : 1.0f, sh = a.shift ? a.shift[oc] : 0.0f;
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float u = sc * acc[o][t][r] + sh;
+                v[t] = a.act == 1 ? fmaxf(u, 0.f) : (a.act == 2 ? (u >= 0.f ? u : u * a.slope) : u);
+            }
+            const int64_t off = ((int64_t)b * a.Cout + oc) * P + p0;
+            if (VEC) {
+                if (a.res) {
+                    const float4 rr = *reinterpret_cast<const float4 *>(a.res + off);
+                    v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
+                }
+                *reinterpret_cast<float4 *>(a.y + off) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (p0 + t < P) a.y[off + t] = a.res ? v[t] + a.res[off + t] : v[t];
+            }
+        }
+    }
+}
+
+template <int OT>
+int launch_pw(const PwArgs &a, int B, bool vec, hipStream_t st) {
+    dim3 grid((unsigned)((a.P + 63) / 64), (unsigned)((a.n_otiles + 4 * OT - 1) / (4 * OT)), (unsigned)B);
+    if (vec) hipLaunchKernelGGL((pointwise_conv_kernel<OT, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pointwise_conv_kernel<OT, false>), grid, dim3(256), 0, st, a);
+    return rpe_launch_status();
+}
+
+}  // namespace
+
+RPE_API int rpe_pointwise_conv(const float *x, int B, int Cin, int64_t P, const float *packed_weight, int Cout, const float *scale,
+                               const float *shift, int act, float slope, const float *residual, float *y, rpe_stream_t stream) {
+    if (!x || !packed_weight || !y || B < 0 || Cin < 1 || Cout < 1 || P < 0 || act < 0 || act > 2) return RPE_EINVAL;
+    if (B == 0 || P == 0) return 0;
+    if (B > 65535) return RPE_EUNSUPPORTED;
+    PwArgs a{x, packed_weight, scale, shift, residual, y, Cin, Cout, (Cin + 3) / 4, (Cout + 15) / 16, act, P, slope};
+    const bool vec = P % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+    hipStream_t st = (hipStream_t)stream;
+    // output tiles per wave: enough workgroups to cover the chip on the small maps, fewer re-reads of x on the wider layers
+    const int64_t wgs1 = ((P + 63) / 64) * ((a.n_otiles + 3) / 4) * B;
+    if (a.n_otiles >= 16 && wgs1 >= 4 * 1024) return launch_pw<4>(a, B, vec, st);
+    if (a.n_otiles >= 8 && wgs1 >= 2 * 1024) return launch_pw<2>(a, B, vec, st);
+    return launch_pw<1>(a, B, vec, st);
+}

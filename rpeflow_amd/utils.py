@@ -62,34 +62,78 @@ def _inference_only(*tensors):
     return not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in tensors)
 
 
-def pointwise_conv(x, weight, bias=None, stride=1, residual=None, inplace=False):
-    """A 1x1 convolution (Conv1d / Conv2d, groups 1, no padding) as ONE strided-batched GEMM: y[b] = W @ x[b] over [B,C,P]
-    (rocBLAS / hipBLASLt through torch.matmul; stride s reads every s-th pixel first).
+# flops per launch up to which the one-launch kernel is used.  Measured on the forward (median step of 40, two runs each): never
+# 17.44 ms, <= 0.6e9 17.60, <= 2.5e9 17.33, <= 1e10 17.32, always 17.21 -- even the level-1 projections (13.5 GFLOP), where the
+# library GEMM alone is faster, gain more from the epilogue / residual pass they no longer need.  The library path stays for
+# anything larger than the model produces.
+_PW_MAX_FLOPS = float(os.environ.get("RPE_POINTWISE_MAX_FLOPS", 1e12))
 
-    Why not the convolution call: MIOpen's own choice for most of this model's ~110 1x1 shapes is this very GEMM
+
+def _pw_packed_weight(weight):
+    """The 1x1 weight [Cout,Cin,...] in rpe_pointwise_conv's fragment order (include/rpeflow_hip.h), cached ON the tensor object
+    until it changes (a cache keyed by address would outlive the tensor: the allocator hands the same block to the next one)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device)
+    hit = getattr(weight, "_rpe_pw_packed", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    cout, cin = weight.shape[0], weight.shape[1]
+    nt, kt = (cout + 15) // 16, (cin + 3) // 4
+    w = torch.zeros((16 * nt, 4 * kt), dtype=torch.float32, device=weight.device)
+    w[:cout, :cin] = weight.detach().reshape(cout, cin).float()
+    packed = w.reshape(nt, 16, kt, 4).permute(0, 2, 3, 1).contiguous()  # [ot][kt][k][i]
+    weight._rpe_pw_packed = (key, packed)
+    return packed
+
+
+def pointwise_conv(x, weight, bias=None, stride=1, residual=None, inplace=False, epilogue=None):
+    """A 1x1 convolution (Conv1d / Conv2d, groups 1, no padding) over [B,C,P] (stride s reads every s-th pixel first), with
+    ``epilogue`` = (scale, shift, act) of the ConvNormRelu block around it and an optional ``residual`` [B,Cout,...].
+
+    Layers up to _PW_MAX_FLOPS (every one of this model's) run in ONE launch of rpe_pointwise_conv -- GEMM, bias / BatchNorm,
+    activation and residual add together (csrc/pointwise.hip).  Larger ones are ONE rocBLAS strided-batched GEMM
+    y[b] = W @ x[b] (the residual accumulated by the GEMM, beta = 1), followed by the epilogue pass if there is one.
+
+    Why not the convolution call: MIOpen's own choice for most of this model's ~110 1x1 shapes is that very GEMM
     (GemmFwd1x1_0_1), but which solver a process gets is decided by a timing race when it first meets a shape, and some of
     the candidates (GemmFwd1x1_0_2 on the small stride-2 layers, the splitting implicit GEMMs) accumulate with atomics:
-    see the note above wants_im2col.  The library's heuristic GEMM selection involves no timing and these kernels no atomics:
-    same kernels and same bits in every process and every replay."""
+    see the note above wants_im2col.  Both paths here have a fixed summation order and no timing-based selection: same
+    bits in every process and every replay."""
     if stride != 1:
         x = x[(slice(None), slice(None)) + (slice(None, None, stride),) * (x.dim() - 2)]
     B, C = x.shape[0], x.shape[1]
     spatial = x.shape[2:]
     xf = x.reshape(B, C, -1)  # (a strided view is copied here: the subsampled pixels, nothing else)
-    w = weight.reshape(weight.shape[0], C)
+    cout, P = weight.shape[0], xf.shape[2]
+    scale, shift, kind = epilogue if epilogue is not None else (None, None, None)
+    if bias is not None:  # (an epilogue's shift already contains the block's bias: callers pass one or the other)
+        shift = bias if shift is None else shift + (bias if scale is None else bias * scale)
+    if x.is_cuda and 2.0 * B * P * C * cout <= _PW_MAX_FLOPS:
+        xf = _f32(xf).contiguous()
+        res = None if residual is None else _f32(residual).reshape(B, cout, P).contiguous()
+        out = res if (inplace and res is not None and res.data_ptr() == residual.data_ptr()) else torch.empty((B, cout, P), dtype=torch.float32, device=x.device)
+        _launch(xf, "pointwise_conv", _lib.lib().rpe_pointwise_conv, _ptr(xf), B, C, P, _ptr(_pw_packed_weight(weight)), cout,
+                _ptr(scale) if scale is not None else _NULL, _ptr(shift.contiguous()) if shift is not None else _NULL,
+                _ACT_CODE[kind], 0.1, _ptr(res) if res is not None else _NULL, _ptr(out))
+        return out.reshape((B, cout) + tuple(spatial))
+    w = weight.reshape(cout, C)
     wb = w.unsqueeze(0).expand(B, -1, -1)  # batch stride 0: one strided-batched GEMM, the weight read once per sample from L2
     # (torch.matmul(w, xf) would fold the batch into the columns instead: a transposed copy of x in, one of y out)
-    add = None if residual is None else residual.reshape(B, w.shape[0], -1)  # ``residual`` [B,Cout,...]: added by the GEMM itself (beta = 1)
-    if bias is not None:
-        add = bias.view(1, -1, 1) if add is None else add + bias.view(1, -1, 1)
+    add = None if residual is None else residual.reshape(B, cout, -1)
+    plain_shift = scale is None and kind is None  # nothing but an additive term: the GEMM can carry it
+    if shift is not None and plain_shift:
+        add = shift.view(1, -1, 1) if add is None else add + shift.view(1, -1, 1)
     with _rocblas():
         if add is None:
             y = torch.bmm(wb, xf)
-        elif inplace and bias is None and residual.is_contiguous():
+        elif inplace and residual is not None and (shift is None or not plain_shift) and residual.is_contiguous():
             y = add.baddbmm_(wb, xf)  # accumulates into ``residual`` itself: no copy of it in front of the GEMM (the caller owns it)
         else:
             y = torch.baddbmm(add, wb, xf)
-    return y.reshape((B, w.shape[0]) + tuple(spatial))
+    if not plain_shift:
+        assert residual is None, "pointwise_conv: epilogue + residual on the library path is not used by the model"
+        from .restormer_ops import channel_affine_act_
+        y = channel_affine_act_(y.contiguous(), scale, shift, kind, 0.1)
+    return y.reshape((B, cout) + tuple(spatial))
 
 
 class _rocblas:
@@ -170,18 +214,33 @@ def im2col_conv(x, weight, bias, stride, padding, dilation):
     return y.reshape(B, k[0], ho, wo)
 
 
-def conv_no_bias_or(conv, x, with_bias):
+def conv_no_bias_or(conv, x, with_bias, epilogue=None):
     """The convolution of an nn.Conv1d / nn.Conv2d on the GPU, outside autograd: 1x1 -> pointwise_conv, small dilated / strided
-    / tiny -> im2col_conv (both deterministic GEMMs), everything else MIOpen."""
+    / tiny -> im2col_conv (both deterministic GEMMs), everything else MIOpen.  ``epilogue`` (scale, shift, act): applied by the
+    call (fused into the 1x1 kernel where that runs, one in-place pass otherwise)."""
     bias = conv.bias if with_bias else None
-    if is_pointwise(conv) or (all(k == 1 for k in conv.kernel_size) and conv.groups == 1 and x.dim() == 4
+    y = _conv_paths(conv, x, bias, epilogue)
+    return y
+
+
+def _apply_epilogue(y, epilogue):
+    if epilogue is None or epilogue == (None, None, None):
+        return y
+    from .restormer_ops import channel_affine_act_
+    return channel_affine_act_(y.contiguous(), epilogue[0], epilogue[1], epilogue[2], 0.1)
+
+
+def _conv_paths(conv, x, bias, epilogue):
+    if is_pointwise(conv):
+        return pointwise_conv(x, conv.weight, bias, 1, epilogue=epilogue)
+    if (all(k == 1 for k in conv.kernel_size) and conv.groups == 1 and x.dim() == 4
                               and x.shape[0] * x.shape[2] * x.shape[3] <= 4 * _IM2COL_MAX_POSITIONS and isinstance(conv.padding, tuple)
                               and all(p == 0 for p in conv.padding) and len(set(conv.stride)) == 1):
-        return pointwise_conv(x, conv.weight, bias, conv.stride[0])  # (the second case: the small stride-2 1x1 layers)
+        return pointwise_conv(x, conv.weight, bias, conv.stride[0], epilogue=epilogue)  # (the small stride-2 1x1 layers)
     if wants_im2col(conv, x):
-        return im2col_conv(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation)
+        return _apply_epilogue(im2col_conv(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation), epilogue)
     f = torch.nn.functional.conv1d if x.dim() == 3 else torch.nn.functional.conv2d
-    return f(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups)
+    return _apply_epilogue(f(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups), epilogue)
 
 
 def conv_module(conv, x, residual=None, inplace=False):
@@ -245,11 +304,8 @@ class _ConvNormRelu(nn.Module):
             return self.relu_fn(self.norm_fn(self.conv_fn(x)))
         # convolution without its bias (MIOpen / hipBLASLt), then bias + BatchNorm + activation in ONE in-place kernel
         from .restormer_ops import channel_affine_act_
-        y = conv_no_bias_or(self.conv_fn, x, False)  # 1x1 / small dilated or strided: deterministic GEMMs; else MIOpen
-        scale, shift, kind = epi
-        if scale is None and shift is None and kind is None:
-            return y
-        return channel_affine_act_(y.contiguous(), scale, shift, kind, 0.1)
+        # 1x1 / small dilated or strided: deterministic GEMMs (1x1: epilogue inside the kernel on the small maps); else MIOpen + one pass
+        return conv_no_bias_or(self.conv_fn, x, False, epilogue=epi)
 
 
 class Conv1dNormRelu(_ConvNormRelu):

@@ -219,3 +219,36 @@ def test_small_convolutions_are_deterministic_gemms(k, s, p, d, H, W, n):
     assert (outs[0] - ref).abs().max() < 1e-4
     big = torch.randn(4, 128, 144, 240, device=DEV)
     assert not wants_im2col(torch.nn.Conv2d(128, 96, 3, 1, 2, 2), big)  # large maps: MIOpen's non-splitting kernels
+
+
+@pytest.mark.parametrize("B,cin,cout,spatial", [(4, 192, 510, (9, 15)), (2, 7, 5, (3, 5)), (8, 67, 96, (500,)), (3, 130, 33, (36, 60)), (1, 4, 16, (64,)),
+                                                (4, 255, 96, (18, 30)), (2, 96, 1020, (135,))])
+@pytest.mark.parametrize("act", [None, "relu", "leaky_relu"])
+def test_pointwise_conv_kernel_with_epilogue(B, cin, cout, spatial, act):
+    """rpe_pointwise_conv (csrc/pointwise.hip): 1x1 convolution + per-channel scale / shift + activation (+ residual, also
+    accumulated in place) in one launch against the plain PyTorch ops on the CPU; ragged channel counts (Cin % 4, Cout % 16),
+    position counts that are not multiples of 4 / 64 (9 x 15 = 135), both Conv1d and Conv2d layouts."""
+    from rpeflow_amd.utils import pointwise_conv
+    torch.manual_seed(cin * 7 + cout)
+    x = torch.randn((B, cin) + spatial)
+    w = torch.randn((cout, cin) + (1,) * len(spatial)) / cin ** 0.5
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.3
+    res = torch.randn((B, cout) + spatial)
+    conv = F.conv1d if len(spatial) == 1 else F.conv2d
+    f = {None: lambda t: t, "relu": torch.relu, "leaky_relu": lambda t: F.leaky_relu(t, 0.1)}[act]
+    shape = (1, -1) + (1,) * len(spatial)
+    ref = f(conv(x, w) * scale.view(shape) + shift.view(shape))
+    d = lambda t: t.to(DEV)
+    got = pointwise_conv(d(x), d(w), epilogue=(d(scale), d(shift), act))
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert (got.cpu() - ref).abs().max() < tol
+    # bias + residual, out of place and accumulated into the residual tensor itself
+    bias = torch.randn(cout)
+    ref2 = conv(x, w, bias) + res
+    got2 = pointwise_conv(d(x), d(w), d(bias), residual=d(res))
+    assert (got2.cpu() - ref2).abs().max() < tol
+    r = d(res).contiguous()
+    got3 = pointwise_conv(d(x), d(w), None, residual=r, inplace=True)
+    assert got3.data_ptr() == r.data_ptr() and (got3.cpu() - (conv(x, w) + res)).abs().max() < tol
+    again = pointwise_conv(d(x), d(w), epilogue=(d(scale), d(shift), act))
+    assert torch.equal(got, again)  # fixed summation order
