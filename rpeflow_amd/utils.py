@@ -76,7 +76,8 @@ def _pw_packed_weight(weight):
     hit = getattr(weight, "_rpe_pw_packed", None)
     if hit is not None and hit[0] == key:
         return hit[1]
-    cout, cin = weight.shape[0], weight.shape[1]
+    cout = weight.shape[0]
+    cin = weight.numel() // cout  # (a k x k weight counts as Cin*k*k input channels: the rows of its im2col matrix)
     nt, kt = (cout + 15) // 16, (cin + 3) // 4
     w = torch.zeros((16 * nt, 4 * kt), dtype=torch.float32, device=weight.device)
     w[:cout, :cin] = weight.detach().reshape(cout, cin).float()
@@ -115,7 +116,7 @@ def pointwise_conv(x, weight, bias=None, stride=1, residual=None, inplace=False,
                 _ptr(scale) if scale is not None else _NULL, _ptr(shift.contiguous()) if shift is not None else _NULL,
                 _ACT_CODE[kind], 0.1, _ptr(res) if res is not None else _NULL, _ptr(out))
         return out.reshape((B, cout) + tuple(spatial))
-    w = weight.reshape(cout, C)
+    w = weight.reshape(cout, -1)
     wb = w.unsqueeze(0).expand(B, -1, -1)  # batch stride 0: one strided-batched GEMM, the weight read once per sample from L2
     # (torch.matmul(w, xf) would fold the batch into the columns instead: a transposed copy of x in, one of y out)
     add = None if residual is None else residual.reshape(B, cout, -1)
@@ -177,6 +178,9 @@ def is_pointwise(conv):
 _IM2COL_MAX_POSITIONS = 36000   # batch x output positions: beyond, MIOpen's implicit GEMMs fill the GPU without splitting K
 _IM2COL_TINY_POSITIONS = 600    # plain 3x3 convolutions this small (9 x 15, batch 4) are sometimes given to the splitting kernels too
 _IM2COL_MAX_BYTES = 192 << 20   # size of the unfolded input
+# The unfolded GEMM stays on rocBLAS + one epilogue pass: K = 9 Cin is deep (1152 for the context network), where the 1x1 kernel
+# (no K split, four channel groups in flight) loses: forward 17.2 ms with the library GEMM, 18.3 fused below 1 GFLOP, 18.6 always.
+_IM2COL_FUSED_MAX_FLOPS = float(os.environ.get("RPE_IM2COL_FUSED_MAX_FLOPS", 0))
 
 
 def _out_size(n, k, s, p, d):
@@ -195,8 +199,9 @@ def wants_im2col(conv, x):
     return positions <= _IM2COL_MAX_POSITIONS and cols <= _IM2COL_MAX_BYTES and (special or positions <= _IM2COL_TINY_POSITIONS)
 
 
-def im2col_conv(x, weight, bias, stride, padding, dilation):
-    """conv2d as F.unfold + one strided-batched rocBLAS GEMM (deterministic summation order)."""
+def im2col_conv(x, weight, bias, stride, padding, dilation, epilogue=None):
+    """conv2d as im2col + ONE GEMM with a fixed summation order: rpe_im2col, then one rocBLAS strided-batched GEMM over the
+    unfolded input and the block's epilogue pass (the 1x1 kernel with the epilogue inside is measurably slower at K = 9 Cin)."""
     B, _, H, W = x.shape
     k = weight.shape
     ho = _out_size(H, k[2], stride[0], padding[0], dilation[0])
@@ -208,10 +213,12 @@ def im2col_conv(x, weight, bias, stride, padding, dilation):
                 dilation[0], dilation[1], _ptr(cols))
     else:
         cols = torch.nn.functional.unfold(x, (k[2], k[3]), dilation=dilation, padding=padding, stride=stride)
+    if x.is_cuda and 2.0 * cols.numel() * k[0] <= _IM2COL_FUSED_MAX_FLOPS:
+        return pointwise_conv(cols, weight, bias, 1, epilogue=epilogue).reshape(B, k[0], ho, wo)
     wb = weight.reshape(1, k[0], -1).expand(B, -1, -1)
     with _rocblas():
         y = torch.bmm(wb, cols) if bias is None else torch.baddbmm(bias.view(1, -1, 1), wb, cols)
-    return y.reshape(B, k[0], ho, wo)
+    return _apply_epilogue(y.reshape(B, k[0], ho, wo), epilogue)
 
 
 def conv_no_bias_or(conv, x, with_bias, epilogue=None):
@@ -238,7 +245,7 @@ def _conv_paths(conv, x, bias, epilogue):
                               and all(p == 0 for p in conv.padding) and len(set(conv.stride)) == 1):
         return pointwise_conv(x, conv.weight, bias, conv.stride[0], epilogue=epilogue)  # (the small stride-2 1x1 layers)
     if wants_im2col(conv, x):
-        return _apply_epilogue(im2col_conv(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation), epilogue)
+        return im2col_conv(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, epilogue)
     f = torch.nn.functional.conv1d if x.dim() == 3 else torch.nn.functional.conv2d
     return _apply_epilogue(f(x, conv.weight, bias, conv.stride, conv.padding, conv.dilation, conv.groups), epilogue)
 
