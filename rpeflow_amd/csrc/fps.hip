@@ -401,7 +401,8 @@ __global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__re
         }
         if (tid == 0) idx[s] = (int64_t)cur;
         if (s == S - 1) break;
-        const float cx = rpe_readlane(qx, win), cy = rpe_readlane(qy, win), cz = rpe_readlane(qz, win);
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        if (PAIRED) cx = rpe_readlane(qx, win), cy = rpe_readlane(qy, win), cz = rpe_readlane(qz, win);
         bool pair = false;
         int win2 = 0;
 #ifdef RPE_FPS_PROBE
@@ -442,6 +443,7 @@ __global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__re
         }
         const bool need1 = (needmask >> win) & 1ull, need2 = pair && ((needmask >> win2) & 1ull);  // wave-uniform
         if (need1 || need2) {
+            if (!PAIRED) cx = rpe_readlane(qx, win), cy = rpe_readlane(qy, win), cz = rpe_readlane(qz, win);  // (only waves that recompute need them)
             // (one of the two may not reach this wave's box: its update would change nothing, so its sample is replaced by the other)
             const float ax = need1 ? cx : c2x, ay = need1 ? cy : c2y, az = need1 ? cz : c2z;
             const f32x2 cx2 = {ax, ax}, cy2 = {ay, ay}, cz2 = {az, az};
