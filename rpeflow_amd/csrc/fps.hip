@@ -213,6 +213,198 @@ __device__ unsigned long long g_fps_stats[4];
 // reduction that picks the winner is in flight; the winner's lane then selects its bit.  A skipping wave's iteration
 // is: read 16 partials, reduce, readlane, republish.  The start needs no special case: every valid point begins at
 // 1e10, all waves tie, the lowest original index (0) wins.
+template <int PPT>
+__global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
+                                                               int N, int S, int64_t *__restrict__ idx) {
+    static_assert(PPT % 2 == 0, "packed path needs an even number of points per thread");
+    constexpr int NP = PPT * kThreads;
+    constexpr int H = PPT / 2;
+    extern __shared__ unsigned long long sortbuf[];
+    __shared__ float red[6][kWaves];
+    __shared__ int part[2][5][kWaves];  // [parity][value bits, index, x, y, z][wave]
+    const int tid = threadIdx.x, lane = rpe_lane();
+    const int wave = rpe_uniform(tid >> 6);
+    const int b = blockIdx.x;
+    xyz += (int64_t)b * sb;
+    idx += (int64_t)b * S;
+
+    // ---- 1. bounding box of the cloud, 2. Morton keys + bitonic sort (as fps_pruned_kernel)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < N; i += kThreads) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = xyz[(int64_t)i * sn + d * sd];
+            lo[d] = fminf(lo[d], v);
+            hi[d] = fmaxf(hi[d], v);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float l = wave_minf(lo[d]), h = wave_max(hi[d]);
+        if (lane == 0) { red[d][wave] = l; red[3 + d][wave] = h; }
+    }
+    __syncthreads();
+    float clo[3], scale[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float l = red[d][0], h = red[3 + d][0];
+        for (int w = 1; w < kWaves; ++w) { l = fminf(l, red[d][w]); h = fmaxf(h, red[3 + d][w]); }
+        clo[d] = l;
+        scale[d] = h > l ? 1023.0f / (h - l) : 0.f;
+    }
+    for (int i = tid; i < NP; i += kThreads) {
+        unsigned long long e = ~0ull;
+        if (i < N) {
+            unsigned key = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float v = xyz[(int64_t)i * sn + d * sd];
+                int q = (int)((v - clo[d]) * scale[d]);
+                q = q < 0 ? 0 : (q > 1023 ? 1023 : q);
+                key |= spread10((unsigned)q) << d;
+            }
+            e = ((unsigned long long)key << 32) | (unsigned)i;
+        }
+        sortbuf[i] = e;
+    }
+    __syncthreads();
+    for (int k = 2; k <= NP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < NP / 2; p += kThreads) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
+                const unsigned long long a = sortbuf[i], c = sortbuf[l];
+                const bool up = (i & k) == 0;
+                if ((a > c) == up) { sortbuf[i] = c; sortbuf[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- 3. this thread's points (row j of wave w = sorted positions w*64*PPT + j*64 + lane) and the wave's box
+    f32x2 px[H], py[H], pz[H];
+    int md[PPT], oi[PPT];
+    float l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const unsigned o = (unsigned)(sortbuf[wave * (RPE_WAVE * PPT) + j * RPE_WAVE + lane] & 0xffffffffu);
+        const bool valid = o != 0xffffffffu;
+        oi[j] = valid ? (int)o : 0x7fffffff;
+        const float *a = xyz + (int64_t)(valid ? o : 0) * sn;
+        const float x = a[0], y = a[sd], z = a[2 * sd];
+        px[j >> 1][j & 1] = x;
+        py[j >> 1][j & 1] = y;
+        pz[j >> 1][j & 1] = z;
+        md[j] = valid ? __float_as_int(1e10f) : -1;
+        if (valid) {
+            l3[0] = fminf(l3[0], x); h3[0] = fmaxf(h3[0], x);
+            l3[1] = fminf(l3[1], y); h3[1] = fmaxf(h3[1], y);
+            l3[2] = fminf(l3[2], z); h3[2] = fmaxf(h3[2], z);
+        }
+    }
+    float blo[3], bhi[3];  // wave-uniform
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        blo[d] = wave_minf(l3[d]);
+        bhi[d] = wave_max(h3[d]);
+    }
+
+    // the wave's candidate (largest running distance, lowest original index holding it, that point's coordinates)
+    int wmax, widx;
+    float wx, wy, wz;
+    auto candidate = [&](int tmax) {
+        wmax = wave_max_i32(tmax);
+        unsigned long long m[PPT];
+        int holders = 0;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            m[j] = __builtin_amdgcn_ballot_w64(md[j] == wmax);
+            holders += (int)__builtin_popcountll(m[j]);
+        }
+        if (holders != 1) {  // several points share the maximum (the start, duplicates): lowest original index among them
+            int v = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) v = md[j] == wmax ? min(v, oi[j]) : v;
+            const int best = wave_min_i32(v);
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) m[j] = __builtin_amdgcn_ballot_w64(md[j] == wmax && oi[j] == best);
+        }
+        widx = 0x7fffffff;
+        wx = wy = wz = 0.f;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if (m[j]) {  // wave-uniform; exactly one j has a (single) bit set unless the wave is empty
+                const int l = (int)__builtin_ctzll(m[j]);
+                widx = __builtin_amdgcn_readlane(oi[j], l);
+                wx = rpe_readlane(px[j >> 1][j & 1], l);
+                wy = rpe_readlane(py[j >> 1][j & 1], l);
+                wz = rpe_readlane(pz[j >> 1][j & 1], l);
+            }
+    };
+    {
+        int t = -1;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) t = max(t, md[j]);
+        candidate(t);
+    }
+    __syncthreads();  // the sort buffer is dead; part[] is a separate array
+
+    for (int s = 0;; ++s) {
+        const int par = s & 1;
+        if (lane == 0) {
+            part[par][0][wave] = wmax;
+            part[par][1][wave] = widx;
+            part[par][2][wave] = __float_as_int(wx);
+            part[par][3][wave] = __float_as_int(wy);
+            part[par][4][wave] = __float_as_int(wz);
+        }
+        __syncthreads();
+        const int l16 = lane & (kWaves - 1);
+        const int pv = part[par][0][l16], pi = part[par][1][l16];
+        const float qx = __int_as_float(part[par][2][l16]), qy = __int_as_float(part[par][3][l16]), qz = __int_as_float(part[par][4][l16]);
+        // lane l: would candidate l, as the next sample, lower any running distance of THIS wave's points?
+        const float ex = fmaxf(fmaxf(blo[0] - qx, qx - bhi[0]), 0.f), ey = fmaxf(fmaxf(blo[1] - qy, qy - bhi[1]), 0.f),
+                    ez = fmaxf(fmaxf(blo[2] - qz, qz - bhi[2]), 0.f);
+        const float lb = ((ex * ex + ey * ey) + ez * ez) * 0.99999f;
+        const unsigned long long needmask = __builtin_amdgcn_ballot_w64(__float_as_int(lb) <= wmax);
+        int bmax;
+        {
+            int r = row_max16_i32(pv);
+            asm volatile("s_nop 1\n\tv_readlane_b32 %0, %1, 15" : "=s"(bmax) : "v"(r));
+        }
+        unsigned long long tied = __builtin_amdgcn_ballot_w64(pv == bmax) & 0xffffull;
+        int win = (int)__builtin_ctzll(tied), cur = __builtin_amdgcn_readlane(pi, win);
+        for (tied &= tied - 1; tied; tied &= tied - 1) {  // two waves tie on the maximum: lowest original index
+            const int l = (int)__builtin_ctzll(tied), c = __builtin_amdgcn_readlane(pi, l);
+            if (c < cur) { cur = c; win = l; }
+        }
+        if (tid == 0) idx[s] = (int64_t)cur;
+        if (s == S - 1) break;
+        if ((needmask >> win) & 1ull) {  // wave-uniform
+            const float cx = rpe_readlane(qx, win), cy = rpe_readlane(qy, win), cz = rpe_readlane(qz, win);
+            const f32x2 cx2 = {cx, cx}, cy2 = {cy, cy}, cz2 = {cz, cz};
+            int t = -1;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
+                const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                f32x2 nd = xx + yy;
+                nd = nd + zz;
+                md[2 * h] = min(md[2 * h], __float_as_int(nd[0]));
+                md[2 * h + 1] = min(md[2 * h + 1], __float_as_int(nd[1]));
+                t = max(t, max(md[2 * h], md[2 * h + 1]));
+            }
+            candidate(t);
+        }
+    }
+}
+
+// ---- fps_paired_kernel: fps_pruned2_kernel emitting two samples per synchronisation round where provable ---------------------------------------
+// One Morton cluster per wave; (a) every wave publishes its candidate's COORDINATES with its
+// partial, so the winner's coordinates are three v_readlane away instead of an LDS lookup, and (b) the skip test is
+// evaluated for all 16 candidates at once -- lane l tests candidate l against this wave's box -- while the DPP
+// reduction that picks the winner is in flight; the winner's lane then selects its bit.  A skipping wave's iteration
+// is: read 16 partials, reduce, readlane, republish.  The start needs no special case: every valid point begins at
+// 1e10, all waves tie, the lowest original index (0) wins.
 //
 // PAIRED (round 3): two samples per barrier round where that is provably what the sequential rule gives.  Every wave also
 // publishes the SECOND-largest running distance among its points (excluding its candidate).  After the barrier all waves see
@@ -223,9 +415,10 @@ __device__ unsigned long long g_fps_stats[4];
 // in its wave -- still holds v2: c2 IS the next sample, whatever else c1's update does.  Both indices are written and every
 // wave applies both updates (each only if the sample can reach its box) in one recompute.  Otherwise the round emits one
 // sample, as before.  The indices are identical by construction; the GPU tests cross-check PAIRED, PRUNED and PLAIN.
-template <int PPT, bool PAIRED>
-__global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
+template <int PPT>
+__global__ __launch_bounds__(kThreads) void fps_paired_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
                                                                int N, int S, int64_t *__restrict__ idx) {
+    constexpr bool PAIRED = true;  // (the one-sample form is fps_pruned2_kernel above, kept verbatim: restructuring it for both cost 3 %)
     static_assert(PPT % 2 == 0, "packed path needs an even number of points per thread");
     constexpr int NP = PPT * kThreads;
     constexpr int H = PPT / 2;
@@ -485,7 +678,7 @@ __global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__re
 template <int PPT, bool PAIRED>
 int launch_fps_pruned2(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, hipStream_t st) {
     const size_t shmem = sizeof(unsigned long long) * (size_t)PPT * kThreads;
-    auto kern = fps_pruned2_kernel<PPT, PAIRED>;
+    auto kern = PAIRED ? fps_paired_kernel<PPT> : fps_pruned2_kernel<PPT>;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return (int)e;
