@@ -74,6 +74,8 @@ def parse():
     p.add_argument("--eval-batches", type=int, default=64, help="batches per rank of the 'eval' leg that the forward workload reports as well (0: skip)")
     p.add_argument("--eval-workers", type=int, default=None, help="loader threads per rank (default: rpeflow_amd.evaluate.default_workers())")
     p.add_argument("--eval-pinned", action="store_true", help="hold the cached synthetic set in pinned memory (no staging pass)")
+    p.add_argument("--eval-distinct", type=int, default=None, help="distinct samples of the evaluation's synthetic set (default: 16 per rank)")
+    p.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)  # tests: all ranks on the visible GPU(s), collective on gloo
     p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
     return p.parse_args()
 
@@ -221,7 +223,7 @@ def cpu_baseline(workload, config="things", timeout_s=420):
                 "sample": f"worker exceeded {timeout_s} s"}
 
 
-def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist, workers=None, pinned=False, backend="nccl"):
+def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist, workers=None, pinned=False, backend="nccl", distinct=None):
     """The sharded evaluation END TO END (rpeflow_amd.evaluate.evaluate, the counterpart of eval_withocc.py:43-135): every
     rank reads its shard of a cached synthetic set (frame pairs r, r + W, ...) through the input pipeline -- loader threads
     into pinned host batches, H2D on a copy stream, the forward replayed from the HIP graph with the next batch's sampling
@@ -232,11 +234,12 @@ def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist,
     from rpeflow_amd.synthetic import SyntheticPairs
     per_rank = 4 * batch_size  # distinct samples a rank cycles through (0.21 GB a batch)
     n = world * n_batches * batch_size
-    data = SyntheticPairs(n, cfg["H"], cfg["W"], NPTS, dsec=cfg["dsec"], distinct=world * per_rank, cache=True, pin=pinned,
+    distinct = world * per_rank if distinct is None else distinct
+    data = SyntheticPairs(n, cfg["H"], cfg["W"], NPTS, dsec=cfg["dsec"], distinct=distinct, cache=True, pin=pinned,
                           first_seed=cfg["first_seed"])
     mine = E.shard_indices(n, rank, world)
     t_gen = data.prepare(indices=mine)
-    warm = SyntheticPairs(world * 3 * batch_size, cfg["H"], cfg["W"], NPTS, dsec=cfg["dsec"], distinct=world * per_rank, first_seed=cfg["first_seed"])
+    warm = SyntheticPairs(world * 3 * batch_size, cfg["H"], cfg["W"], NPTS, dsec=cfg["dsec"], distinct=distinct, first_seed=cfg["first_seed"])
     warm.cache, warm.pin = data.cache, pinned  # same samples: the loader threads, the rings and the graph get their first use untimed
     E.evaluate(model, warm, batch_size, dev, rank, world, forward=forward, workers=workers)
     torch.cuda.synchronize()
@@ -249,7 +252,7 @@ def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist,
     torch.cuda.synchronize()
     dts = [mine_dt]
     if dist is not None:
-        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t = torch.zeros(world, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         t[rank] = mine_dt
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         dts = [float(x) for x in t.tolist()]
@@ -261,9 +264,9 @@ def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist,
         "h2d_GBps_per_rank": round(stats["bytes"] / mine_dt / 1e9, 2), "h2d_MB_per_batch": round(stats["bytes"] / max(1, stats["batches"]) / 1e6, 1),
         "loader": {"threads": stats["workers"], "staging": "none: samples lie in pinned memory" if stats["direct"] else "pinned ring of host batches",
                    "copy": "dedicated HIP stream, one batch ahead of the replay", "copy_stream_probe_ms": stats.get("copy_stream_probe_ms"), "generator_s_untimed": round(t_gen, 2),
-                   "distinct_samples_per_rank": per_rank},
+                   "distinct_samples": distinct},
         "collective": "one SUM all-reduce of float64[12] (%s)" % (backend if dist is not None else "single rank: none"),
-        "metrics": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in metrics.items() if k != "counts"},
+        "metrics": {k: (float("%.12g" % v) if isinstance(v, float) else v) for k, v in metrics.items() if k != "counts"},
         "samples": metrics["counts"]["3d"] / NPTS,
         **({"timeline_ms": stats["timeline_ms"]} if "timeline_ms" in stats else {}), **({"trace": stats["trace"]} if "trace" in stats else {}),
     }
@@ -316,13 +319,13 @@ def main():
     if not on_gpu and args.backend != "gloo":
         raise SystemExit("--workload selftest runs on CPU tensors: use --backend gloo")
     dist = None
-    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if args.share_gpu else local_rank) if on_gpu else torch.device("cpu")
     if on_gpu:
         torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": dev} if on_gpu else {}))
+        dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": dev} if (on_gpu and args.backend == "nccl") else {}))
         assert dist.get_world_size() == args.gpus
 
     def sync():
@@ -352,7 +355,7 @@ def main():
         if marks is not None:
             print("step ms:", [round(a.elapsed_time(b), 2) for a, b in zip(marks[:-1], marks[1:])], file=sys.stderr, flush=True)
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -442,7 +445,7 @@ def main():
         n_eval = args.steps if args.workload == "eval" else args.eval_batches
         if forward is not None and n_eval > 0:
             dt_eval, eval_info = eval_leg(model, forward, dev, cfg, args.batch, n_eval, rank, world, dist, workers=args.eval_workers,
-                                          pinned=args.eval_pinned, backend=args.backend)
+                                          pinned=args.eval_pinned, backend=args.backend, distinct=args.eval_distinct)
             if args.workload == "eval":
                 dt = dt_eval
             else:

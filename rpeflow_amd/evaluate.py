@@ -252,7 +252,12 @@ def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=Non
         mark()
     if world_size > 1:
         import torch.distributed as dist
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # the one collective of the evaluation
+        if acc.is_cuda and dist.get_backend(group) == "gloo":  # (tests on a one-GPU box: the collective through host memory)
+            host = acc.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            acc.copy_(host)
+        else:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # the one collective of the evaluation
     if stats is not None:
         stats.update(pipe.stats, shard=len(mine), workers=pipe.workers)
         from . import loader
