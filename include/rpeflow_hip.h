@@ -165,6 +165,12 @@ int rpe_gather_channel_last(const float *data, int64_t sb, int64_t sn, int64_t s
  * 1 relu, 2 leaky_relu(slope).  Meant for the latency-bound layers (below ~0.5 GFLOP); deterministic.                  */
 int rpe_pointwise_conv(const float *x, int B, int Cin, int64_t P, const float *packed_weight, int Cout, const float *scale,
                        const float *shift, int act, float slope, const float *residual, float *y, rpe_stream_t stream);
+/* The same with a batch stride for x (a channel slice of a wider tensor) and, with weight_batch_stride > 0, ONE PACKED WEIGHT
+ * PER SAMPLE: y[b] = W[b] x[b] (+ ...), W[b] at packed_weight + b * weight_batch_stride -- the channel attention's per-sample
+ * matrix M[b] (rpe_channel_attention_matrix_packed) applied to v[b] with the block's residual in the epilogue.          */
+int rpe_pointwise_conv_strided(const float *x, int64_t x_batch_stride, int B, int Cin, int64_t P, const float *packed_weight,
+                               int64_t weight_batch_stride, int Cout, const float *scale, const float *shift, int act, float slope,
+                               const float *residual, float *y, rpe_stream_t stream);
 /* rpe_im2col: cols [B, C*kh*kw, Ho*Wo] = torch.nn.functional.unfold(x [B,C,H,W], (kh,kw), dilation, padding, stride) for the whole
  * batch in one launch: the input side of the small convolutions that run as one deterministic GEMM instead of MIOpen's
  * atomically accumulating split-K kernels (rpeflow_amd/utils.py, wants_im2col).                                    */
@@ -350,6 +356,11 @@ int64_t rpe_channel_attention_workspace_floats(int B, int heads, int c, int64_t 
 int rpe_channel_attention_matrix(const float *q, const float *k, int64_t batch_stride, const float *temperature,
                                  const float *w_out, int B, int heads, int c, int64_t P, float eps,
                                  float *workspace, float *m_out, rpe_stream_t stream);
+/* The same, with every m_out[b] written in rpe_pointwise_conv's weight-fragment order ([ceil(C/16)][ceil(C/4)][64] floats per
+ *   sample, zero outside): the block then ends with ONE rpe_pointwise_conv_strided launch, out = residual + m[b] v[b].   */
+int rpe_channel_attention_matrix_packed(const float *q, const float *k, int64_t batch_stride, const float *temperature,
+                                        const float *w_out, int B, int heads, int c, int64_t P, float eps,
+                                        float *workspace, float *m_packed, rpe_stream_t stream);
 /* rpe_convex_upsample: RAFT-style convex up-sampling of a 2-D flow (models/utils.py:201-214):
  *   out[b][c][h*s+i][w*s+j] = sum_k softmax_k(mask[b][k*s*s + i*s + j][h][w]) * s * flow[b][c][h + k/3 - 1][w + k%3 - 1]
  *   (zero outside).  flow [B,2,H,W], mask [B,9*s*s,H,W], out [B,2,H*s,W*s]; s in {2,4,8}.                        */

@@ -197,18 +197,33 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(const float *__restri
 }
 
 // M[b][o][h*c + j] = sum_i W_o[o][h*c + i] * attn[b][h][i][j].  grid (B, slices of M's elements), 256 threads;
-// dynamic LDS: attn[b] (C*c floats).
+// dynamic LDS: attn[b] (C*c floats).  PACKED: M[b] is written in rpe_pointwise_conv's weight-fragment order
+// ([ceil(C/16)][ceil(C/4)][64]: entry (ot, kt, 16 k + i) = M[16 ot + i][4 kt + k], zero outside), so that the block's
+// "x + M[b] v[b]" is ONE launch of the 1x1 kernel with the residual in its epilogue instead of a copy + a batched GEMM.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void attn_project_kernel(const float *__restrict__ attn_in, const float *__restrict__ w_out, int heads,
                                                            int c, float *__restrict__ m_out) {
     extern __shared__ float attn[];
     const int C = heads * c, b = blockIdx.x;
     for (int o = threadIdx.x; o < C * c; o += 256) attn[o] = attn_in[(int64_t)b * C * c + o];
     __syncthreads();
-    float *mb = m_out + (int64_t)b * C * C;
-    const int per = (C * C + gridDim.y - 1) / gridDim.y;
-    const int e_end = min(C * C, (int)(blockIdx.y + 1) * per);
+    const int kt_n = (C + 3) / 4, total = PACKED ? ((C + 15) / 16) * kt_n * 64 : C * C;
+    float *mb = m_out + (int64_t)b * total;
+    const int per = (total + gridDim.y - 1) / gridDim.y;
+    const int e_end = min(total, (int)(blockIdx.y + 1) * per);
     for (int e = blockIdx.y * per + threadIdx.x; e < e_end; e += 256) {
-        const int o = e / C, col = e - o * C, h = col / c, j = col - h * c;
+        int o, col;
+        if (PACKED) {
+            const int i = e & 15, k = (e >> 4) & 3, piece = e >> 6, kt = piece % kt_n, ot = piece / kt_n;
+            o = 16 * ot + i, col = 4 * kt + k;
+            if (o >= C || col >= C) {
+                mb[e] = 0.f;
+                continue;
+            }
+        } else {
+            o = e / C, col = e - o * C;
+        }
+        const int h = col / c, j = col - h * c;
         const float *w = w_out + (int64_t)o * C + h * c;
         const float *a = attn + (h * c) * c + j;
         float s0 = 0.f, s1 = 0.f;
@@ -238,9 +253,9 @@ RPE_API int64_t rpe_channel_attention_workspace_floats(int B, int heads, int c, 
     return (int64_t)B * attn_chunks(P > 0 ? P : 1) * ((int64_t)heads * c * c + 2 * (int64_t)heads * c) + (int64_t)B * heads * c * c;
 }
 
-RPE_API int rpe_channel_attention_matrix(const float *q, const float *k, int64_t batch_stride, const float *temperature,
-                                         const float *w_out, int B, int heads, int c, int64_t P, float eps, float *workspace,
-                                         float *m_out, rpe_stream_t stream) {
+namespace {
+int attention_matrix(const float *q, const float *k, int64_t batch_stride, const float *temperature, const float *w_out, int B, int heads, int c,
+                     int64_t P, float eps, float *workspace, float *m_out, bool packed, rpe_stream_t stream) {
     if (!q || !k || !temperature || !w_out || !workspace || !m_out || B < 0 || heads < 1 || c < 1 || P < 1) return RPE_EINVAL;
     if (B == 0) return 0;
     if (c > 96 || heads > 65535 || B > 65535) return RPE_EUNSUPPORTED;
@@ -263,6 +278,20 @@ RPE_API int rpe_channel_attention_matrix(const float *q, const float *k, int64_t
     if (rc) return rc;
     float *attn = npart + (int64_t)B * S * 2 * C;
     hipLaunchKernelGGL(attn_softmax_kernel, dim3((B * C + 3) / 4), dim3(256), 0, st, gpart, npart, S, temperature, B, heads, c, eps, attn);
-    hipLaunchKernelGGL(attn_project_kernel, dim3(B, C >= 64 ? 16 : 4), dim3(256), (size_t)C * c * sizeof(float), st, attn, w_out, heads, c, m_out);
+    if (packed) hipLaunchKernelGGL(attn_project_kernel<true>, dim3(B, C >= 64 ? 16 : 4), dim3(256), (size_t)C * c * sizeof(float), st, attn, w_out, heads, c, m_out);
+    else hipLaunchKernelGGL(attn_project_kernel<false>, dim3(B, C >= 64 ? 16 : 4), dim3(256), (size_t)C * c * sizeof(float), st, attn, w_out, heads, c, m_out);
     return rpe_launch_status();
+}
+}  // namespace
+
+RPE_API int rpe_channel_attention_matrix(const float *q, const float *k, int64_t batch_stride, const float *temperature,
+                                         const float *w_out, int B, int heads, int c, int64_t P, float eps, float *workspace,
+                                         float *m_out, rpe_stream_t stream) {
+    return attention_matrix(q, k, batch_stride, temperature, w_out, B, heads, c, P, eps, workspace, m_out, false, stream);
+}
+
+RPE_API int rpe_channel_attention_matrix_packed(const float *q, const float *k, int64_t batch_stride, const float *temperature,
+                                                const float *w_out, int B, int heads, int c, int64_t P, float eps, float *workspace,
+                                                float *m_packed, rpe_stream_t stream) {
+    return attention_matrix(q, k, batch_stride, temperature, w_out, B, heads, c, P, eps, workspace, m_packed, true, stream);
 }

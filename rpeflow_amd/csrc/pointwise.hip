@@ -28,7 +28,7 @@ struct PwArgs {
     const float *res;     // [B][Cout][P] or NULL
     float *y;             // [B][Cout][P]
     int Cin, Cout, ktiles, n_otiles, act;
-    int64_t P;
+    int64_t P, x_bstride, w_bstride;  // floats between samples of x; between per-sample weights (0: one weight for all)
     float slope;
 };
 
@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(PwArgs a) {
     if (ot0 >= a.n_otiles) return;
     const int b = blockIdx.z;
     const int64_t P = a.P, p0 = (int64_t)blockIdx.x * 64 + 4 * j;
-    const float *xb = a.x + (int64_t)b * a.Cin * P;
+    const float *xb = a.x + (int64_t)b * a.x_bstride;
+    const float *wpk = a.wpk + (int64_t)b * a.w_bstride;
     pw_f32x4 acc[OT][4];
 #pragma unroll
     for (int o = 0; o < OT; ++o)
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(PwArgs a) {
             }
 #pragma unroll
             for (int o = 0; o < OT; ++o)
-                av[u][o] = (kt < a.ktiles && ot0 + o < a.n_otiles) ? a.wpk[((int64_t)(ot0 + o) * a.ktiles + kt) * 64 + lane] : 0.f;
+                av[u][o] = (kt < a.ktiles && ot0 + o < a.n_otiles) ? wpk[((int64_t)(ot0 + o) * a.ktiles + kt) * 64 + lane] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -119,17 +120,25 @@ int launch_pw(const PwArgs &a, int B, bool vec, hipStream_t st) {
 
 }  // namespace
 
-RPE_API int rpe_pointwise_conv(const float *x, int B, int Cin, int64_t P, const float *packed_weight, int Cout, const float *scale,
-                               const float *shift, int act, float slope, const float *residual, float *y, rpe_stream_t stream) {
+RPE_API int rpe_pointwise_conv_strided(const float *x, int64_t x_batch_stride, int B, int Cin, int64_t P, const float *packed_weight,
+                                       int64_t weight_batch_stride, int Cout, const float *scale, const float *shift, int act, float slope,
+                                       const float *residual, float *y, rpe_stream_t stream) {
     if (!x || !packed_weight || !y || B < 0 || Cin < 1 || Cout < 1 || P < 0 || act < 0 || act > 2) return RPE_EINVAL;
+    if (x_batch_stride < (int64_t)Cin * P || weight_batch_stride < 0) return RPE_EINVAL;
     if (B == 0 || P == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
-    PwArgs a{x, packed_weight, scale, shift, residual, y, Cin, Cout, (Cin + 3) / 4, (Cout + 15) / 16, act, P, slope};
-    const bool vec = P % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
+    PwArgs a{x, packed_weight, scale, shift, residual, y, Cin, Cout, (Cin + 3) / 4, (Cout + 15) / 16, act, P, x_batch_stride, weight_batch_stride, slope};
+    const bool vec = P % 4 == 0 && x_batch_stride % 4 == 0 &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
     // output tiles per wave: enough workgroups to cover the chip on the small maps, fewer re-reads of x on the wider layers
     const int64_t wgs1 = ((P + 63) / 64) * ((a.n_otiles + 3) / 4) * B;
     if (a.n_otiles >= 16 && wgs1 >= 4 * 1024) return launch_pw<4>(a, B, vec, st);
     if (a.n_otiles >= 8 && wgs1 >= 2 * 1024) return launch_pw<2>(a, B, vec, st);
     return launch_pw<1>(a, B, vec, st);
+}
+
+RPE_API int rpe_pointwise_conv(const float *x, int B, int Cin, int64_t P, const float *packed_weight, int Cout, const float *scale,
+                               const float *shift, int act, float slope, const float *residual, float *y, rpe_stream_t stream) {
+    return rpe_pointwise_conv_strided(x, (int64_t)Cin * P, B, Cin, P, packed_weight, 0, Cout, scale, shift, act, slope, residual, y, stream);
 }

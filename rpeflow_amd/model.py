@@ -95,16 +95,12 @@ class _MutualAttention(nn.Module):
         if x.is_cuda and shape[1] // self.num_heads <= 96:
             # depth-wise conv reading x | y | y in place of the concatenation; gram + softmax + project_out folded into
             # one C x C matrix per sample (csrc/attention.hip); one batched GEMM applies it to v and adds the residual
-            from .restormer_ops import channel_attention_matrix, dwconv3
+            from .restormer_ops import attention_apply, channel_attention_matrix, dwconv3
             qkv = dwconv3([x, y, y], self.qkv_dwconv.weight, self.qkv_dwconv.bias)
-            m = channel_attention_matrix(qkv, self.num_heads, self.temperature, self.project_out.weight)
-            v = qkv.reshape(shape[0], 3 * shape[1], -1)[:, 2 * shape[1]:]
-            if self.project_out.bias is not None:
-                bias = self.project_out.bias.view(1, -1, 1)
-                residual = bias.expand(shape[0], shape[1], v.shape[2]) if residual is None else residual.reshape(shape[0], shape[1], -1) + bias
-            if residual is None:
-                return torch.bmm(m, v).reshape(shape)
-            return torch.baddbmm(residual.reshape(shape[0], shape[1], -1), m, v).reshape(shape)
+            # the per-sample matrix in the 1x1 kernel's weight order: "residual + M[b] v[b] (+ bias)" is then ONE launch reading v
+            # in place (was: a copy of the residual + a batched GEMM)
+            m = channel_attention_matrix(qkv, self.num_heads, self.temperature, self.project_out.weight, packed=True)
+            return attention_apply(qkv, m, residual=residual, bias=self.project_out.bias)
         out = self._forward_plain(x, y)
         return out if residual is None else residual + out
 
@@ -270,10 +266,11 @@ class ContextNetwork2D(nn.Module):
             for a, b, d in zip(n_channels[:-1], n_channels[1:], dilations))
         self.conv_last = nn.Conv2d(n_channels[-1], 2, kernel_size=3, stride=1, padding=1)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """(features, conv_last(features) (+ residual: the flow the delta is added to, RPEFlow_core.py:419))."""
         for conv in self.convs:
             x = conv(x)
-        return x, conv_module(self.conv_last, x)
+        return x, conv_module(self.conv_last, x, residual=residual)
 
 
 # ------------------------------------------------------------------ Bi-CLFM fusers (RPEFlow_core.py:14-162)
@@ -733,9 +730,8 @@ class RPEFlow_core(nn.Module):
             side_in = [flow_feat_2d_raw] + (_tensors(nxt) + [xyzs1[level - 1], xyzs2[level - 1]] if nxt is not None else [xyzs1[0]])
             out_s1 = br.fork(chain_3d, side_in)
             flow_feat_2d = self.estimator_feat_fuser_2d(xy1, flow_feat_2d_raw, flow_feat_3d_raw, nn_proj1)
-            flow_2d = last_flow_2d + conv_module(self.conv_last_2d, flow_feat_2d)
-            flow_feat_2d, flow_delta_2d = self.context_network_2d(torch.cat([flow_feat_2d, flow_2d], dim=1))
-            flow_2d = flow_delta_2d + flow_2d
+            flow_2d = conv_module(self.conv_last_2d, flow_feat_2d, residual=last_flow_2d)
+            flow_feat_2d, flow_2d = self.context_network_2d(torch.cat([flow_feat_2d, flow_2d], dim=1), residual=flow_2d)
             _stamp("main L%d stage3 done" % level)
             flows_2d.append(flow_2d)
             flow_feats_2d.append(flow_feat_2d)

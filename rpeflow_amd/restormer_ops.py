@@ -97,9 +97,10 @@ def channel_affine_add_act_(y, scale, shift, z, zscale, act, slope=0.1):
     return y
 
 
-def channel_attention_matrix(qkv, heads, temperature, w_out, eps=1e-12):
+def channel_attention_matrix(qkv, heads, temperature, w_out, eps=1e-12, packed=False):
     """qkv [B,3C,...] contiguous (q | k | v along channels).  Returns M [B,C,C] with
-    project_out(softmax(normalize(q) normalize(k)^T * temperature) v) == M @ v  (restormer_arch.py:184-203)."""
+    project_out(softmax(normalize(q) normalize(k)^T * temperature) v) == M @ v  (restormer_arch.py:184-203).
+    ``packed``: M[b] in rpe_pointwise_conv's weight-fragment order [B, ceil(C/16), ceil(C/4), 64] (for attention_apply)."""
     _lib.require_gpu(qkv, temperature, w_out, op="channel_attention_matrix")
     assert qkv.is_contiguous() and qkv.dtype == torch.float32 and qkv.shape[1] % (3 * heads) == 0
     B, C = qkv.shape[0], qkv.shape[1] // 3
@@ -110,13 +111,30 @@ def channel_attention_matrix(qkv, heads, temperature, w_out, eps=1e-12):
     assert t.numel() == heads
     L = _lib.lib()
     ws = torch.empty(L.rpe_channel_attention_workspace_floats(B, heads, c, P), dtype=torch.float32, device=qkv.device)
-    m = torch.empty(B, C, C, dtype=torch.float32, device=qkv.device)
+    m = torch.empty((B, (C + 15) // 16, (C + 3) // 4, 64) if packed else (B, C, C), dtype=torch.float32, device=qkv.device)
     q_ptr = qkv.data_ptr()
+    fn = L.rpe_channel_attention_matrix_packed if packed else L.rpe_channel_attention_matrix
     with torch.cuda.device(qkv.device):
-        rc = L.rpe_channel_attention_matrix(ctypes.c_void_p(q_ptr), ctypes.c_void_p(q_ptr + 4 * C * P), 3 * C * P, _ptr(t), _ptr(w),
-                                            B, heads, c, P, float(eps), _ptr(ws), _ptr(m), _lib.stream_of(qkv))
+        rc = fn(ctypes.c_void_p(q_ptr), ctypes.c_void_p(q_ptr + 4 * C * P), 3 * C * P, _ptr(t), _ptr(w),
+                B, heads, c, P, float(eps), _ptr(ws), _ptr(m), _lib.stream_of(qkv))
     _lib.check(rc, "channel_attention_matrix")
     return m
+
+
+def attention_apply(qkv, m_packed, residual=None, bias=None):
+    """out[b] = m[b] @ v[b] (+ bias) (+ residual): v = the last third of qkv's channels (read in place, batch stride 3 C P), m
+    from channel_attention_matrix(..., packed=True); one launch of the 1x1 kernel with per-sample weights."""
+    _lib.require_gpu(qkv, m_packed, op="attention_apply")
+    B, C = qkv.shape[0], qkv.shape[1] // 3
+    P = qkv.numel() // (B * 3 * C)
+    res = None if residual is None else (residual if (residual.dtype == torch.float32 and residual.is_contiguous()) else residual.float().contiguous())
+    out = torch.empty((B, C) + tuple(qkv.shape[2:]), dtype=torch.float32, device=qkv.device)
+    with torch.cuda.device(qkv.device):
+        rc = _lib.lib().rpe_pointwise_conv_strided(ctypes.c_void_p(qkv.data_ptr() + 4 * 2 * C * P), 3 * C * P, B, C, P, _ptr(m_packed),
+                                                   m_packed[0].numel(), C, _NULL, _ptr(bias.float().contiguous()) if bias is not None else _NULL,
+                                                   0, 0.1, _ptr(res) if res is not None else _NULL, _ptr(out), _lib.stream_of(qkv))
+    _lib.check(rc, "attention_apply")
+    return out
 
 
 def convex_upsample(flow, mask, scale_factor):

@@ -256,6 +256,13 @@ def conv_module(conv, x, residual=None, inplace=False):
     if x.is_cuda and _inference_only(x, *conv.parameters()):
         if residual is not None and is_pointwise(conv):
             return pointwise_conv(x, conv.weight, conv.bias, 1, residual=residual, inplace=inplace)
+        if residual is not None and residual.shape[1] == conv.out_channels and residual.dtype == torch.float32:
+            # bias and residual in ONE pass over the raw convolution output (was: the library's bias kernel + an add)
+            from .restormer_ops import channel_affine_add_act_
+            y = conv_no_bias_or(conv, x, False).contiguous()
+            if y.shape == residual.shape:
+                return channel_affine_add_act_(y, None, conv.bias, residual.contiguous(), None, None)
+            return residual + (y if conv.bias is None else y + conv.bias.view((1, -1) + (1,) * (y.dim() - 2)))
         y = conv_no_bias_or(conv, x, True)
     else:
         y = conv(x)
