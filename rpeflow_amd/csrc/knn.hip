@@ -728,33 +728,47 @@ struct MfmaBlockLds {
     unsigned long long list[kWavesPerBlock][kLaneList][RPE_WAVE];  // entry s of lane l at [s][l] (lane-interleaved: no bank conflicts): (index << 32) | distance bits
 };
 
-// one query, the insertion sweep with plain loads (the fallback of the matrix kernel; not a fast path)
+// one query, the insertion sweep with plain loads: the fallback of the matrix kernel when a lane list fills up.  Rare (a lane
+// holds ~5 entries on average, 15 fit: a few queries per launch) but the wave that meets one runs on alone after every other
+// wave has finished, so its latency is the launch's: eight tiles a round (24 loads in flight, one "anything below the
+// bound?" test) instead of one tile per load-wait-compare round: 128 rounds of ~0.16 us for a cloud of 8192 were +20 us on
+// a 117 us launch (tools/exp/knn_k_cliff.py).
 template <int D>
 __device__ void serial_select(const float *__restrict__ inp, int64_t in_sn, int64_t in_sd, int M, const float (&qm2)[3], float qq,
                               int kk, int lane, float &Ld, int &Li) {
     Ld = INFINITY;
     Li = 0;
     float tau = INFINITY;
-    for (int base = 0; base < M; base += RPE_WAVE) {
-        const bool valid = base + lane < M;
-        float p[3] = {0.f, 0.f, 0.f};
-        if (valid) load_point<D>(inp, in_sn, in_sd, base + lane, p);
-        const float pp = valid ? rpe_sqnorm<D>(p) : INFINITY;
-        const float d = rpe_pair_dist<D>(qm2, qq, p, pp);
-        unsigned long long m = __ballot(d < tau);
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const float nd = rpe_readlane(d, l);
-            if (nd < tau) {
-                const int ni = base + l;
-                const float upd = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Ld), __float_as_int(Ld), 0x138, 0xf, 0xf, false));
-                const int upi = __builtin_amdgcn_update_dpp(Li, Li, 0x138, 0xf, 0xf, false);
-                const bool gt = nd < Ld;
-                const bool gtp = (lane > 0) && (nd < upd);
-                Ld = gt ? (gtp ? upd : nd) : Ld;
-                Li = gt ? (gtp ? upi : ni) : Li;
-                tau = rpe_readlane(Ld, kk - 1);
+    constexpr int kTiles = 8;
+    for (int base0 = 0; base0 < M; base0 += kTiles * RPE_WAVE) {
+        float pt[kTiles][3], d[kTiles];
+#pragma unroll
+        for (int u = 0; u < kTiles; ++u) load_point<D>(inp, in_sn, in_sd, min(base0 + u * RPE_WAVE + lane, M - 1), pt[u]);
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int u = 0; u < kTiles; ++u) {
+            const float pp = base0 + u * RPE_WAVE + lane < M ? rpe_sqnorm<D>(pt[u]) : INFINITY;
+            d[u] = rpe_pair_dist<D>(qm2, qq, pt[u], pp);
+            any |= __ballot(d[u] < tau);  // (tau only falls: a superset of what passes below)
+        }
+        if (!any) continue;
+#pragma unroll
+        for (int u = 0; u < kTiles; ++u) {
+            unsigned long long m = __ballot(d[u] < tau);
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const float nd = rpe_readlane(d[u], l);
+                if (nd < tau) {
+                    const int ni = base0 + u * RPE_WAVE + l;
+                    const float upd = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(Ld), __float_as_int(Ld), 0x138, 0xf, 0xf, false));
+                    const int upi = __builtin_amdgcn_update_dpp(Li, Li, 0x138, 0xf, 0xf, false);
+                    const bool gt = nd < Ld;
+                    const bool gtp = (lane > 0) && (nd < upd);
+                    Ld = gt ? (gtp ? upd : nd) : Ld;
+                    Li = gt ? (gtp ? upi : ni) : Li;
+                    tau = rpe_readlane(Ld, kk - 1);
+                }
             }
         }
     }
