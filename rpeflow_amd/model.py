@@ -11,6 +11,8 @@ Inference only.  The mutual-information heads (models/mutual_info.py) exist as p
 holders so state dicts match, but are not evaluated: their output is a training loss that
 never reaches the flows (RPEFlow_core.py:33-35, RPEFlow.py:95-99).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -564,8 +566,59 @@ class RPEFlow_core(nn.Module):
     def encode_event(self, event_voxel):
         return self.efeature_pyramid_2d(event_voxel)
 
+    def hoist(self, xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d, camera_info, pre_stream=None):
+        """Stage 1 of every level, hoisted out of the coarse-to-fine recurrence: projections, neighbour searches, pyramid
+        fusers, aligners, Correlation3D's feature halves -- functions of the encoders' outputs only.  Issued on
+        ``pre_stream`` when given (after everything queued on the current stream so far); decode() waits per level.
+        ``efeats_2d`` None: the event pyramid is not there yet (forward() issues this call between the image and the event
+        pyramid); decode() then aligns the event features itself."""
+        sensor_h, sensor_w = camera_info["sensor_h"], camera_info["sensor_w"]
+        k = self.cfgs3d.k
+        k_nearest_neighbor = self.ops.k_nearest_neighbor
+        camera_both = {key: (torch.cat([v, v]) if torch.is_tensor(v) else v) for key, v in camera_info.items()}
+        top = len(xyzs1) - 1
+        batch_size = feats_2d_both[1].shape[0] // 2
+
+        def fuse_level(level):
+            image_h, image_w = feats_2d_both[level].shape[2:]
+            xy_both = project_pc2image(torch.cat([xyzs1[level], xyzs2[level]], dim=0), camera_both)
+            xy_both *= _pair_scale((image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1), xy_both)
+            grid = mesh_grid(2 * batch_size, image_h, image_w, xy_both.device).reshape(2 * batch_size, 2, -1)
+            nn_proj_both = k_nearest_neighbor(xy_both, grid, k=1)
+            knn_1in1 = k_nearest_neighbor(xyzs1[level], xyzs1[level], k=k)
+            # (same map, same points, same stream: the 3-D fuser's samples serve the 2-D fuser's per-point rows)
+            share = "sampled_2d" in self._project_feat_params
+            fused_3d, sampled = self.pyramid_feat_fusers_3d[level](xy_both, feats_2d_both[level], feats_3d_both[level], return_sampled=True)
+            fused_2d = self.pyramid_feat_fusers_2d[level](xy_both, feats_2d_both[level], feats_3d_both[level], nn_proj_both,
+                                                          sampled_2d=sampled if share else None)
+            # the aligners of the estimator inputs (:385-390) read the fused frame-1 features and the event features only
+            aligned = (self.feature_aligners_2d[level](fused_2d[:batch_size]),
+                       self.efeature_aligners_2d[level](efeats_2d[level]) if efeats_2d is not None else None,
+                       self.feature_aligners_3d[level](fused_3d[:batch_size]))
+            # the feat1 / feat2 halves of Correlation3D's first layer need the fused features only (pwc3d_core.Correlation3D)
+            corr = self.correlations_3d[level]
+            corr_proj = corr.project_stacked(fused_3d) if hasattr(corr, "project_stacked") else None
+            return xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d, *aligned, corr_proj
+
+        fused, ready = {}, {}
+        if pre_stream is not None:
+            main = torch.cuda.current_stream(pre_stream.device)
+            pre_stream.wait_stream(main)
+            for t in list(xyzs1) + list(xyzs2) + list(feats_2d_both) + list(feats_3d_both) + list(efeats_2d or []):
+                t.record_stream(pre_stream)
+            with torch.cuda.stream(pre_stream):
+                for level in range(top, 0, -1):
+                    fused[level] = fuse_level(level)
+                    _stamp("pre L%d done" % level)
+                    ready[level] = torch.cuda.Event()
+                    ready[level].record(pre_stream)
+        else:
+            for level in range(top, 0, -1):
+                fused[level] = fuse_level(level)
+        return fused, ready
+
     def decode(self, xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d, camera_info, side_stream=None, pre_stream=None,
-               all_levels=False):
+               all_levels=False, hoisted_early=None):
         """RPEFlow_core.py:302-432 without the MI loss bookkeeping.
 
         ``feats_2d_both`` / ``feats_3d_both``: pyramids of frame 1 and frame 2 stacked on the batch axis ([2B,...], frame 1
@@ -586,42 +639,9 @@ class RPEFlow_core(nn.Module):
         top = len(xyzs1) - 1
         batch_size = feats_2d_both[1].shape[0] // 2
 
-        # ---- stage 1, hoisted out of the recurrence: projections, neighbour searches, pyramid fusers of every level
-        def fuse_level(level):
-            image_h, image_w = feats_2d_both[level].shape[2:]
-            xy_both = project_pc2image(torch.cat([xyzs1[level], xyzs2[level]], dim=0), camera_both)
-            xy_both *= _pair_scale((image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1), xy_both)
-            grid = mesh_grid(2 * batch_size, image_h, image_w, xy_both.device).reshape(2 * batch_size, 2, -1)
-            nn_proj_both = k_nearest_neighbor(xy_both, grid, k=1)
-            knn_1in1 = k_nearest_neighbor(xyzs1[level], xyzs1[level], k=k)
-            # (same map, same points, same stream: the 3-D fuser's samples serve the 2-D fuser's per-point rows)
-            share = "sampled_2d" in self._project_feat_params
-            fused_3d, sampled = self.pyramid_feat_fusers_3d[level](xy_both, feats_2d_both[level], feats_3d_both[level], return_sampled=True)
-            fused_2d = self.pyramid_feat_fusers_2d[level](xy_both, feats_2d_both[level], feats_3d_both[level], nn_proj_both,
-                                                          sampled_2d=sampled if share else None)
-            # the aligners of the estimator inputs (:385-390) read the fused frame-1 features and the event features only
-            aligned = (self.feature_aligners_2d[level](fused_2d[:batch_size]), self.efeature_aligners_2d[level](efeats_2d[level]),
-                       self.feature_aligners_3d[level](fused_3d[:batch_size]))
-            # the feat1 / feat2 halves of Correlation3D's first layer need the fused features only (pwc3d_core.Correlation3D)
-            corr = self.correlations_3d[level]
-            corr_proj = corr.project_stacked(fused_3d) if hasattr(corr, "project_stacked") else None
-            return xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d, *aligned, corr_proj
-
-        fused, ready = {}, {}
-        if pre_stream is not None:
-            main = torch.cuda.current_stream(pre_stream.device)
-            pre_stream.wait_stream(main)
-            for t in list(xyzs1) + list(xyzs2) + list(feats_2d_both) + list(feats_3d_both) + list(efeats_2d):
-                t.record_stream(pre_stream)
-            with torch.cuda.stream(pre_stream):
-                for level in range(top, 0, -1):
-                    fused[level] = fuse_level(level)
-                    _stamp("pre L%d done" % level)
-                    ready[level] = torch.cuda.Event()
-                    ready[level].record(pre_stream)
-        else:
-            for level in range(top, 0, -1):
-                fused[level] = fuse_level(level)
+        # ---- stage 1, hoisted out of the recurrence (hoist() above): issued here unless forward() did it earlier
+        fused, ready = hoisted_early if hoisted_early is not None else self.hoist(xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d, camera_info,
+                                                                      pre_stream)
 
         zeros = lambda *s: torch.zeros(s, dtype=feats_2d_both[1].dtype, device=feats_2d_both[1].device)
         main_stream = torch.cuda.current_stream(pre_stream.device) if pre_stream is not None else None
@@ -669,6 +689,8 @@ class RPEFlow_core(nn.Module):
             image_h, image_w = feats_2d_both[level].shape[2:]
             _stamp("main L%d start" % level)
             xy_both, nn_proj_both, knn_1in1, fused_2d, fused_3d, aligned_2d, aligned_e2d, aligned_3d, _ = hoisted
+            if aligned_e2d is None:  # (hoisted before the event pyramid existed)
+                aligned_e2d = self.efeature_aligners_2d[level](efeat_2d)
             xy1, nn_proj1 = xy_both[:batch_size], nn_proj_both[:batch_size]
             feat1_2d, feat2_2d_fused = fused_2d[:batch_size], fused_2d[batch_size:]
 
@@ -767,6 +789,7 @@ class RPEFlow(nn.Module):
         self.cfgs = cfgs or things_config()
         self.ids_on_host = ids_on_host
         self.overlap_streams = True
+        self.early_hoist = os.environ.get("RPE_EARLY_HOIST", "1") != "0"  # hoisted stage beside the event pyramid (forward())
         self.keep_levels = False  # also return every pyramid level's up-sampled flows, as decode() hands them over (tests)
         self._streams = {}
         self.pwc_fusion_core = RPEFlow_core(self.cfgs.pwc2d, self.cfgs.pwc3d, self.cfgs.get("attention"), ops=ops)
@@ -865,27 +888,43 @@ class RPEFlow(nn.Module):
         n_samples = self.N_SAMPLES
         _stamp("main start")
 
+        camera = paral if self.cfgs.ids.enabled else persp
+        early = None
         if pc1.is_cuda and self.overlap_streams:
             # The 3-D encoder (FPS: 4096 dependent samples on 2B workgroups, then small PointConv kernels) and
             # the 2-D pyramids (large convolutions) share no data until decode(): run them on two HIP
             # streams.  FPS alone keeps 2B of 256 CUs busy for ~3.5 ms; here it hides behind the convolutions.
             main = torch.cuda.current_stream(pc1.device)
             side = self._side_stream(pc1.device)
+            pre = self._side_stream(pc1.device, "pre")
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 xyzs1, xyzs2, _, _ = self._pyramid(pc1, pc2, n_samples, fps_order)
                 both = [torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)]
                 _stamp("side fps done")
+                if self.early_hoist:
+                    feats_3d_both = core.feature_pyramid_3d(both)
+                    _stamp("side encode3d done")
+                    encoded_3d = torch.cuda.Event()
+                    encoded_3d.record(side)
             feats_2d_both = core.feature_pyramid_2d(image_both)
             _stamp("main image pyramid done")
+            if self.early_hoist:
+                # The hoisted stage of every level reads the image and point pyramids only: it starts here, beside the event
+                # pyramid, instead of behind it (the coarsest level's set was what the first decoder level waited for).
+                main.wait_event(encoded_3d)
+                for t in list(xyzs1) + list(xyzs2) + list(feats_3d_both):
+                    t.record_stream(main)  # allocated on the side stream, consumed on the main one
+                early = core.hoist(xyzs1, xyzs2, feats_2d_both, feats_3d_both, None, camera, pre_stream=pre)
             efeats_2d = core.encode_event(event_voxel)
             _stamp("main event pyramid done")
-            with torch.cuda.stream(side):
-                feats_3d_both = core.feature_pyramid_3d(both)
-                _stamp("side encode3d done")
-            main.wait_stream(side)
-            for t in list(xyzs1) + list(xyzs2) + list(feats_3d_both):
-                t.record_stream(main)  # allocated on the side stream, consumed on the main one
+            if not self.early_hoist:
+                with torch.cuda.stream(side):
+                    feats_3d_both = core.feature_pyramid_3d(both)
+                    _stamp("side encode3d done")
+                main.wait_stream(side)
+                for t in list(xyzs1) + list(xyzs2) + list(feats_3d_both):
+                    t.record_stream(main)  # allocated on the side stream, consumed on the main one
         else:
             xyzs1, xyzs2, _, _ = self._pyramid(pc1, pc2, n_samples, fps_order)
             feats_3d_both = core.feature_pyramid_3d([torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)])
@@ -893,9 +932,8 @@ class RPEFlow(nn.Module):
             efeats_2d = core.encode_event(event_voxel)
         side = self._side_stream(pc1.device) if (pc1.is_cuda and self.overlap_streams) else None
         pre = self._side_stream(pc1.device, "pre") if side is not None else None
-        flows_2d, flows_3d = core.decode(xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d,
-                                         paral if self.cfgs.ids.enabled else persp, side_stream=side, pre_stream=pre,
-                                         all_levels=self.keep_levels)
+        flows_2d, flows_3d = core.decode(xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d, camera, side_stream=side, pre_stream=pre,
+                                         all_levels=self.keep_levels, hoisted_early=early)
         _stamp("main decode done")
         flow_3d = flows_3d[0]
         if self.cfgs.ids.enabled:

@@ -7,9 +7,12 @@ import os
 
 # Replaying a captured multi-stream HIP graph, the runtime spreads the graph's branches over this many hardware queues
 # (its default: 4).  The forward's graph has four branches -- 2-D chain, 3-D chain, hoisted per-level work, the next
-# batch's sampling -- of ~1400 small kernels; with three queues the replay is 3 % faster (216 vs 210 frame-pairs/s,
-# five A/B runs; two queues: 179).  The variable is read once, when the HIP runtime initialises.
-GRAPH_QUEUES = "3"
+# batch's sampling -- of ~900 small kernels.  Rounds 1-2 ran it on three queues (216 vs 210 frame-pairs/s then; two: 179):
+# fewer queues, cheaper dispatch of the small kernels.  Since round 3 the hoisted work starts beside the event pyramid and the
+# first decoder level is ready before the next batch's sampling (3.2 ms) ends; on three queues the main chain then sits
+# behind that sampling kernel in a shared queue until it finishes, on four it does not: 16.34 vs 16.58 ms per batch (median
+# of 40, two runs each, tools/ab_step.sh).  The variable is read once, when the HIP runtime initialises.
+GRAPH_QUEUES = "4"
 
 
 def usable_cores():
@@ -27,11 +30,10 @@ def usable_cores():
 
 def configure():
     """Idempotent; an explicit setting in the environment wins.  Returns what is in effect (bench.py prints it in ``config``).
-    The MIOpen convolution solvers are left at the library's defaults everywhere -- tests, bench and evaluation alike.
-    MIOpen picks some of this model's convolutions by timing near-equal candidates when a process first meets a shape,
-    so on a fresh machine two solver sets occur: the benched configuration is then 8e-6 (most runs) or 7.5e-5 (EPE2D) away
-    from the reference's EPEs, both inside the 1e-4 bound (tests/test_model.py; seeding the user find-db with one run's
-    search results was tried and does not remove the second set)."""
+    The MIOpen convolution solvers are left at the library's defaults everywhere -- tests, bench and evaluation alike.  The
+    convolutions MIOpen would run through atomically accumulating split-K kernels (the source of the run-to-run differences of
+    rounds 1-2) go through the deterministic GEMM paths of rpeflow_amd/utils.py instead, so the forward is bit-reproducible
+    whatever MIOpen's timing-based search picks for the rest."""
     os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", GRAPH_QUEUES)
     # PyTorch sizes its OpenMP teams by the HOST's core count; inside a CPU quota that oversubscribes every host-side
     # tensor op (collate, Tensor.copy_) and gets the whole process throttled.  Read when OpenMP initialises.
