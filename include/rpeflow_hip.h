@@ -384,6 +384,13 @@ int rpe_channel_affine_act(float *y, const float *scale, const float *shift, int
  *   one pass.  scale / shift / zscale may be NULL (1 / 0 / 1); shift carries both branches' shifts.                */
 int rpe_channel_affine_add_act(float *y, const float *scale, const float *shift, const float *z, const float *zscale, int B, int C,
                                int64_t P, int act, float slope, rpe_stream_t stream);
+/* rpe_residual_tail: the tail of the 2-D pyramid's residual block with its shortcut branch inside (pwc2d_core.py:6-25): in place on y [B][Cout][Ho][Wo]
+ * (the raw output of the block's second convolution), y = act(scale * y + shift + shortcut_scale * (W0 . x[:, :, ::stride, ::stride]))
+ * with x [B][Cin][H][W] the block's input, W0 [Cout][Cin] the 1x1 shortcut convolution (no padding; Ho = (H - 1) / stride + 1),
+ * shift the sum of both branches' shifts; act 0 none / 1 ReLU / 2 LeakyReLU(slope).  Cin <= 256. */
+int rpe_residual_tail(float *y, const float *scale, const float *shift, const float *x, const float *shortcut_weight,
+                              const float *shortcut_scale, int B, int Cin, int Cout, int H, int W, int stride, int act, float slope,
+                              rpe_stream_t stream);
 
 /* ---- evaluation metric sums (eval_withocc.py:65-108, eval_noocc.py:57-99) ----------------------------------
  * The caller of the hot path: per batch, the twelve sums the reference's Evaluator keeps (there: a Python loop over

@@ -235,6 +235,56 @@ __global__ __launch_bounds__(256) void affine_add_act_kernel(float *__restrict__
     }
 }
 
+// The same tail with the shortcut branch computed here: y = act(scale * y + shift + zscale * (W0 . x[:, :, ::S, ::S])).
+// The reference's down-sampling shortcut is a 1x1 convolution of stride 2 without padding (pwc2d_core.py:9: kernel_size 1,
+// stride 2): per output pixel a Cin-long dot product with a row of W0 -- 0.05 to 0.3 GFLOP per pyramid level, nothing for
+// the vector units, but as its own layer it was a strided copy + a GEMM launch (or a MIOpen convolution at the finest level)
+// in front of this pass, on the main chain of both 2-D pyramids.  A thread owns one output pixel and kTailOc output channels;
+// the weights of the block's channel group sit in LDS (read at one address by the whole wave: broadcast).  Summation over
+// the input channels in ascending order, one chain per output: fixed.
+constexpr int kTailOc = 8;
+constexpr int kTailMaxCin = 256;
+__global__ __launch_bounds__(256) void residual_tail_kernel(float *__restrict__ y, const float *__restrict__ scale, const float *__restrict__ shift,
+                                                            const float *__restrict__ x, const float *__restrict__ w0, const float *__restrict__ zscale,
+                                                            int Cin, int Cout, int H, int W, int Ho, int Wo, int stride, int act, float slope) {
+    __shared__ float wl[kTailOc][kTailMaxCin];
+    const int oc0 = blockIdx.y * kTailOc, b = blockIdx.z;
+    for (int i = threadIdx.x; i < kTailOc * Cin; i += blockDim.x) {
+        const int o = i / Cin, c = i - o * Cin;
+        wl[o][c] = oc0 + o < Cout ? w0[(int64_t)(oc0 + o) * Cin + c] : 0.f;
+    }
+    __syncthreads();
+    const int P = Ho * Wo;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int oy = p / Wo, ox = p - oy * Wo;
+    const float *xp = x + (int64_t)b * Cin * H * W + (int64_t)(oy * stride) * W + ox * stride;
+    float acc[kTailOc];
+#pragma unroll
+    for (int o = 0; o < kTailOc; ++o) acc[o] = 0.f;
+    const int64_t plane = (int64_t)H * W;
+    int c = 0;
+    for (; c + 4 <= Cin; c += 4) {  // four loads in flight
+        const float v0 = xp[(int64_t)c * plane], v1 = xp[(int64_t)(c + 1) * plane], v2 = xp[(int64_t)(c + 2) * plane], v3 = xp[(int64_t)(c + 3) * plane];
+#pragma unroll
+        for (int o = 0; o < kTailOc; ++o) acc[o] = fmaf(wl[o][c + 3], v3, fmaf(wl[o][c + 2], v2, fmaf(wl[o][c + 1], v1, fmaf(wl[o][c], v0, acc[o]))));
+    }
+    for (; c < Cin; ++c) {
+        const float v = xp[(int64_t)c * plane];
+#pragma unroll
+        for (int o = 0; o < kTailOc; ++o) acc[o] = fmaf(wl[o][c], v, acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < kTailOc; ++o) {
+        const int oc = oc0 + o;
+        if (oc >= Cout) break;
+        const float a = scale ? scale[oc] : 1.0f, s = shift ? shift[oc] : 0.0f, za = zscale ? zscale[oc] : 1.0f;
+        float *row = y + ((int64_t)b * Cout + oc) * P + p;
+        float v = (a * *row + s) + za * acc[o];
+        *row = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v >= 0.f ? v : v * slope) : v);
+    }
+}
+
 // RAFT-style convex up-sampling (models/utils.py:201-214, the last step of RPEFlow_core.forward :424): every fine pixel
 // (h*s+i, w*s+j) is a softmax-weighted combination (9 weights from mask channels k*s*s + i*s + j) of the 3x3
 // coarse neighbourhood of s*flow.  One thread per coarse pixel walks its s*s fine pixels: the mask planes are read
@@ -385,5 +435,18 @@ RPE_API int rpe_channel_affine_add_act(float *y, const float *scale, const float
     if (B > 65535 || C > 65535) return RPE_EUNSUPPORTED;
     dim3 grid((unsigned)((P + 1023) / 1024), C, B), block(256);
     hipLaunchKernelGGL(affine_add_act_kernel, grid, block, 0, (hipStream_t)stream, y, scale, shift, z, zscale, C, P, act, slope);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_residual_tail(float *y, const float *scale, const float *shift, const float *x, const float *shortcut_weight,
+                              const float *shortcut_scale, int B, int Cin, int Cout, int H, int W, int stride, int act, float slope,
+                              rpe_stream_t stream) {
+    if (!y || !x || !shortcut_weight || B < 0 || Cin < 1 || Cout < 1 || H < 1 || W < 1 || stride < 1 || act < 0 || act > 2) return RPE_EINVAL;
+    if (Cin > kTailMaxCin || B > 65535) return RPE_EUNSUPPORTED;
+    if (B == 0) return 0;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;  // kernel 1, no padding
+    dim3 grid((unsigned)((Ho * Wo + 255) / 256), (unsigned)((Cout + kTailOc - 1) / kTailOc), (unsigned)B), block(256);
+    hipLaunchKernelGGL(residual_tail_kernel, grid, block, 0, (hipStream_t)stream, y, scale, shift, x, shortcut_weight, shortcut_scale, Cin, Cout,
+                       H, W, Ho, Wo, stride, act, slope);
     return rpe_launch_status();
 }

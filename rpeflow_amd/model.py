@@ -216,14 +216,19 @@ class ResidualBlock(nn.Module):
         if epi1 is None or epi0 is None or epi1[2] is not None or epi0[2] is not None:
             return self.relu(self.conv1(self.conv0(x)) + self.down0(x))
         # both branches' bias / BatchNorm, the sum and the activation in ONE pass over the two raw convolution outputs
-        from .restormer_ops import channel_affine_add_act_
+        from .restormer_ops import channel_affine_add_act_, residual_tail_
         raw1 = conv_no_bias_or(self.conv1.conv_fn, self.conv0(x), False).contiguous()
-        raw0 = conv_no_bias_or(self.down0.conv_fn, x, False).contiguous()
         key = tuple(id(t) for t in (epi1[1], epi0[1]))
         if getattr(self, "_shift_key", None) != key:
             shifts = [t for t in (epi1[1], epi0[1]) if t is not None]
             self._shift_sum = (shifts[0] + shifts[1]) if len(shifts) == 2 else (shifts[0] if shifts else None)
             self._shift_key = key
+        down = self.down0.conv_fn
+        if (x.dtype == torch.float32 and x.is_contiguous() and down.kernel_size == (1, 1) and down.padding == (0, 0) and down.groups == 1
+                and down.stride[0] == down.stride[1] and down.in_channels <= 256):
+            # the strided 1x1 shortcut inside the tail's pass: no strided copy, no GEMM launch of its own
+            return residual_tail_(raw1, epi1[0], self._shift_sum, x, down.weight, epi0[0], down.stride[0], "leaky_relu", 0.1)
+        raw0 = conv_no_bias_or(down, x, False).contiguous()
         return channel_affine_add_act_(raw1, epi1[0], self._shift_sum, raw0, epi0[0], "leaky_relu", 0.1)
 
 
@@ -928,8 +933,11 @@ class RPEFlow(nn.Module):
         else:
             xyzs1, xyzs2, _, _ = self._pyramid(pc1, pc2, n_samples, fps_order)
             feats_3d_both = core.feature_pyramid_3d([torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)])
+            _stamp("side encode3d done")
             feats_2d_both = core.feature_pyramid_2d(image_both)
+            _stamp("main image pyramid done")
             efeats_2d = core.encode_event(event_voxel)
+            _stamp("main event pyramid done")
         side = self._side_stream(pc1.device) if (pc1.is_cuda and self.overlap_streams) else None
         pre = self._side_stream(pc1.device, "pre") if side is not None else None
         flows_2d, flows_3d = core.decode(xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d, camera, side_stream=side, pre_stream=pre,

@@ -97,6 +97,24 @@ def channel_affine_add_act_(y, scale, shift, z, zscale, act, slope=0.1):
     return y
 
 
+def residual_tail_(y, scale, shift, x, shortcut_weight, shortcut_scale, stride, act, slope=0.1):
+    """In place on y [B,Cout,Ho,Wo]: y = act(scale[c]*y + shift[c] + shortcut_scale[c] * conv1x1(x, shortcut_weight, stride)) -- the
+    residual block's tail with the strided 1x1 shortcut (no padding) computed inside the pass (rpe_residual_tail)."""
+    _lib.require_gpu(y, x, shortcut_weight, op="residual_tail")
+    assert y.is_contiguous() and x.is_contiguous() and y.dtype == torch.float32 and x.dtype == torch.float32 and x.dim() == 4
+    B, cin, H, W = x.shape
+    cout = y.shape[1]
+    w = shortcut_weight.reshape(cout, cin)
+    assert w.is_contiguous() and w.dtype == torch.float32
+    assert tuple(y.shape) == (B, cout, (H - 1) // stride + 1, (W - 1) // stride + 1), (tuple(y.shape), tuple(x.shape), stride)
+    code = {None: 0, "relu": 1, "leaky_relu": 2}[act]
+    with torch.cuda.device(y.device):
+        rc = _lib.lib().rpe_residual_tail(_ptr(y), _ptr(scale), _ptr(shift), _ptr(x), _ptr(w), _ptr(shortcut_scale), B, cin, cout, H, W, int(stride),
+                                          code, float(slope), _lib.stream_of(y))
+    _lib.check(rc, "residual_tail")
+    return y
+
+
 def channel_attention_matrix(qkv, heads, temperature, w_out, eps=1e-12, packed=False):
     """qkv [B,3C,...] contiguous (q | k | v along channels).  Returns M [B,C,C] with
     project_out(softmax(normalize(q) normalize(k)^T * temperature) v) == M @ v  (restormer_arch.py:184-203).

@@ -188,6 +188,30 @@ def test_residual_block_tail_in_one_pass(norm, cin, cout, H, W):
     assert (got - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("B,cin,cout,H,W,stride", [(2, 16, 32, 36, 60, 2), (3, 3, 16, 65, 97, 2), (1, 128, 192, 18, 30, 2), (2, 7, 9, 5, 7, 2),
+                                                    (1, 256, 20, 9, 15, 1), (2, 5, 3, 11, 4, 3)])
+def test_residual_tail_kernel_against_float64(B, cin, cout, H, W, stride):
+    """rpe_residual_tail: y = leaky(scale * y + shift + zscale * conv1x1(x, W0, stride)) in place, against float64 -- odd sizes
+    (Ho = (H - 1) // stride + 1), channel counts off the kernel's group of 8, missing scale / shift / zscale."""
+    from rpeflow_amd.restormer_ops import residual_tail_
+    torch.manual_seed(B * 100 + cin)
+    x = torch.randn(B, cin, H, W)
+    w = torch.randn(cout, cin, 1, 1) * 0.3
+    ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.randn(B, cout, ho, wo)
+    for with_affine in (True, False):
+        scale = torch.rand(cout) + 0.5 if with_affine else None
+        shift = torch.randn(cout) if with_affine else None
+        zscale = torch.rand(cout) + 0.5 if with_affine else None
+        short = torch.nn.functional.conv2d(x.double(), w.double(), stride=stride)
+        ref = y.double() * (scale.double().view(1, -1, 1, 1) if with_affine else 1.0) + (shift.double().view(1, -1, 1, 1) if with_affine else 0.0)
+        ref = ref + short * (zscale.double().view(1, -1, 1, 1) if with_affine else 1.0)
+        ref = torch.where(ref >= 0, ref, ref * 0.1)
+        got = residual_tail_(y.clone().to(DEV), scale.to(DEV) if with_affine else None, shift.to(DEV) if with_affine else None, x.to(DEV), w.to(DEV),
+                             zscale.to(DEV) if with_affine else None, stride, "leaky_relu", 0.1).cpu()
+        assert (got.double() - ref).abs().max() < 2e-6 * max(1.0, float(ref.abs().max())) * max(1.0, cin ** 0.5)
+
+
 def test_feed_forward_adds_its_residual_in_the_gemm():
     """_GatedFeedForward(x, residual=r) == r + _GatedFeedForward(x): project_out's GEMM carries the add (beta = 1)."""
     from rpeflow_amd.model import _GatedFeedForward
