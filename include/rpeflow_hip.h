@@ -176,6 +176,12 @@ int rpe_pointwise_conv_strided(const float *x, int64_t x_batch_stride, int B, in
  * atomically accumulating split-K kernels (rpeflow_amd/utils.py, wants_im2col).                                    */
 int rpe_im2col(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
                float *cols, rpe_stream_t stream);
+/* rpe_im2col_act: the same with the per-channel epilogue of the layer that produced x applied to every value read --
+ *   act(in_scale[c] * x + in_shift[c]), act 0 none / 1 ReLU / 2 LeakyReLU(in_slope), padding stays 0 -- so that a run of im2col
+ *   convolutions (the context network's dilated layers, the coarsest level's estimators) needs no pass of its own for bias /
+ *   BatchNorm / activation between two layers.  in_scale / in_shift may be NULL (1 / 0).                                   */
+int rpe_im2col_act(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                   const float *in_scale, const float *in_shift, int in_act, float in_slope, float *cols, rpe_stream_t stream);
 
 /* ---- knn_interpolation after its KNN (models/utils.py:148-154) ------------------
  * w_j = 1/max(||in_xyz[:,knn_j] - q_xyz||_2, 1e-8), normalised over the k neighbours;

@@ -63,6 +63,7 @@ _PROTOTYPES = {
     "rpe_gather_channel_last": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_pointwise_conv": [_c_ptr, _c_int, _c_int, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_float, _c_ptr, _c_ptr, _c_ptr],
     "rpe_im2col": [_c_ptr] + [_c_int] * 12 + [_c_ptr, _c_ptr],
+    "rpe_im2col_act": [_c_ptr] + [_c_int] * 12 + [_c_ptr, _c_ptr, _c_int, _c_float, _c_ptr, _c_ptr],
     "rpe_knn_interpolate": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                             _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
     "rpe_resize_frames": [_c_ptr, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],

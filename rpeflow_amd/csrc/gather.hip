@@ -306,8 +306,12 @@ namespace {
 // for the whole batch in one launch (ATen's im2col runs one kernel per sample).  A thread writes four consecutive output
 // positions (one 16-byte store when Ho*Wo is a multiple of 4); lanes run along the positions, so for stride 1 the reads
 // of a wave are contiguous row pieces of x.
+// in_scale / in_shift / in_act: the per-channel epilogue act(scale * x + shift) of the layer that PRODUCED x, applied to the values
+// read (padding stays 0): a run of im2col convolutions passes each layer's bias / BatchNorm / activation on to the next unfold
+// instead of running a pass of its own over the raw GEMM output.
 __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x, int C, int H, int W, int kh, int kw, int sh, int sw, int ph,
-                                                     int pw, int dh, int dw, int Ho, int Wo, float *__restrict__ cols) {
+                                                     int pw, int dh, int dw, int Ho, int Wo, const float *__restrict__ in_scale,
+                                                     const float *__restrict__ in_shift, int in_act, float in_slope, float *__restrict__ cols) {
     const int64_t P = (int64_t)Ho * Wo;
     const int64_t p0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     const int row = blockIdx.y, b = blockIdx.z;  // row = (c*kh + i)*kw + j
@@ -315,11 +319,19 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x
     const int j = row % kw, i = (row / kw) % kh, c = row / (kw * kh);
     const float *plane = x + ((int64_t)b * C + c) * H * W;
     int oy = (int)(p0 / Wo), ox = (int)(p0 - (int64_t)oy * Wo);
+    const float a = in_scale ? in_scale[c] : 1.0f, s = in_shift ? in_shift[c] : 0.0f;
     float v[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int y = oy * sh - ph + i * dh, xx = ox * sw - pw + j * dw;
-        v[t] = (p0 + t < P && y >= 0 && y < H && xx >= 0 && xx < W) ? plane[(int64_t)y * W + xx] : 0.f;
+        const bool in = p0 + t < P && y >= 0 && y < H && xx >= 0 && xx < W;
+        float u = in ? plane[(int64_t)y * W + xx] : 0.f;
+        if (in_scale || in_shift || in_act) {
+            u = a * u + s;
+            u = in_act == 1 ? fmaxf(u, 0.f) : (in_act == 2 ? (u >= 0.f ? u : u * in_slope) : u);
+            u = in ? u : 0.f;
+        }
+        v[t] = u;
         if (++ox == Wo) ox = 0, ++oy;
     }
     float *out = cols + ((int64_t)b * C * kh * kw + row) * P + p0;
@@ -333,8 +345,9 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x
 }
 }  // namespace
 
-RPE_API int rpe_im2col(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
-                       float *cols, rpe_stream_t stream) {
+RPE_API int rpe_im2col_act(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                           const float *in_scale, const float *in_shift, int in_act, float in_slope, float *cols, rpe_stream_t stream) {
+    if (in_act < 0 || in_act > 2) return RPE_EINVAL;
     if (!x || !cols || B < 0 || C < 1 || H < 1 || W < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || dh < 1 || dw < 1)
         return RPE_EINVAL;
     const int Ho = (H + 2 * ph - dh * (kh - 1) - 1) / sh + 1, Wo = (W + 2 * pw - dw * (kw - 1) - 1) / sw + 1;
@@ -342,8 +355,14 @@ RPE_API int rpe_im2col(const float *x, int B, int C, int H, int W, int kh, int k
     if (B == 0) return 0;
     if (B > 65535 || (int64_t)C * kh * kw > 65535) return RPE_EUNSUPPORTED;
     dim3 grid((unsigned)(((int64_t)Ho * Wo + 1023) / 1024), (unsigned)(C * kh * kw), (unsigned)B);
-    hipLaunchKernelGGL(im2col_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo, cols);
+    hipLaunchKernelGGL(im2col_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo, in_scale, in_shift,
+                       in_act, in_slope, cols);
     return rpe_launch_status();
+}
+
+RPE_API int rpe_im2col(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                       float *cols, rpe_stream_t stream) {
+    return rpe_im2col_act(x, B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, nullptr, nullptr, 0, 0.f, cols, stream);
 }
 
 RPE_API int rpe_gather_channel_first(const float *data, int64_t sb, int64_t sc, int64_t sn, const int64_t *idx, int B, int C,

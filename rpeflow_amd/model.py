@@ -21,7 +21,7 @@ from .csrc import correlation2d as native_correlation2d
 from .csrc.wrapper import _correlation2d_algo as correlation2d_fused_leaky
 from .hotpath import native_ops
 from .pwc3d_core import FlowEstimator3D as NativeFlowEstimator3D
-from .utils import Conv1dNormRelu, Conv2dNormRelu, conv_module, mesh_grid, resize_frames, run_chain, upsample2x_pair
+from .utils import Conv1dNormRelu, Conv2dNormRelu, conv_chain, conv_module, mesh_grid, resize_frames, run_chain, upsample2x_pair
 from .utils import backwarp_2d as native_backwarp_2d
 
 
@@ -258,7 +258,7 @@ class FlowEstimator2D(nn.Module):
         self.conv_last = nn.Conv2d(self.flow_feat_dim, 2, kernel_size=3, stride=1, padding=1) if conv_last else None
 
     def forward(self, x):
-        x4 = self.conv4(self.conv3(self.conv2(self.conv1(x))))
+        x4 = conv_chain([self.conv1, self.conv2, self.conv3, self.conv4], x)
         flow_feat = torch.cat([self.conv5(x4), x4], dim=1)
         return (flow_feat, conv_module(self.conv_last, flow_feat)) if self.conv_last is not None else flow_feat
 
@@ -275,8 +275,7 @@ class ContextNetwork2D(nn.Module):
 
     def forward(self, x, residual=None):
         """(features, conv_last(features) (+ residual: the flow the delta is added to, RPEFlow_core.py:419))."""
-        for conv in self.convs:
-            x = conv(x)
+        x = conv_chain(self.convs, x)
         return x, conv_module(self.conv_last, x, residual=residual)
 
 

@@ -22,7 +22,7 @@ _NULL = ctypes.c_void_p(0)
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
 def _f32(t):
@@ -199,9 +199,10 @@ def wants_im2col(conv, x):
     return positions <= _IM2COL_MAX_POSITIONS and cols <= _IM2COL_MAX_BYTES and (special or positions <= _IM2COL_TINY_POSITIONS)
 
 
-def im2col_conv(x, weight, bias, stride, padding, dilation, epilogue=None):
+def im2col_conv(x, weight, bias, stride, padding, dilation, epilogue=None, pending=None):
     """conv2d as im2col + ONE GEMM with a fixed summation order: rpe_im2col, then one rocBLAS strided-batched GEMM over the
-    unfolded input and the block's epilogue pass (the 1x1 kernel with the epilogue inside is measurably slower at K = 9 Cin)."""
+    unfolded input and the block's epilogue pass (the 1x1 kernel with the epilogue inside is measurably slower at K = 9 Cin).
+    ``pending``: the (scale, shift, act) epilogue the layer that produced ``x`` still owes; the unfold applies it to what it reads."""
     B, _, H, W = x.shape
     k = weight.shape
     ho = _out_size(H, k[2], stride[0], padding[0], dilation[0])
@@ -209,9 +210,11 @@ def im2col_conv(x, weight, bias, stride, padding, dilation, epilogue=None):
     if x.is_cuda:  # [B, C*kh*kw, ho*wo] in one launch (F.unfold: one per sample)
         x = _f32(x)
         cols = torch.empty((B, k[1] * k[2] * k[3], ho * wo), dtype=torch.float32, device=x.device)
-        _launch(x, "im2col", _lib.lib().rpe_im2col, _ptr(x), B, k[1], H, W, k[2], k[3], stride[0], stride[1], padding[0], padding[1],
-                dilation[0], dilation[1], _ptr(cols))
+        scale, shift, act = pending if pending is not None else (None, None, None)
+        _launch(x, "im2col", _lib.lib().rpe_im2col_act, _ptr(x), B, k[1], H, W, k[2], k[3], stride[0], stride[1], padding[0], padding[1],
+                dilation[0], dilation[1], _ptr(scale), _ptr(shift), {None: 0, "relu": 1, "leaky_relu": 2}[act], 0.1, _ptr(cols))
     else:
+        assert pending is None
         cols = torch.nn.functional.unfold(x, (k[2], k[3]), dilation=dilation, padding=padding, stride=stride)
     if x.is_cuda and 2.0 * cols.numel() * k[0] <= _IM2COL_FUSED_MAX_FLOPS:
         return pointwise_conv(cols, weight, bias, 1, epilogue=epilogue).reshape(B, k[0], ho, wo)
@@ -339,6 +342,36 @@ class Conv2dNormRelu(_ConvNormRelu):
     def forward(self, x):
         y = pointwise_chain([self], x) if x.is_cuda else None
         return y if y is not None else super().forward(x)
+
+
+def conv_chain(blocks, x):
+    """blocks[-1](... blocks[0](x)) for Conv2dNormRelu blocks.  Where a block and its successor both run as im2col + GEMM
+    (wants_im2col: the context network's dilated layers, every 3x3 layer of the coarsest level), the block's epilogue -- bias,
+    BatchNorm, activation -- is not a pass of its own over the GEMM's output: the successor's unfold applies it to what it reads."""
+    blocks = list(blocks)
+    if not (x.is_cuda and all(isinstance(b, Conv2dNormRelu) for b in blocks) and _inference_only(x, *[p for b in blocks for p in b.parameters()])):
+        for b in blocks:
+            x = b(x)
+        return x
+    pending = None
+    for i, b in enumerate(blocks):
+        conv = b.conv_fn
+        epi = b._epilogue()
+        mine = epi is not None and not is_pointwise(conv) and wants_im2col(conv, x)
+        if pending is not None and not mine:  # (cannot happen: a block is only deferred when its successor unfolds)
+            raise RuntimeError("conv_chain: a deferred epilogue met a layer that does not unfold")
+        if not mine:
+            x = b(x)
+            continue
+        nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+        defer = False
+        if nxt is not None and nxt._epilogue() is not None and not is_pointwise(nxt.conv_fn):
+            ho = _out_size(x.shape[2], conv.kernel_size[0], conv.stride[0], conv.padding[0], conv.dilation[0])
+            wo = _out_size(x.shape[3], conv.kernel_size[1], conv.stride[1], conv.padding[1], conv.dilation[1])
+            defer = wants_im2col(nxt.conv_fn, torch.empty((x.shape[0], conv.out_channels, ho, wo), device="meta"))
+        x = im2col_conv(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, epilogue=None if defer else epi, pending=pending)
+        pending = epi if defer else None
+    return x
 
 
 _CHAIN_MAX_POSITIONS = int(os.environ.get("RPE_CHAIN_MAX_POSITIONS", 70000))  # batch x positions: up to 72 x 120 x 8 (beyond: GEMM + epilogue)

@@ -212,6 +212,46 @@ def test_residual_tail_kernel_against_float64(B, cin, cout, H, W, stride):
         assert (got.double() - ref).abs().max() < 2e-6 * max(1.0, float(ref.abs().max())) * max(1.0, cin ** 0.5)
 
 
+@pytest.mark.parametrize("norm", ["batch_norm", None])
+@pytest.mark.parametrize("H,W", [(9, 15), (18, 30), (36, 60), (5, 7)])
+def test_conv_chain_passes_epilogues_on_to_the_next_unfold(norm, H, W):
+    """ContextNetwork2D / FlowEstimator2D on small maps: runs of im2col convolutions hand their bias / BatchNorm / LeakyReLU to
+    the next layer's unfold (rpe_im2col_act) instead of a pass of their own -- against the plain module chain on the CPU, and
+    the launch count shows the passes are gone."""
+    from rpeflow_amd.model import ContextNetwork2D, FlowEstimator2D
+    from rpeflow_amd import utils as U
+    torch.manual_seed(H)
+    nets = [ContextNetwork2D([34, 128, 128, 128, 96, 64, 32], [1, 2, 4, 8, 16, 1], norm=norm).eval(),
+            FlowEstimator2D([40, 128, 128, 96, 64, 32], norm=norm, conv_last=True).eval()]
+    for m in nets:
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight.data.uniform_(0.5, 1.5)
+                mod.bias.data.normal_(0, 0.2)
+    for m in nets:
+        cin = 34 if isinstance(m, ContextNetwork2D) else 40
+        x = torch.randn(2, cin, H, W)
+        with torch.no_grad():
+            ref = m(x)
+            got = m.to(DEV)(x.to(DEV))
+        for a, b in zip(got, ref):
+            assert a.shape == b.shape
+            assert (a.cpu() - b).abs().max() < 3e-5 * max(1.0, float(b.abs().max()))
+    # a layer between two unfolding layers has no pass of its own: count the epilogue launches of the dilated run
+    calls = []
+    import rpeflow_amd.restormer_ops as R
+    real = R.channel_affine_act_
+    R.channel_affine_act_ = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            nets[0](torch.randn(2, 34, 18, 30, device=DEV))
+    finally:
+        R.channel_affine_act_ = real
+    assert len(calls) <= 3, "the dilated layers 2, 4, 8 of the context network still run an epilogue pass (%d passes)" % len(calls)
+
+
 def test_feed_forward_adds_its_residual_in_the_gemm():
     """_GatedFeedForward(x, residual=r) == r + _GatedFeedForward(x): project_out's GEMM carries the add (beta = 1)."""
     from rpeflow_amd.model import _GatedFeedForward
