@@ -732,7 +732,7 @@ struct MfmaBlockLds {
 // holds ~5 entries on average, 15 fit: a few queries per launch) but the wave that meets one runs on alone after every other
 // wave has finished, so its latency is the launch's: eight tiles a round (24 loads in flight, one "anything below the
 // bound?" test) instead of one tile per load-wait-compare round: 128 rounds of ~0.16 us for a cloud of 8192 were +20 us on
-// a 117 us launch (tools/exp/knn_k_cliff.py).
+// a 117 us launch (tools/experiments/knn_k_cliff.py).
 template <int D>
 __device__ void serial_select(const float *__restrict__ inp, int64_t in_sn, int64_t in_sd, int M, const float (&qm2)[3], float qq,
                               int kk, int lane, float &Ld, int &Li) {

@@ -140,7 +140,7 @@ def pointwise_conv(x, weight, bias=None, stride=1, residual=None, inplace=False,
 class _rocblas:
     """These GEMMs through rocBLAS, as MIOpen's own GemmFwd1x1 solver runs them, not hipBLASLt (PyTorch's default on this
     GPU): fp32 rocBLAS kernels are built on v_mfma_f32_16x16x4 and measure 1.0-1.4x faster on the model's shapes, 16x on
-    the 510 -> 192 projections over 135 positions (hipBLASLt: 16x16x1 tiles; tools/exp/blas_pref.py).  Host-side dispatch
+    the 510 -> 192 projections over 135 positions (hipBLASLt: 16x16x1 tiles; tools/experiments/blas_pref.py).  Host-side dispatch
     state only: safe under graph capture."""
     lib = os.environ.get("RPE_POINTWISE_BLAS", "cublas")  # PyTorch's name for rocBLAS; "cublaslt": leave the default
 
@@ -169,7 +169,7 @@ def is_pointwise(conv):
 # MIOpen runs SMALL convolutions it cannot give to Winograd (dilated, strided; sometimes plain 3x3 ones on a 9 x 15 map) as
 # implicit GEMMs that split the reduction over workgroups and add the partial sums with fp32 ATOMICS (igemm ... _gkgs,
 # GemmFwd1x1_0_2): the summation order, and with it the last bits of the result, changes from launch to launch.  Fifteen of
-# the forward's 194 convolution shapes did (tools/exp/conv_determinism.py) -- the context network's dilated 3x3 layers and
+# the forward's 194 convolution shapes did (tools/experiments/conv_determinism.py) -- the context network's dilated 3x3 layers and
 # the pyramids' last stride-2 layers, up to 72 x 120 -- and the decoder amplifies those last bits: 40 replays of ONE graph on
 # ONE batch gave 35 different outputs, max |d flow_2d| 4e-4 ... 2.7e-2, |dEPE2D| against the reference 2e-6 ... 7.6e-5 (what
 # rounds 1-2 read as two "solver populations").  torch.backends.cudnn.deterministic makes MIOpen avoid those kernels at 3x

@@ -269,7 +269,7 @@ def test_feed_forward_adds_its_residual_in_the_gemm():
 @pytest.mark.parametrize("k,s,p,d,H,W,n", [(3, 1, 2, 2, 9, 15, 4), (3, 1, 8, 8, 18, 30, 4), (3, 2, 1, 1, 18, 30, 8), (3, 1, 4, 4, 72, 120, 4), (1, 2, 0, 1, 18, 30, 8),
                                            (3, 1, 1, 1, 9, 15, 4)])
 def test_small_convolutions_are_deterministic_gemms(k, s, p, d, H, W, n):
-    """The shapes MIOpen runs with atomic split-K accumulation (tools/exp/conv_determinism.py) go through im2col / gather + one
+    """The shapes MIOpen runs with atomic split-K accumulation (tools/experiments/conv_determinism.py) go through im2col / gather + one
     rocBLAS GEMM instead: equal to the library convolution to fp32 rounding, and bit-identical from call to call."""
     from rpeflow_amd.utils import conv_module, wants_im2col
     torch.manual_seed(k * 100 + d)

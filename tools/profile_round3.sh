@@ -54,5 +54,5 @@ python3 tools/pmc_summary.py fps_pruned2_kernel $OUT/fps_pmc.json "furthest_poin
 cp $(find /tmp/p6 -name "*kernel_stats.csv" | head -1) $OUT/hotpath_kernel_stats.csv
 # 7. determinism: ten fresh processes with empty MIOpen databases, and 40 forwards / replays in one process
 python3 tools/solver_lottery.py --runs 10 --mode default --no-log --out $OUT/fresh_process_epe.json > $OUT/fresh_process_epe.txt 2>&1
-python3 tools/exp/repeat_forward.py 40 2>&1 | grep -v "MIOpen\|amdgpu.ids\|per-iteration\|Warning" > $OUT/repeat_forward.txt
+python3 tools/experiments/repeat_forward.py 40 2>&1 | grep -v "MIOpen\|amdgpu.ids\|per-iteration\|Warning" > $OUT/repeat_forward.txt
 ls -la $OUT
