@@ -713,13 +713,14 @@ class RPEFlow_core(nn.Module):
                 feat_corr_2d = correlation2d_fused_leaky(feat1_2d, feat2_2d_warp, md, 0, leaky_slope=0.1)
             else:
                 feat_corr_2d = F.leaky_relu(correlation2d(feat1_2d, feat2_2d_warp, md), 0.1)
-            last_flow_2d_to_3d = last_flow_2d * _pair_scale((sensor_w - 1) / (image_w - 1), (sensor_h - 1) / (image_h - 1), last_flow_2d)
             _stamp("main L%d stage1 done" % level)
             br.join(out_s1)
             last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d = out_s1
 
             # ---- stage 2: correlation fusers and flow estimators
             def chain_3d():
+                # (the 3-D chain is the only reader of the 2-D flow in sensor units: computed on its stream, off the main chain)
+                last_flow_2d_to_3d = last_flow_2d * _pair_scale((sensor_w - 1) / (image_w - 1), (sensor_h - 1) / (image_h - 1), last_flow_2d)
                 corr_3d_fused = self.corr_feat_fusers_3d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d,
                                                                 last_flow_2d_to_3d)
                 x_3d = [self.correlation_aligners_3d[level](corr_3d_fused), aligned_3d, last_flow_3d, last_flow_feat_3d]
@@ -729,7 +730,7 @@ class RPEFlow_core(nn.Module):
                 _stamp("side L%d stage2 done" % level)
                 return (est,)
 
-            out_3d = br.fork(chain_3d, [feat_corr_2d, efeat_2d, last_flow_2d_to_3d])
+            out_3d = br.fork(chain_3d, [feat_corr_2d, efeat_2d, last_flow_2d])
             corr_2d_fused = self.corr_feat_fusers_2d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_2d,
                                                             last_flow_3d_to_2d, nn_proj1)
             x_2d = torch.cat([corr_2d_fused, aligned_2d, aligned_e2d, last_flow_2d, last_flow_feat_2d], dim=1)
