@@ -176,7 +176,7 @@ def is_pointwise(conv):
 # their time (10x for the whole forward).  Here such a convolution is im2col (F.unfold) + one rocBLAS strided-batched GEMM:
 # fixed summation order, +10 us on the smallest maps, equal from 36 x 60 on (+0.13 ms per forward in all).
 _IM2COL_MAX_POSITIONS = 36000   # batch x output positions: beyond, MIOpen's implicit GEMMs fill the GPU without splitting K
-_IM2COL_TINY_POSITIONS = 600    # plain 3x3 convolutions this small (9 x 15, batch 4) are sometimes given to the splitting kernels too
+_IM2COL_TINY_POSITIONS = int(os.environ.get("RPE_IM2COL_TINY", 2200))  # plain 3x3 convolutions up to 18 x 30, batch 4: sometimes given to the splitting kernels too, and (with the epilogue handed to the next unfold, conv_chain) faster than Winograd + its epilogue pass on maps this small: 15.92 -> 15.83 ms per batch; 8700 (36 x 60): no gain
 _IM2COL_MAX_BYTES = 192 << 20   # size of the unfolded input
 # The unfolded GEMM stays on rocBLAS + one epilogue pass: K = 9 Cin is deep (1152 for the context network), where the 1x1 kernel
 # (no K split, four channel groups in flight) loses: forward 17.2 ms with the library GEMM, 18.3 fused below 1 GFLOP, 18.6 always.
