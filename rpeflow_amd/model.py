@@ -321,7 +321,10 @@ class CorrFeatureFuser2D(nn.Module):
         self.fuse = CrossTransformerBlock2D(dim=in_channels_2d, num_heads=num_heads)
 
     def forward(self, xy, feat_2d, feat_3d, efeat_2d, last_flow_2d, last_flow_3d_to_2d, nn_proj):
-        feat_3d = torch.cat([feat_3d, last_flow_3d_to_2d], dim=1)
+        """``last_flow_3d_to_2d`` None: ``feat_3d`` carries it already as its last two channels (RPEFlow_core.py:371-373's cat,
+        done by the caller on the stream that produced both)."""
+        if last_flow_3d_to_2d is not None:
+            feat_3d = torch.cat([feat_3d, last_flow_3d_to_2d], dim=1)
         feat_3d_to_2d = self._ops.project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])
         feat_3d_to_2d[:, -2:] -= last_flow_2d  # RPEFlow_core.py:82
         return self.fuse(feat_2d, run_chain(self.mlps, torch.cat([feat_3d_to_2d, efeat_2d], dim=1)))
@@ -682,8 +685,10 @@ class RPEFlow_core(nn.Module):
             else:
                 feat_corr_3d = self.correlations_3d[level](xyz1, fused_3d[:batch_size], xyz2_warp, fused_3d[batch_size:], knn_1in1)
             last_flow_3d_to_2d = last_flow_3d[:, :2] * _pair_scale(sx, sy, last_flow_3d)  # (:371-372) one launch, not mul, mul, cat
+            # the 2-D correlation fuser reads [cost volume | projected flow] (:373): joined here, on the stream that made both
+            feat_corr_3d_and_flow = torch.cat([feat_corr_3d, last_flow_3d_to_2d], dim=1)
             _stamp("side L%d stage1 done" % level)
-            return last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d
+            return last_flow_3d, last_flow_feat_3d, feat_corr_3d, feat_corr_3d_and_flow
 
         hoisted = take(top)
         out_s1 = br.fork(lambda: stage1_3d(top, hoisted), _tensors(hoisted) + [xyzs1[top], xyzs2[top]])
@@ -715,7 +720,7 @@ class RPEFlow_core(nn.Module):
                 feat_corr_2d = F.leaky_relu(correlation2d(feat1_2d, feat2_2d_warp, md), 0.1)
             _stamp("main L%d stage1 done" % level)
             br.join(out_s1)
-            last_flow_3d, last_flow_feat_3d, feat_corr_3d, last_flow_3d_to_2d = out_s1
+            last_flow_3d, last_flow_feat_3d, feat_corr_3d, feat_corr_3d_and_flow = out_s1
 
             # ---- stage 2: correlation fusers and flow estimators
             def chain_3d():
@@ -731,8 +736,7 @@ class RPEFlow_core(nn.Module):
                 return (est,)
 
             out_3d = br.fork(chain_3d, [feat_corr_2d, efeat_2d, last_flow_2d])
-            corr_2d_fused = self.corr_feat_fusers_2d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_2d,
-                                                            last_flow_3d_to_2d, nn_proj1)
+            corr_2d_fused = self.corr_feat_fusers_2d[level](xy1, feat_corr_2d, feat_corr_3d_and_flow, efeat_2d, last_flow_2d, None, nn_proj1)
             x_2d = torch.cat([corr_2d_fused, aligned_2d, aligned_e2d, last_flow_2d, last_flow_feat_2d], dim=1)
             flow_feat_2d_raw = self.flow_estimator_2d(x_2d)
             _stamp("main L%d stage2 done" % level)
