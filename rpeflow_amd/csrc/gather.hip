@@ -237,17 +237,45 @@ __global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict
     float *row = rows + ((int64_t)b * N + i) * CT;
     if (c0 < C2 && sampled) {  // the caller has grid_sample_wrapper(feat_2d, xy) already (the 3-D fuser of the same pair needs it)
         const float *sp = sampled + (int64_t)b * sm_sb + (int64_t)i * sm_sn;
-        for (int c = c0; c < min(c1, C2); ++c) row[c] = sp[(int64_t)c * sm_sc];
+        const int ce = min(c1, C2);
+        int c = c0;
+        for (; c + 8 <= ce; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = sp[(int64_t)(c + u) * sm_sc];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) row[c + u] = v[u];
+        }
+        for (; c < ce; ++c) row[c] = sp[(int64_t)c * sm_sc];
     } else if (c0 < C2) {
         const float px = xy[(int64_t)b * xy_sb + (int64_t)i * xy_sn], py = xy[(int64_t)b * xy_sb + xy_sd + (int64_t)i * xy_sn];
         Bilinear bl;
         bl.setup(px, py, H, W, false);
         const int64_t HW = (int64_t)H * W;
         const float *f2 = feat2d + (int64_t)b * C2 * HW;
-        for (int c = c0; c < min(c1, C2); ++c) row[c] = bl.sample(f2 + (int64_t)c * HW);
+        const int ce = min(c1, C2);
+        int c = c0;
+        for (; c + 4 <= ce; c += 4) {  // four channels per trip: 16 independent gathered loads in flight
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = bl.sample(f2 + (int64_t)(c + u) * HW);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) row[c + u] = v[u];
+        }
+        for (; c < ce; ++c) row[c] = bl.sample(f2 + (int64_t)c * HW);
     }
     const float *f3 = feat3d + (int64_t)b * f3_sb + (int64_t)i * f3_sn;
-    for (int c = max(c0, C2); c < c1; ++c) row[c] = f3[(int64_t)(c - C2) * f3_sc];
+    {
+        int c = max(c0, C2);
+        for (; c + 8 <= c1; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = f3[(int64_t)(c + u - C2) * f3_sc];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) row[c + u] = v[u];
+        }
+        for (; c < c1; ++c) row[c] = f3[(int64_t)(c - C2) * f3_sc];
+    }
 }
 
 __global__ __launch_bounds__(256) void project_rows_kernel(const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
