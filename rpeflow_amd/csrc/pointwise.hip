@@ -110,6 +110,91 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(PwArgs a) {
     }
 }
 
+// The same layer on the coarse maps (a few hundred workgroups at most): there a launch is a chain of K / 16 load-wait-multiply
+// rounds per wave and most of the chip is idle, so the four waves of a workgroup split the K loop of ONE output tile (wave w
+// takes rounds w, w + 4, ...) and the partial sums are added through LDS in wave order: a quarter of the dependent rounds
+// (389 -> 273 channels over 135 positions: 33 -> ~12 us).  Summation order: channels of a wave's rounds ascending, then
+// ((w0 + w1) + w2) + w3 -- fixed.
+template <bool VEC>
+__global__ __launch_bounds__(256) void pointwise_conv_ksplit_kernel(PwArgs a) {
+    __shared__ float part[3][64][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = lane >> 4, j = lane & 15;
+    const int ot = blockIdx.y;
+    const int b = blockIdx.z;
+    const int64_t P = a.P, p0 = (int64_t)blockIdx.x * 64 + 4 * j;
+    const float *xb = a.x + (int64_t)b * a.x_bstride;
+    const float *wpk = a.wpk + (int64_t)b * a.w_bstride;
+    pw_f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = pw_f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool p_in = p0 < P;
+    constexpr int U = 4;
+    for (int kt0 = wave * U; kt0 < a.ktiles; kt0 += 4 * U) {
+        float xv[U][4], av[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kt = kt0 + u, c = 4 * kt + k;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) xv[u][t] = 0.f;
+            if (c < a.Cin && p_in) {
+                const float *row = xb + (int64_t)c * P + p0;
+                if (VEC) {
+                    const float4 v = *reinterpret_cast<const float4 *>(row);
+                    xv[u][0] = v.x, xv[u][1] = v.y, xv[u][2] = v.z, xv[u][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) xv[u][t] = p0 + t < P ? row[t] : 0.f;
+                }
+            }
+            av[u] = kt < a.ktiles ? wpk[((int64_t)ot * a.ktiles + kt) * 64 + lane] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], xv[u][t], acc[t], 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[wave - 1][lane][4 * t + r] = acc[t][r];
+    }
+    __syncthreads();
+    if (wave > 0 || !p_in) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] += part[w][lane][4 * t + r];
+    const int g = k;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oc = 16 * ot + 4 * g + r;
+        if (oc >= a.Cout) continue;
+        const float sc = a.scale ? a.scale[oc] : 1.0f, sh = a.shift ? a.shift[oc] : 0.0f;
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float u = sc * acc[t][r] + sh;
+            v[t] = a.act == 1 ? fmaxf(u, 0.f) : (a.act == 2 ? (u >= 0.f ? u : u * a.slope) : u);
+        }
+        const int64_t off = ((int64_t)b * a.Cout + oc) * P + p0;
+        if (VEC) {
+            if (a.res) {
+                const float4 rr = *reinterpret_cast<const float4 *>(a.res + off);
+                v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
+            }
+            *reinterpret_cast<float4 *>(a.y + off) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (p0 + t < P) a.y[off + t] = a.res ? v[t] + a.res[off + t] : v[t];
+        }
+    }
+}
+
 template <int OT>
 int launch_pw(const PwArgs &a, int B, bool vec, hipStream_t st) {
     dim3 grid((unsigned)((a.P + 63) / 64), (unsigned)((a.n_otiles + 4 * OT - 1) / (4 * OT)), (unsigned)B);
@@ -133,6 +218,16 @@ RPE_API int rpe_pointwise_conv_strided(const float *x, int64_t x_batch_stride, i
     hipStream_t st = (hipStream_t)stream;
     // output tiles per wave: enough workgroups to cover the chip on the small maps, fewer re-reads of x on the wider layers
     const int64_t wgs1 = ((P + 63) / 64) * ((a.n_otiles + 3) / 4) * B;
+#ifndef RPE_PW_KSPLIT_MAX_WGS
+#define RPE_PW_KSPLIT_MAX_WGS 1024
+#endif
+    const int64_t wgs_ks = ((P + 63) / 64) * a.n_otiles * B;
+    if (wgs_ks <= RPE_PW_KSPLIT_MAX_WGS && a.ktiles >= 16 && a.n_otiles <= 65535) {
+        dim3 grid((unsigned)((P + 63) / 64), (unsigned)a.n_otiles, (unsigned)B);
+        if (vec) hipLaunchKernelGGL((pointwise_conv_ksplit_kernel<true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((pointwise_conv_ksplit_kernel<false>), grid, dim3(256), 0, st, a);
+        return rpe_launch_status();
+    }
     if (a.n_otiles >= 16 && wgs1 >= 4 * 1024) return launch_pw<4>(a, B, vec, st);
     if (a.n_otiles >= 8 && wgs1 >= 2 * 1024) return launch_pw<2>(a, B, vec, st);
     return launch_pw<1>(a, B, vec, st);

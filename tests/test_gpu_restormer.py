@@ -286,12 +286,13 @@ def test_small_convolutions_are_deterministic_gemms(k, s, p, d, H, W, n):
 
 
 @pytest.mark.parametrize("B,cin,cout,spatial", [(4, 192, 510, (9, 15)), (2, 7, 5, (3, 5)), (8, 67, 96, (500,)), (3, 130, 33, (36, 60)), (1, 4, 16, (64,)),
-                                                (4, 255, 96, (18, 30)), (2, 96, 1020, (135,))])
+                                                (4, 255, 96, (18, 30)), (2, 96, 1020, (135,)), (4, 389, 273, (9, 15)), (1, 66, 17, (7,)), (2, 215, 81, (18, 30))])
 @pytest.mark.parametrize("act", [None, "relu", "leaky_relu"])
 def test_pointwise_conv_kernel_with_epilogue(B, cin, cout, spatial, act):
     """rpe_pointwise_conv (csrc/pointwise.hip): 1x1 convolution + per-channel scale / shift + activation (+ residual, also
     accumulated in place) in one launch against the plain PyTorch ops on the CPU; ragged channel counts (Cin % 4, Cout % 16),
-    position counts that are not multiples of 4 / 64 (9 x 15 = 135), both Conv1d and Conv2d layouts."""
+    position counts that are not multiples of 4 / 64 (9 x 15 = 135), both Conv1d and Conv2d layouts.  The coarse-map cases (few
+    workgroups, Cin >= 64) run the kernel whose four waves split the channel loop (pointwise_conv_ksplit_kernel)."""
     from rpeflow_amd.utils import pointwise_conv
     torch.manual_seed(cin * 7 + cout)
     x = torch.randn((B, cin) + spatial)
