@@ -258,6 +258,15 @@ int rpe_project_feat_nn_corr_sampled(const float *xy, int64_t xy_sb, int64_t xy_
                                      const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
                                      const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
                                      const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream);
+/* rpe_project_feat_nn_corr_fused: the same with the two element-wise steps the 2-D correlation fuser puts behind it
+ *   (RPEFlow_core.py:82-83) inside the launch: `subtract` [B, n_subtract, H*W] is subtracted from the LAST n_subtract projected
+ *   channels ("projected 3-D flow minus the 2-D flow") and `append` [B, n_append, H*W] is copied behind the C3 + 3 channels
+ *   (the cat with the event features): out [B, C3 + 3 + n_append, H, W].  Either may be NULL with a count of 0.          */
+int rpe_project_feat_nn_corr_fused(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
+                                   int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
+                                   const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
+                                   const int64_t *nn_idx, const float *subtract, int n_subtract, const float *append, int n_append,
+                                   int B, int N, float *workspace, float *out, rpe_stream_t stream);
 
 /* ---- PointConv in one kernel (models/pointconv.py:33-61, 90-122) -----------------
  * rpe_pointconv_pack_rows: rows[b][m][:] = [xyz[b][:,m] | srcs[0][b][:,m] | ... | zeros] -- cat([xyz, features]) channel-last

@@ -281,14 +281,18 @@ __global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void project_rows_kernel(const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
                                                            const float *__restrict__ feat2d, int C2, int H, int W, int C3, int N,
                                                            const float *__restrict__ rows, const int64_t *__restrict__ nn,
+                                                           const float *__restrict__ sub, int n_sub, const float *__restrict__ tail, int n_tail,
                                                            float *__restrict__ out) {
+    // sub [B][n_sub][HW]: subtracted from the LAST n_sub projected channels (the 2-D correlation fuser's "projected flow minus
+    // the 2-D flow", RPEFlow_core.py:82); tail [B][n_tail][HW]: copied behind the C3 + 3 channels (its cat with the event
+    // features, :83): the fuser's MLP input leaves this kernel complete.
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     const int HW = H * W;
     if (p >= HW) return;
     const int64_t i = nn[(int64_t)b * HW + p];
     const float px = xy[(int64_t)b * xy_sb + i * xy_sn], py = xy[(int64_t)b * xy_sb + xy_sd + i * xy_sn];
-    float *o = out + (int64_t)b * (C3 + 3) * HW + p;
+    float *o = out + (int64_t)b * (C3 + 3 + n_tail) * HW + p;
     o[0] = px - (float)(p % W);
     o[HW] = py - (float)(p / W);
     const float *row = rows + ((int64_t)b * N + i) * (C2 + C3);
@@ -336,6 +340,21 @@ __global__ __launch_bounds__(256) void project_rows_kernel(const float *__restri
         for (int u = 0; u < 4; ++u) o[(int64_t)(3 + c + u) * HW] = r[u];
     }
     for (; c < C3; ++c) o[(int64_t)(3 + c) * HW] = row[C2 + c];
+    for (int t = 0; t < n_sub; ++t) {  // (after the copy above: same thread, same addresses)
+        float *q = o + (int64_t)(3 + C3 - n_sub + t) * HW;
+        *q = *q - sub[((int64_t)b * n_sub + t) * HW + p];
+    }
+    c = 0;
+    const float *tp = tail + (int64_t)b * n_tail * HW + p;
+    float *ot = o + (int64_t)(3 + C3) * HW;
+    for (; c + 8 <= n_tail; c += 8) {
+        float r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = tp[(int64_t)(c + u) * HW];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ot[(int64_t)(c + u) * HW] = r[u];
+    }
+    for (; c < n_tail; ++c) ot[(int64_t)c * HW] = tp[(int64_t)c * HW];
 }
 
 int channel_split(int C, long items, int B);
@@ -508,12 +527,14 @@ RPE_API int rpe_upsample2x_pair(const float *a, int Ca, float scale_a, const flo
     return rpe_launch_status();
 }
 
-RPE_API int rpe_project_feat_nn_corr_sampled(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
-                                             int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
-                                             const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
-                                             const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream) {
+RPE_API int rpe_project_feat_nn_corr_fused(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
+                                           int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
+                                           const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
+                                           const int64_t *nn_idx, const float *subtract, int n_subtract, const float *append, int n_append,
+                                           int B, int N, float *workspace, float *out, rpe_stream_t stream) {
     if (!xy || !feat_2d || !feat_3d || !nn_idx || !out || !workspace || B < 0 || C2 < 1 || C3 < 0 || H < 1 || W < 1 || N < 1)
         return RPE_EINVAL;
+    if (n_subtract < 0 || n_subtract > C3 || n_append < 0 || (n_subtract > 0 && !subtract) || (n_append > 0 && !append)) return RPE_EINVAL;
     if (B == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
@@ -521,8 +542,16 @@ RPE_API int rpe_project_feat_nn_corr_sampled(const float *xy, int64_t xy_sb, int
     hipLaunchKernelGGL(point_rows_kernel, dim3((N + 255) / 256, (C2 + C3 + cpb - 1) / cpb, B), dim3(256), 0, st, xy, xy_sb, xy_sd,
                        xy_sn, feat_2d, C2, H, W, feat_3d, f3_sb, f3_sc, f3_sn, C3, N, cpb, sampled_2d, sm_sb, sm_sc, sm_sn, workspace);
     hipLaunchKernelGGL(project_rows_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2,
-                       H, W, C3, N, workspace, nn_idx, out);
+                       H, W, C3, N, workspace, nn_idx, subtract, n_subtract, append, n_append, out);
     return rpe_launch_status();
+}
+
+RPE_API int rpe_project_feat_nn_corr_sampled(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
+                                             int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
+                                             const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
+                                             const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream) {
+    return rpe_project_feat_nn_corr_fused(xy, xy_sb, xy_sd, xy_sn, feat_2d, C2, H, W, sampled_2d, sm_sb, sm_sc, sm_sn, feat_3d, f3_sb, f3_sc, f3_sn,
+                                          C3, nn_idx, nullptr, 0, nullptr, 0, B, N, workspace, out, stream);
 }
 
 RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,

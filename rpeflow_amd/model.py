@@ -23,6 +23,7 @@ from .hotpath import native_ops
 from .pwc3d_core import FlowEstimator3D as NativeFlowEstimator3D
 from .utils import Conv1dNormRelu, Conv2dNormRelu, conv_chain, conv_module, mesh_grid, resize_frames, run_chain, upsample2x_pair
 from .utils import backwarp_2d as native_backwarp_2d
+from .utils import project_feat_with_nn_corr as native_project_feat_with_nn_corr
 
 
 class Config(dict):
@@ -325,9 +326,15 @@ class CorrFeatureFuser2D(nn.Module):
         done by the caller on the stream that produced both)."""
         if last_flow_3d_to_2d is not None:
             feat_3d = torch.cat([feat_3d, last_flow_3d_to_2d], dim=1)
-        feat_3d_to_2d = self._ops.project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_proj[..., 0])
-        feat_3d_to_2d[:, -2:] -= last_flow_2d  # RPEFlow_core.py:82
-        return self.fuse(feat_2d, run_chain(self.mlps, torch.cat([feat_3d_to_2d, efeat_2d], dim=1)))
+        project = self._ops.project_feat_with_nn_corr
+        if feat_2d.is_cuda and project is native_project_feat_with_nn_corr:
+            # "-= last_flow_2d" on the projected flow (RPEFlow_core.py:82) and the cat with the event features (:83) inside the launch
+            both = project(xy, feat_2d, feat_3d, nn_proj[..., 0], subtract_last=last_flow_2d, append=efeat_2d)
+        else:
+            feat_3d_to_2d = project(xy, feat_2d, feat_3d, nn_proj[..., 0])
+            feat_3d_to_2d[:, -2:] -= last_flow_2d  # RPEFlow_core.py:82
+            both = torch.cat([feat_3d_to_2d, efeat_2d], dim=1)
+        return self.fuse(feat_2d, run_chain(self.mlps, both))
 
 
 class CorrFeatureFuser3D(nn.Module):

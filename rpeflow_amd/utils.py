@@ -597,12 +597,15 @@ def grid_sample_wrapper(feat_2d, xy):
 
 
 @torch.no_grad()
-def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=None):
+def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=None, subtract_last=None, append=None):
     """utils.py:297-317.  xy [B,2,N], feat_2d [B,C2,H,W], feat_3d [B,C3,N], nn_indices [B,H*W]
     -> [B,C3+3,H,W].  Two launches (per-point rows, then per-pixel gather + correlation); the
     reference runs grid_sample over all N points, three gathers, a product, a mean and a concat.
     ``sampled_2d`` [B,C2,N] (optional, any strides): ``grid_sample_wrapper(feat_2d, xy)`` if the caller has it -- the 3-D
-    fuser of the same (map, points) pair computes it anyway; the per-point bilinear taps are then not repeated."""
+    fuser of the same (map, points) pair computes it anyway; the per-point bilinear taps are then not repeated.
+    ``subtract_last`` [B,n,H,W]: subtracted from the last n projected channels; ``append`` [B,m,H,W]: concatenated behind the
+    result (-> [B,C3+3+m,H,W]) -- the two steps the 2-D correlation fuser puts behind this call (RPEFlow_core.py:82-83), inside
+    the second launch."""
     _lib.require_gpu(xy, feat_2d, feat_3d, op="project_feat_with_nn_corr")
     xy, feat_2d, feat_3d = _f32(xy), _f32(feat_2d).contiguous(), _f32(feat_3d)
     B, C2, H, W = feat_2d.shape
@@ -613,18 +616,25 @@ def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=
         assert nn_indices.shape == (B, H * W)
     nn_indices = nn_indices.to(torch.int64).contiguous()
     C3, N = feat_3d.shape[1], feat_3d.shape[2]
-    out = torch.empty((B, C3 + 3, H, W), dtype=torch.float32, device=feat_2d.device)
+    n_sub = n_app = 0
+    if subtract_last is not None:
+        subtract_last = _f32(subtract_last).contiguous()
+        n_sub = subtract_last.shape[1]
+        assert subtract_last.shape == (B, n_sub, H, W) and n_sub <= C3
+    if append is not None:
+        append = _f32(append).contiguous()
+        n_app = append.shape[1]
+        assert append.shape == (B, n_app, H, W)
+    out = torch.empty((B, C3 + 3 + n_app, H, W), dtype=torch.float32, device=feat_2d.device)
     rows = torch.empty((B, N, C2 + C3), dtype=torch.float32, device=feat_2d.device)  # kernel scratch
+    sm_strides = (0, 0, 0)
     if sampled_2d is not None:
         sampled_2d = _f32(sampled_2d)
         assert sampled_2d.shape == (B, C2, N)
-        _launch(feat_2d, "project_feat_with_nn_corr", _lib.lib().rpe_project_feat_nn_corr_sampled,
-                _ptr(xy), *xy.stride(), _ptr(feat_2d), C2, H, W, _ptr(sampled_2d), *sampled_2d.stride(), _ptr(feat_3d), *feat_3d.stride(), C3,
-                _ptr(nn_indices), B, N, _ptr(rows), _ptr(out))
-        return out
-    _launch(feat_2d, "project_feat_with_nn_corr", _lib.lib().rpe_project_feat_nn_corr,
-            _ptr(xy), *xy.stride(), _ptr(feat_2d), C2, H, W, _ptr(feat_3d), *feat_3d.stride(), C3,
-            _ptr(nn_indices), B, N, _ptr(rows), _ptr(out))
+        sm_strides = sampled_2d.stride()
+    _launch(feat_2d, "project_feat_with_nn_corr", _lib.lib().rpe_project_feat_nn_corr_fused,
+            _ptr(xy), *xy.stride(), _ptr(feat_2d), C2, H, W, _ptr(sampled_2d), *sm_strides, _ptr(feat_3d), *feat_3d.stride(), C3,
+            _ptr(nn_indices), _ptr(subtract_last), n_sub, _ptr(append), n_app, B, N, _ptr(rows), _ptr(out))
     return out
 
 

@@ -472,3 +472,26 @@ def test_knn_interpolation_with_the_callers_indices():
     plain, idx = U.knn_interpolation(coarse, feat, fine, return_indices=True)
     assert idx.shape == (2, 700, 3) and torch.equal(plain, U.knn_interpolation(coarse, feat, fine))
     assert torch.equal(plain, U.knn_interpolation(coarse, feat, fine, knn_indices=idx))
+
+
+def test_project_feat_with_the_fusers_two_elementwise_steps_inside():
+    """project_feat_with_nn_corr(..., subtract_last=, append=) == cat([project_feat(...) with its last channels minus a map, another
+    map]) -- the 2-D correlation fuser's "-= last_flow_2d" and cat with the event features (RPEFlow_core.py:82-83) -- bit for bit
+    against the plain call followed by the two PyTorch steps; odd map sizes, with and without caller-provided samples."""
+    from rpeflow_amd import utils as U
+    torch.manual_seed(11)
+    for B, C2, C3, H, W, N, E in [(2, 81, 34, 9, 15, 256, 32), (1, 32, 5, 7, 5, 40, 3), (3, 16, 66, 18, 30, 512, 64)]:
+        xy = torch.rand(B, 2, N, device="cuda:0") * torch.tensor([W - 1.0, H - 1.0], device="cuda:0").view(1, 2, 1)
+        f2, f3 = torch.randn(B, C2, H, W, device="cuda:0"), torch.randn(B, C3, N, device="cuda:0")
+        nn = torch.randint(0, N, (B, H * W), device="cuda:0")
+        sub, app = torch.randn(B, 2, H, W, device="cuda:0"), torch.randn(B, E, H, W, device="cuda:0")
+        plain = U.project_feat_with_nn_corr(xy, f2, f3, nn)
+        ref = plain.clone()
+        ref[:, -2:] -= sub
+        ref = torch.cat([ref, app], dim=1)
+        got = U.project_feat_with_nn_corr(xy, f2, f3, nn, subtract_last=sub, append=app)
+        assert got.shape == ref.shape and torch.equal(got, ref)
+        only_sub = U.project_feat_with_nn_corr(xy, f2, f3, nn, subtract_last=sub)
+        assert torch.equal(only_sub, ref[:, :C3 + 3])
+        sampled = U.grid_sample_wrapper(f2, xy)
+        assert torch.equal(U.project_feat_with_nn_corr(xy, f2, f3, nn, sampled_2d=sampled, subtract_last=sub, append=app), ref)
