@@ -20,9 +20,11 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kChunk = 2048;  // positions per workgroup (4 waves x 16-position groups, interleaved)
-
-__host__ __device__ inline int attn_chunks(int64_t P) { return (int)((P + kChunk - 1) / kChunk); }
+// positions per workgroup (4 waves x 16-position groups, interleaved).  On the coarse maps a launch is a handful of workgroups
+// and a wave's loop over its positions is a chain of load-wait-multiply rounds: shorter chunks there (more workgroups, 4 rounds
+// a wave instead of up to 32; the partial grams are added in chunk order by the softmax kernel either way).
+__host__ __device__ inline int attn_chunk(int64_t P) { return P <= 16384 ? 256 : 2048; }
+__host__ __device__ inline int attn_chunks(int64_t P) { return (int)((P + attn_chunk(P) - 1) / attn_chunk(P)); }
 
 template <bool VEC>
 __device__ __forceinline__ float4 load_row4(const float *__restrict__ base, int row, int c, int64_t P, int64_t p, int64_t pend) {
@@ -39,7 +41,7 @@ __device__ __forceinline__ float4 load_row4(const float *__restrict__ base, int 
 }
 
 // grid (chunks * T, heads, B), 256 threads; T = ceil(c / 16).  Workgroup (s, ti) owns rows 16 ti .. 16 ti + 15 of the
-// gram for positions [s * kChunk, (s + 1) * kChunk): one q tile row against all T k tiles (k is re-read T times, from L2).
+// gram for positions [s * chunk, (s + 1) * chunk): one q tile row against all T k tiles (k is re-read T times, from L2).
 template <int T, bool VEC>
 __global__ __launch_bounds__(256) void attn_gram_kernel(const float *__restrict__ q, const float *__restrict__ k, int64_t batch_stride,
                                                         int heads, int c, int64_t P, float *__restrict__ gpart,
@@ -51,8 +53,9 @@ __global__ __launch_bounds__(256) void attn_gram_kernel(const float *__restrict_
     const int row = lane & 15, grp = lane >> 4;
     const float *qh = q + (int64_t)b * batch_stride + (int64_t)h * c * P;
     const float *kh = k + (int64_t)b * batch_stride + (int64_t)h * c * P;
-    const int64_t p0 = (int64_t)s * kChunk;
-    const int64_t pend = p0 + kChunk < P ? p0 + kChunk : P;
+    const int chunk = attn_chunk(P);
+    const int64_t p0 = (int64_t)s * chunk;
+    const int64_t pend = p0 + chunk < P ? p0 + chunk : P;
     const bool k_norms = ti == 0;  // the k norms are the same in every tile row: the first one writes them
 
     f32x4 acc[T];
