@@ -139,6 +139,120 @@ struct LaneHeap {  // element r of the heap lives in lane r
     }
 };
 
+// __adjust_heap(first, node, len, value) + its __push_heap for the lane-distributed heap of a compile-time k -- the step of
+// __make_heap, __heap_select (~100 replacements per replayed row) and __sort_heap -- as a decision tree over CONSTANT lanes: the children of node n sit in lanes
+// 2n + 1 and 2n + 2, so every v_readlane / v_writelane has an immediate lane select and every comparison is a scalar integer
+// compare on order-preserving keys (sign bit flipped, negative values complemented; a distance is never -0).  libstdc++ walks
+// the hole down to a leaf along the larger children (the right one unless it is smaller than the left) and pushes the value
+// back up while the parent is smaller; the values along that path do not increase, so the value ends at the first path node
+// whose path child is smaller than it and every node below keeps its old value: walking down and stopping there gives the
+// same array.  The generic LaneHeap::adjust (dynamic lane selects, float compares, masked moves) costs ~1100 cycles a
+// replacement for a lone wave.
+__device__ __forceinline__ unsigned heap_key(float d) {
+    const unsigned b = (unsigned)__float_as_int(d);
+    return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+}
+__device__ __forceinline__ float heap_dist(unsigned k) { return __int_as_float((int)((k & 0x80000000u) ? k ^ 0x80000000u : ~k)); }
+template <int LANE>
+__device__ __forceinline__ void heap_put(unsigned &kv, int &iv, unsigned nk, int ni) {  // (wave-uniform nk, ni)
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(kv) : "s"(nk), "n"(LANE));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(iv) : "s"(ni), "n"(LANE));
+}
+template <int NODE, int LEN>
+__device__ __forceinline__ void heap_sift(unsigned &kv, int &iv, unsigned nk, int ni) {  // __adjust_heap(first, NODE, LEN, value)
+    constexpr int L = 2 * NODE + 1, R = L + 1;
+    if constexpr (L >= LEN) {
+        heap_put<NODE>(kv, iv, nk, ni);
+    } else if constexpr (R >= LEN) {  // LEN even: the last inner node has a left child only, and that child is a leaf
+        const unsigned kl = (unsigned)__builtin_amdgcn_readlane((int)kv, L);
+        if (kl < nk) {
+            heap_put<NODE>(kv, iv, nk, ni);
+        } else {
+            heap_put<NODE>(kv, iv, kl, __builtin_amdgcn_readlane(iv, L));
+            heap_put<L>(kv, iv, nk, ni);
+        }
+    } else {
+        const unsigned kl = (unsigned)__builtin_amdgcn_readlane((int)kv, L), kr = (unsigned)__builtin_amdgcn_readlane((int)kv, R);
+        if (kr < kl) {
+            if (kl < nk) {
+                heap_put<NODE>(kv, iv, nk, ni);
+            } else {
+                heap_put<NODE>(kv, iv, kl, __builtin_amdgcn_readlane(iv, L));
+                heap_sift<L, LEN>(kv, iv, nk, ni);
+            }
+        } else {
+            if (kr < nk) {
+                heap_put<NODE>(kv, iv, nk, ni);
+            } else {
+                heap_put<NODE>(kv, iv, kr, __builtin_amdgcn_readlane(iv, R));
+                heap_sift<R, LEN>(kv, iv, nk, ni);
+            }
+        }
+    }
+}
+template <int K, int PARENT>
+__device__ __forceinline__ void heap_make(unsigned &kv, int &iv) {  // std::__make_heap: parents (K - 2) / 2 .. 0
+    heap_sift<PARENT, K>(kv, iv, (unsigned)__builtin_amdgcn_readlane((int)kv, PARENT), __builtin_amdgcn_readlane(iv, PARENT));
+    if constexpr (PARENT > 0) heap_make<K, PARENT - 1>(kv, iv);
+}
+template <int LAST>
+__device__ __forceinline__ void heap_sort(unsigned &kv, int &iv) {  // std::__sort_heap: last = K - 1 .. 1
+    const unsigned lv = (unsigned)__builtin_amdgcn_readlane((int)kv, LAST);
+    const int li = __builtin_amdgcn_readlane(iv, LAST);
+    heap_put<LAST>(kv, iv, (unsigned)__builtin_amdgcn_readlane((int)kv, 0), __builtin_amdgcn_readlane(iv, 0));
+    heap_sift<0, LAST>(kv, iv, lv, li);
+    if constexpr (LAST > 1) heap_sort<LAST - 1>(kv, iv);
+}
+
+// std::partial_sort of one query's row for a compile-time k on that tree: __make_heap of the first K distances, every later
+// one below the top replaces it (__heap_select), __sort_heap; the result in lane r = rank r.
+template <int D, int K>
+__device__ __forceinline__ void heap_replay_static(float &Ld, int &Li, const float (&qm2)[3], float qq, const float *__restrict__ inp,
+                                                   int64_t in_sn, int64_t in_sd, int M, int lane) {
+    unsigned kv = heap_key(INFINITY);
+    int iv = 0;
+    float top = INFINITY;
+    constexpr int kTieTiles = 4;  // (eight tiles a round make the kernel spill and slow its sweeps: 125 -> 138 us)
+    for (int base0 = 0; base0 < M; base0 += kTieTiles * RPE_WAVE) {
+        float d[kTieTiles];
+        unsigned long long m[kTieTiles];
+        float pt[kTieTiles][3];
+#pragma unroll
+        for (int u = 0; u < kTieTiles; ++u) load_point<D>(inp, in_sn, in_sd, min(base0 + u * RPE_WAVE + lane, M - 1), pt[u]);
+#pragma unroll
+        for (int u = 0; u < kTieTiles; ++u) {
+            const float pp = base0 + u * RPE_WAVE + lane < M ? rpe_sqnorm<D>(pt[u]) : INFINITY;
+            d[u] = rpe_pair_dist<D>(qm2, qq, pt[u], pp);
+        }
+        if (base0 == 0) {
+            kv = heap_key(d[0]);
+            iv = lane;
+            if constexpr (K >= 2) heap_make<K, (K - 2) / 2>(kv, iv);
+            top = heap_dist((unsigned)__builtin_amdgcn_readlane((int)kv, 0));
+        }
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int u = 0; u < kTieTiles; ++u) {
+            m[u] = __ballot((base0 > 0 || u > 0 || lane >= K) && d[u] < top);  // (top only falls: a superset of what passes later)
+            any |= m[u];
+        }
+        if (!any) continue;
+#pragma unroll
+        for (int u = 0; u < kTieTiles; ++u) {
+            unsigned long long mu = m[u] & __ballot(d[u] < top);  // against the top as it is now
+            while (mu) {  // __pop_heap(first, middle, i) for every later element below the heap's top, in order
+                const int l = __builtin_ctzll(mu);
+                heap_sift<0, K>(kv, iv, heap_key(rpe_readlane(d[u], l)), base0 + u * RPE_WAVE + l);
+                top = heap_dist((unsigned)__builtin_amdgcn_readlane((int)kv, 0));
+                mu &= (~1ull << l) & __ballot(d[u] < top);  // what is left of this tile, against the new top
+            }
+        }
+    }
+    if constexpr (K >= 2) heap_sort<K - 1>(kv, iv);
+    Ld = heap_dist(kv);
+    Li = iv;
+}
+
 // libstdc++ on an array of (value, index) pairs in LDS, executed by one lane (M < 64 k: at most ~1100 elements)
 struct SeqPairs {
     float *v;
@@ -375,7 +489,11 @@ template <int D, bool SMALL>
 __device__ __forceinline__ void resolve_ties(float &Ld, int &Li, const float (&qm2)[3], float qq, const float *__restrict__ inp,
                                              int64_t in_sn, int64_t in_sd, int M, int k, int lane, int wave, float *seq_lds, int row_stride,
                                              int wide) {
-    if (!SMALL || k * 64 <= M) {  // std::partial_sort: __heap_select over the row in index order, then __sort_heap
+    if ((!SMALL || k * 64 <= M) && k == 16) {  // (the k of the PointConv / Correlation3D searches)
+        heap_replay_static<D, 16>(Ld, Li, qm2, qq, inp, in_sn, in_sd, M, lane);
+    } else if ((!SMALL || k * 64 <= M) && k == 3) {  // (knn_interpolation, backwarp_3d)
+        heap_replay_static<D, 3>(Ld, Li, qm2, qq, inp, in_sn, in_sd, M, lane);
+    } else if (!SMALL || k * 64 <= M) {  // std::partial_sort: __heap_select over the row in index order, then __sort_heap
         LaneHeap h;
         h.v = INFINITY;
         h.i = 0;
