@@ -44,6 +44,12 @@ RUNTIME = runtime.configure()  # before anything initialises the HIP runtime (gr
 
 import torch  # noqa: E402
 
+RUNTIME.update(torch=torch.__version__, hip=getattr(torch.version, "hip", None))  # what the queue count above was tuned on
+try:
+    RUNTIME["miopen"] = torch.backends.cudnn.version()
+except Exception:  # noqa: BLE001 -- a build without MIOpen reports none
+    RUNTIME["miopen"] = None
+
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (SURVEY.md 8d prices KNN against it)
 H, W, NPTS = 544, 960, 8192  # the correlation microbench's frame (BASELINE config 2) and the default workload's
@@ -76,7 +82,10 @@ def parse():
     p.add_argument("--eval-pinned", action="store_true", help="hold the cached synthetic set in pinned memory (no staging pass)")
     p.add_argument("--eval-distinct", type=int, default=None, help="distinct samples of the evaluation's synthetic set (default: 16 per rank)")
     p.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)  # tests: all ranks on the visible GPU(s), collective on gloo
-    p.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
+    p.add_argument("--backend", choices=["nccl", "gloo", "none"], default="nccl",
+                   help="process-group backend; nccl is RCCL.  A single rank joins a world-size-1 nccl group as well, so the one "
+                        "collective of the evaluation and the timing protocol's barrier / MAX run on RCCL in every run; 'none' "
+                        "(single rank only) skips the group")
     return p.parse_args()
 
 
@@ -322,9 +331,19 @@ def main():
     dev = torch.device("cuda", local_rank % torch.cuda.device_count() if args.share_gpu else local_rank) if on_gpu else torch.device("cpu")
     if on_gpu:
         torch.cuda.set_device(dev)
-    if world > 1:
+    if args.backend == "none" and world > 1:
+        raise SystemExit("--backend none is for a single rank")
+    if world > 1 or (on_gpu and args.backend == "nccl"):
+        # One rank joins a process group too (world size 1 is legal): RCCL is loaded, its watchdog thread runs beside the HIP-graph
+        # capture, and the evaluation's float64[12] SUM all-reduce and the timing protocol's barrier / MAX execute on the real
+        # backend in every run -- what a multi-GPU launch does, short of the xGMI transport (train.py:65 is the reference's set-up).
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
         dist.init_process_group(args.backend, rank=rank, world_size=world, **({"device_id": dev} if (on_gpu and args.backend == "nccl") else {}))
         assert dist.get_world_size() == args.gpus
 
@@ -501,7 +520,8 @@ def main():
                                     + cfg["name"] + "; dense 2D convs/attention excluded"),
                        "frame": [H, W], "points": NPTS, "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "sharding": f"frame pairs over {world} rank(s), no data-path collective",
-                       "launch": launch, "runtime": RUNTIME},
+                       "launch": launch, "runtime": RUNTIME,
+                       "process_group": ("%s, world size %d" % (args.backend, world)) if dist is not None else "none"},
             "roofline": {"kernel": "fps_pruned2_kernel (furthest_point_sampling, 2B clouds 8192 -> 4096)", "bound": "latency",
                          "achieved": round(fps_bytes / fps_us / 1e3, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(fps_bytes / fps_us / 1e3 / HBM_PEAK_GBS, 6), "algorithmic_bytes": fps_bytes,

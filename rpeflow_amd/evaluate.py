@@ -250,12 +250,14 @@ def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=Non
         mark()
         accumulate(acc, out, batch)
         mark()
-    if world_size > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if world_size > 1 or group is not None or (dist.is_available() and dist.is_initialized()):
+        # also with ONE rank inside an initialised process group (bench.py --gpus 1 joins a world-size-1 nccl group): the sum is
+        # the identity there, and the collective has then run on the real backend in every configuration
         if acc.is_cuda and dist.get_backend(group) == "gloo":  # (tests on a one-GPU box: the collective through host memory)
-            host = acc.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-            acc.copy_(host)
+            acc_host = acc.cpu()
+            dist.all_reduce(acc_host, op=dist.ReduceOp.SUM, group=group)
+            acc.copy_(acc_host)
         else:
             dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)  # the one collective of the evaluation
     if stats is not None:
@@ -277,7 +279,7 @@ def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=Non
                 stats["timeline_ms"]["host_in_replay_call_samples"] = [round(x * 1e3, 2) for x in ht[8:20]]
                 stats["timeline_ms"]["host_in_static_copies"] = [round(x * 1e3, 2) for x in forward.host_copy_times[-n:][8:20]]
                 stats["timeline_ms"]["host_loop"] = round((host[-1] - host[0]) / max(1, n - 1) * 1e3 * (n - 1) / n, 3)
-            if pipe.trace:  # per batch, ms relative to the start of batch 8's forward: forward begin/end on the device, its H2D copy's
+            if pipe.trace and len(marks) > 24:  # per batch, ms relative to the start of batch 8's forward: forward begin/end on the device, its H2D copy's
                 base, hbase = marks[24], host[24]  # begin/end on the device, and when the host issued the replay and the copy
                 rows = []
                 for j, begin, done, t_issue in pipe.trace:
@@ -306,7 +308,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    if world > 1:
+    if world > 1 or "MASTER_PORT" in os.environ:  # (a launcher's single rank joins its world-size-1 group as well)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
@@ -323,7 +325,7 @@ def main():
     metrics["seconds"] = round(time.perf_counter() - t0, 3)
     if rank == 0:
         print(json.dumps(metrics))
-    if world > 1:
+    if world > 1 or "MASTER_PORT" in os.environ:
         dist.destroy_process_group()
 
 

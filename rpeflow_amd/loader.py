@@ -118,6 +118,8 @@ class InputPipeline:
         # launches out of three (ROCm 7.2, measured); the host-side wait costs nothing: the event is three batches old.
         self.sync_release = os.environ.get("RPE_PIPE_SYNC_RELEASE", "host")
         self.depth = max(self.depth, int(os.environ.get("RPE_PIPE_DEPTH", self.depth)))
+        # diagnostic (tools/host_rehearsal.py: N ranks sharing ONE PCIe link): move only this fraction of every tensor to the device
+        self.copy_fraction = float(os.environ.get("RPE_PIPE_COPY_FRACTION", "1"))
         self.stats = {"batches": 0, "bytes": 0, "direct": 0}
         self.trace = [] if os.environ.get("RPE_EVAL_TIMELINE") else None  # (batch, copy begin / end events, host time of issue)
         self._threads, self._stop, self._error = [], threading.Event(), None
@@ -221,6 +223,11 @@ class InputPipeline:
                         begin.record(self._copy_stream)
                     if os.environ.get("RPE_PIPE_NOCOPY"):  # diagnostic: everything but the copies themselves
                         pass
+                    elif kind == "slot" and self.copy_fraction < 1:
+                        for k, v in src.items():
+                            m = max(1, int(v[:n].numel() * self.copy_fraction))
+                            dev[k].view(-1)[:m].copy_(v.view(-1)[:m], non_blocking=True)
+                            self.stats["bytes"] += m * v.element_size()
                     elif kind == "slot":
                         for k, v in src.items():
                             dev[k][:n].copy_(v[:n], non_blocking=True)

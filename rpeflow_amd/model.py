@@ -219,11 +219,11 @@ class ResidualBlock(nn.Module):
         # both branches' bias / BatchNorm, the sum and the activation in ONE pass over the two raw convolution outputs
         from .restormer_ops import channel_affine_add_act_, residual_tail_
         raw1 = conv_no_bias_or(self.conv1.conv_fn, self.conv0(x), False).contiguous()
-        key = tuple(id(t) for t in (epi1[1], epi0[1]))
-        if getattr(self, "_shift_key", None) != key:
+        held = getattr(self, "_shift_of", (None, None))  # the two shift tensors the cached sum was made from (held, so
+        if held[0] is not epi1[1] or held[1] is not epi0[1] or not hasattr(self, "_shift_sum"):  # their identity cannot be recycled)
             shifts = [t for t in (epi1[1], epi0[1]) if t is not None]
             self._shift_sum = (shifts[0] + shifts[1]) if len(shifts) == 2 else (shifts[0] if shifts else None)
-            self._shift_key = key
+            self._shift_of = (epi1[1], epi0[1])
         down = self.down0.conv_fn
         if (x.dtype == torch.float32 and x.is_contiguous() and down.kernel_size == (1, 1) and down.padding == (0, 0) and down.groups == 1
                 and down.stride[0] == down.stride[1] and down.in_channels <= 256):

@@ -39,5 +39,16 @@ def configure():
     # tensor op (collate, Tensor.copy_) and gets the whole process throttled.  Read when OpenMP initialises.
     os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # multi-process GPU work on this driver needs dmabuf IPC
-    return {"DEBUG_HIP_FORCE_GRAPH_QUEUES": os.environ["DEBUG_HIP_FORCE_GRAPH_QUEUES"], "OMP_NUM_THREADS": os.environ["OMP_NUM_THREADS"],
-            "miopen_solvers": "library defaults"}
+    out = {"DEBUG_HIP_FORCE_GRAPH_QUEUES": os.environ["DEBUG_HIP_FORCE_GRAPH_QUEUES"], "OMP_NUM_THREADS": os.environ["OMP_NUM_THREADS"],
+           "miopen_solvers": "library defaults"}
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None:  # imported before this call (python -m rpeflow_amd.evaluate, an embedder): libgomp has read the
+        try:               # environment already, so cap the intra-op team through the API and report what is in effect
+            torch.set_num_threads(min(torch.get_num_threads(), int(os.environ["OMP_NUM_THREADS"])))
+        except (RuntimeError, ValueError):
+            pass
+        out["torch_num_threads"] = torch.get_num_threads()
+        out["hip"] = getattr(torch.version, "hip", None)
+        out["torch"] = torch.__version__
+    return out

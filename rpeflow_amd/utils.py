@@ -208,7 +208,7 @@ def im2col_conv(x, weight, bias, stride, padding, dilation, epilogue=None, pendi
     ho = _out_size(H, k[2], stride[0], padding[0], dilation[0])
     wo = _out_size(W, k[3], stride[1], padding[1], dilation[1])
     if x.is_cuda:  # [B, C*kh*kw, ho*wo] in one launch (F.unfold: one per sample)
-        x = _f32(x)
+        x = _f32(x).contiguous()  # the kernel indexes a dense [B, C, H, W]: channels_last or channel-sliced inputs are copied once
         cols = torch.empty((B, k[1] * k[2] * k[3], ho * wo), dtype=torch.float32, device=x.device)
         scale, shift, act = pending if pending is not None else (None, None, None)
         _launch(x, "im2col", _lib.lib().rpe_im2col_act, _ptr(x), B, k[1], H, W, k[2], k[3], stride[0], stride[1], padding[0], padding[1],

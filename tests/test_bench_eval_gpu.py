@@ -25,7 +25,12 @@ def run(*argv):
 
 
 def test_two_ranks_reach_the_metrics_of_one():
-    one = run("--gpus", "1", "--steps", "4")                                  # 16 frame pairs on one rank
+    one = run("--gpus", "1", "--steps", "4")                                  # 16 frame pairs on one rank, inside a world-size-1 RCCL group
+    bare = run("--gpus", "1", "--steps", "4", "--backend", "none")            # the same without any process group
+    # RCCL executed: process group created as a multi-GPU launch creates it (init_process_group("nccl", device_id=dev),
+    # train.py:65), the HIP-graph capture beside its watchdog thread, the float64[12] SUM on the device (utils.py:26-31)
+    assert "(nccl)" in one["eval"]["collective"] and one["eval"]["world_size"] == 1 and "none" in bare["eval"]["collective"]
+    assert one["eval"]["metrics"] == bare["eval"]["metrics"], (one["eval"]["metrics"], bare["eval"]["metrics"])  # SUM over one rank: identity
     two = run("--gpus", "2", "--steps", "2", "--share-gpu", "--backend", "gloo")  # the same 16 over two ranks (8 each)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["eval"]["world_size"] == 2
     assert one["eval"]["samples"] == two["eval"]["samples"] == 16.0

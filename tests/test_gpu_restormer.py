@@ -285,6 +285,24 @@ def test_small_convolutions_are_deterministic_gemms(k, s, p, d, H, W, n):
     assert not wants_im2col(torch.nn.Conv2d(128, 96, 3, 1, 2, 2), big)  # large maps: MIOpen's non-splitting kernels
 
 
+def test_im2col_convolution_takes_strided_inputs():
+    """rpe_im2col_act indexes a dense [B, C, H, W]: a channels_last or channel-sliced map reaching a small dilated / strided
+    3x3 layer is made dense first (round-3 advisor finding: it was read as if dense) -- against F.conv2d on the same views."""
+    from rpeflow_amd.utils import conv_module, wants_im2col
+    torch.manual_seed(11)
+    conv = torch.nn.Conv2d(64, 48, 3, 1, 2, 2).to(DEV)
+    dense = torch.randn(4, 64, 18, 30, device=DEV)
+    wide = torch.randn(4, 96, 18, 30, device=DEV)
+    views = {"dense": dense, "channels_last": dense.contiguous(memory_format=torch.channels_last), "channel slice": wide[:, 16:80],
+             "spatial slice": torch.randn(4, 64, 20, 34, device=DEV)[:, :, 1:19, 2:32], "transposed": dense.transpose(2, 3).contiguous().transpose(2, 3)}
+    with torch.no_grad():
+        for name, x in views.items():
+            assert wants_im2col(conv, x), name
+            assert name == "dense" or not x.is_contiguous(), name
+            ref = F.conv2d(x.contiguous(), conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation)
+            assert (conv_module(conv, x) - ref).abs().max() < 1e-4, name
+
+
 @pytest.mark.parametrize("B,cin,cout,spatial", [(4, 192, 510, (9, 15)), (2, 7, 5, (3, 5)), (8, 67, 96, (500,)), (3, 130, 33, (36, 60)), (1, 4, 16, (64,)),
                                                 (4, 255, 96, (18, 30)), (2, 96, 1020, (135,)), (4, 389, 273, (9, 15)), (1, 66, 17, (7,)), (2, 215, 81, (18, 30))])
 @pytest.mark.parametrize("act", [None, "relu", "leaky_relu"])

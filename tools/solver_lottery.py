@@ -57,7 +57,6 @@ MODES = {
     "default": dict(env={}, pre="", configure_kw=""),
     "immediate": dict(env={}, pre="torch.backends.miopen.immediate = True", configure_kw=""),
     "fast": dict(env={"MIOPEN_FIND_MODE": "2"}, pre="", configure_kw=""),
-    "policy": dict(env={}, pre="", configure_kw="deterministic_convs=True"),
 }
 
 
