@@ -327,6 +327,17 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation in rpeflow_amd")
     if not on_gpu and args.backend != "gloo":
         raise SystemExit("--workload selftest runs on CPU tensors: use --backend gloo")
+    # The line on stdout is the contract: ONE JSON line.  Libraries write there too (RCCL prints a five-line version banner to
+    # stdout when its first communicator comes up), so file descriptor 1 is pointed at stderr for the run and the line goes to
+    # the saved descriptor.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(line) + "\n").encode())
+
     dist = None
     dev = torch.device("cuda", local_rank % torch.cuda.device_count() if args.share_gpu else local_rank) if on_gpu else torch.device("cpu")
     if on_gpu:
@@ -381,7 +392,7 @@ def main():
 
     def finish(line):
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            emit(line)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -549,7 +560,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, args.config)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

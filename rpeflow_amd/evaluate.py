@@ -214,11 +214,13 @@ class GraphedForward:
 
 
 def default_workers():
-    """Loader threads per rank: the cores this process may use (affinity, cgroup quota), shared by the ranks of the node,
-    minus the main and the copy thread; at most 4 (a batch is 0.2 GB of memcpy: two threads keep up with one GPU)."""
+    """Loader threads per rank: the cores this process may use (affinity, cgroup quota), shared by the ranks of the node; at
+    most 4, at least ``RPE_MIN_LOADER_THREADS`` (default 1).  A batch is 0.2 GB of memcpy: one thread stages ~70 batches/s
+    when eight ranks share a 16-core quota (tools/host_rehearsal.py) -- the main and the copy thread of a rank are mostly
+    asleep, so the loaders may use the rank's whole share."""
     from .runtime import usable_cores
     local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    return max(1, min(4, usable_cores() // max(1, local) - 1))
+    return max(int(os.environ.get("RPE_MIN_LOADER_THREADS", "1")), min(4, usable_cores() // max(1, local)))
 
 
 @torch.no_grad()

@@ -108,9 +108,10 @@ MODEL_SEED = 4242
 MODEL_SCALES = [("conv_last_", 0.05), ("linear.", 0.25), ("weight_net1.convs.2", 0.15), ("weight_net2.convs.2", 0.15)]
 
 
-def model_params(shapes):
-    """Seeded parameters for the full model (reference and counterpart alike), keyed by state-dict name."""
-    params = fill_params(shapes, MODEL_SEED)
+def model_params(shapes, seed=MODEL_SEED):
+    """Seeded parameters for the full model (reference and counterpart alike), keyed by state-dict name.  ``seed``: another
+    fill of the same distribution (the stress goldens use a second one)."""
+    params = fill_params(shapes, seed)
     for k in params:
         for pattern, scale in MODEL_SCALES:
             if pattern in k and k.endswith("weight") and params[k].ndim > 1:

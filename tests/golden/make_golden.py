@@ -319,6 +319,40 @@ def gen_model_bench():
          **ids_clouds())
 
 
+@torch.no_grad()
+def gen_model_stress():
+    """Parity of the COMPOSITION off the easy regime (round-3 review): a second seeded parameter fill (STRESS_MODEL_SEED) and
+    large-motion samples (tests/inputs.py frame_pair_stress: rigid motion + N(0, 0.5^2), ~5-10 % of the points projecting
+    outside the frame, zero-mask and NaN pixels in the 2-D target) through the reference on the CPU: 128x192 with every
+    decoder level's flows, 544x960 (BASELINE config 3's frame) and a DSEC-shaped 480x640 with the masked EPEs."""
+    m = reference_model()
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    m.load_state_dict({k: T(v) for k, v in I.model_params(shapes, seed=I.STRESS_MODEL_SEED).items()}, strict=True)
+    m.eval()
+    for name, seed, H, W, dsec in (("model_128x192_stress", 5000, 128, 192, False), ("model_544x960_stress", 5001, 544, 960, False),
+                                   ("model_dsec_480x640_stress", 5002, 480, 640, True)):
+        IDS_LOG.clear()
+        sample = I.frame_pair_stress(seed, H=H, W=W, N=8192, dsec=dsec)
+        batch = {k: T(v)[None] for k, v in sample.items()}
+        levels, decode = {}, m.pwc_fusion_core.decode
+
+        def recording(*a, **k):
+            flows_2d, flows_3d, mi = decode(*a, **k)
+            if H == 128:
+                levels.update({"level%d_flow_2d" % i: f.numpy().copy() for i, f in enumerate(flows_2d)})
+                levels.update({"level%d_flow_3d" % i: f.numpy().copy() for i, f in enumerate(flows_3d)})
+            return flows_2d, flows_3d, mi
+        m.pwc_fusion_core.decode = recording
+        out = m(batch, is_Train=False)
+        m.pwc_fusion_core.decode = decode
+        f2, f3 = out["flow_2d"].numpy(), out["flow_3d"].numpy()
+        assert np.isfinite(f2).all() and np.isfinite(f3).all(), name
+        epe2, epe3 = I.masked_epes(f2[0], f3[0], sample)
+        print(name, "flow_2d |max|", np.abs(f2).max(), "flow_3d |max|", np.abs(f3).max(), "EPE", epe2, epe3)
+        save(name, **({"flow_2d": f2} if H == 128 else {"flow_2d_s8": f2[:, :, ::8, ::8].copy()}), flow_3d=f3,
+             epe2d=np.float64(epe2), epe3d=np.float64(epe3), **ids_clouds(), **levels)
+
+
 def gen_eval():
     """The reference's evaluation loops themselves (eval_withocc.py:45-135, eval_noocc.py:45-116), unmodified, over the
     synthetic frame pairs and the stand-in predictions of tests/test_evaluate.py; stored: the accumulated metric sums.
@@ -382,6 +416,6 @@ def gen_eval():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval", "fblocks", "model_bench", "model_bench_dsec"]
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval", "fblocks", "model_bench", "model_bench_dsec", "model_stress"]
     for w in which:
         globals()["gen_" + w]()

@@ -53,3 +53,50 @@ def frame_pair(seed, H=544, W=960, N=8192, f=1050.0, dsec=False):
     because bench and the harness use it too."""
     from rpeflow_amd.synthetic import frame_pair as gen
     return gen(seed, H, W, N, f, dsec)
+
+
+STRESS_MODEL_SEED = 31337  # the second parameter fill (model_*_stress goldens)
+
+
+def frame_pair_stress(seed, H=544, W=960, N=8192, f=1050.0, dsec=False):
+    """A LARGE-MOTION sample for the composition's parity (round-3 review, weak #1): the second cloud is a rigid motion of the
+    first (a 2-degree rotation about the vertical axis + a translation) plus N(0, 0.5^2) noise (lateral parts scaled by W / 960), about 5 % of the points of
+    either cloud project outside the frame (so grid_sample_wrapper's zero padding, the nearest-pixel search off the raster and
+    backwarp's border clamp all take part), and the 2-D targets carry zero-mask and NaN pixels as DSEC's do
+    (eval_noocc.py:57-99 masks both).  Same keys and dtypes as frame_pair."""
+    r = np.random.default_rng(seed)
+    cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
+    images = r.integers(0, 256, (6, H, W), dtype=np.uint8)
+    event_voxel = r.standard_normal((20, H, W), dtype=np.float32)
+    z = r.uniform(4.0, 35.0, N)
+    m = 0.013  # margin on each side: (1 + 2m)^2 - 1 = 5.3 % of the area lies outside the frame
+    u = r.uniform(-m * W, (1 + m) * W - 1.0, N)
+    v = r.uniform(-m * H, (1 + m) * H - 1.0, N)
+    pc1 = np.stack([(u - cx) * z / f, (v - cy) * z / f, z])
+    g = W / 960.0  # the image-plane part of the motion scales with the frame, so that small test frames keep most points inside
+    a = np.deg2rad(2.0 * g)
+    rot = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    pc2 = rot @ pc1 + np.array([[0.6 * g], [-0.25 * g], [0.8]]) + r.standard_normal((3, N)) * np.array([[0.5 * g], [0.5 * g], [0.5]])
+    pc2[2] = np.maximum(pc2[2], 1.0)  # depth stays in front of the camera (the IDS transform takes its logarithm)
+    pc1, pc2 = pc1.astype(np.float32), pc2.astype(np.float32)
+    flow_2d = np.concatenate([r.standard_normal((2, H, W)) * 25.0, (r.random((1, H, W)) < 0.85)]).astype(np.float32)
+    flow_2d[:2][:, r.random((H, W)) < 0.01] = np.nan
+    flow_3d = (pc2 - pc1).astype(np.float32)
+    sample = {"images": images, "event_voxel": event_voxel, "pcs": np.concatenate([pc1, pc2]).astype(np.float32),
+              "flow_2d": flow_2d, "flow_3d": flow_3d, "intrinsics": np.array([f, cx, cy], np.float32)}
+    if dsec:
+        sample["flow_3d"] = np.concatenate([flow_3d, (r.random((1, N)) < 0.9).astype(np.float32)])
+    else:
+        sample["occ_mask_3d"] = (r.random(N) < 0.2).astype(np.float32)
+    return sample
+
+
+def masked_epes(flow_2d, flow_3d, sample):
+    """EPE2D / EPE3D of one sample's prediction as the evaluators count them (eval_withocc.py:71-87, eval_noocc.py:57-75):
+    pixels / points with a zero mask channel or a NaN end-point error are left out."""
+    t2, t3 = sample["flow_2d"], sample["flow_3d"]
+    e2 = np.sqrt(((flow_2d - t2[:2]) ** 2).sum(0))
+    m2 = (t2[2] > 0 if t2.shape[0] > 2 else np.ones_like(e2, bool)) & ~np.isnan(e2)
+    e3 = np.sqrt(((flow_3d - t3[:3]) ** 2).sum(0))
+    m3 = (t3[3] > 0 if t3.shape[0] > 3 else np.ones_like(e3, bool)) & ~np.isnan(e3)
+    return float(e2[m2].astype(np.float64).mean()), float(e3[m3].astype(np.float64).mean())
