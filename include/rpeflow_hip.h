@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 4
+#define RPE_ABI_VERSION 5
 
 #define RPE_EINVAL (-1)       /* bad size / null pointer */
 #define RPE_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
@@ -80,6 +80,18 @@ typedef struct rpe_knn_job {
     float *dist;                    /* [B,Q,k] or NULL */
 } rpe_knn_job;
 int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, int tie_mode, rpe_stream_t stream);
+
+/* k = 1, D = 2 on a cloud binned into a uniform cell grid (csrc/knn_binned.hip): the nearest projected point of every pixel
+ * (RPEFlow_core.py:327-330 -> wrapper.py:106-127).  idx / dist are EXACTLY rpe_knn(..., D = 2, k = 1, any tie_mode)'s for any
+ * queries (M >= 64); spatially coherent query order (a raster) is what makes it fast: a wave's 64 consecutive queries meet
+ * only the points of the cells around their bounding box, every candidate evaluated with the arithmetic above, lowest index
+ * among equal distances.  Two launches (bin the cloud, search); `workspace` (16-byte aligned device memory of
+ * rpe_knn_nearest2d_workspace_bytes(B, M) bytes) holds the binned cloud between them and may be reused afterwards.        */
+int64_t rpe_knn_nearest2d_workspace_bytes(int B, int M);
+int rpe_knn_nearest2d(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd,
+                      const float *query, int64_t q_sb, int64_t q_sn, int64_t q_sd,
+                      int B, int M, int Q, int64_t *idx, float *dist,
+                      void *workspace, int64_t workspace_bytes, rpe_stream_t stream);
 
 /* The same search on spatially ordered point sets (k >= 2; csrc/knn_grid.h).  rpe_knn_grid_build puts a set [B,N,D] into
  * Morton-cell order: `sorted` [B][Npad/64][4][64] (one 1-KiB record per 64 points: coordinate rows, then |p|^2; Npad = N rounded up to 64; layout in csrc/knn_grid.h), `perm` [B][Npad] (original

@@ -52,6 +52,9 @@ _PROTOTYPES = {
     "rpe_corr3d_n2n": [_c_ptr] * 7 + [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_correlation2d_backward": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_knn_multi": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr],
+    "rpe_knn_nearest2d_workspace_bytes": [_c_int, _c_int],
+    "rpe_knn_nearest2d": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_ptr, _c_ptr,
+                          _c_ptr, _c_i64, _c_ptr],
     "rpe_debug_stamp": [_c_ptr, _c_ptr],
     "rpe_knn_grid_set_stats": [_c_ptr],
     "rpe_knn_grid_sizes": [_c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
@@ -92,7 +95,7 @@ _PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 4  # RPE_ABI_VERSION of include/rpeflow_hip.h
+ABI_VERSION = 5  # RPE_ABI_VERSION of include/rpeflow_hip.h
 KNN_TIES = {"torch": 3, "set": 1, "index": 0}  # RPE_KNN_TIES_* (how equal distances are resolved)
 
 
@@ -120,6 +123,7 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = _c_int
         handle.rpe_channel_attention_workspace_floats.restype = _c_i64
+        handle.rpe_knn_nearest2d_workspace_bytes.restype = _c_i64
         handle.rpe_error_string.argtypes = [_c_int]
         handle.rpe_error_string.restype = ctypes.c_char_p
         if handle.rpe_abi_version() != ABI_VERSION:

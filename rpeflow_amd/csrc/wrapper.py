@@ -155,13 +155,21 @@ def _same_view(a, b):
 _GRID_MIN_M, _GRID_MIN_QUERIES = 1 << 30, 16384  # (not yet faster than the sweep anywhere: explicit algo="grid" only)
 
 
+# the binned nearest-point search (csrc/knn_binned.hip: k = 1, D = 2) against the sweeping kernels: two launches (8 us to bin
+# the clouds, then a search whose waves meet ~50 points instead of the whole cloud).  Measured, both frames of a batch of 4
+# (tools/knn2d_bench.py, kernel time): 4096 points / 144 x 240 queries 8 + 22 us against 201; 2048 / 72 x 120: 8 + 13 against 34;
+# 1024 / 36 x 60: 8 + 10 against 10 -- from 2048 points on
+_BINNED_MIN_M, _BINNED_MIN_QUERIES = 2048, 16384
+
+
 def k_nearest_neighbor_ties(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cpp_impl=True, ties="torch", algo="auto",
                             input_grid=None, query_grid=None, return_distances=False):
     """k_nearest_neighbor with the treatment of EQUAL distances chosen per call (no global state): "torch" -- as above;
     "set" -- the reference's neighbour SET, equal distances inside it in index order (cheaper); "index" -- lowest index
     first (RPE_KNN_TIES_* of include/rpeflow_hip.h).
     ``algo``: "auto" | "grid" (spatially ordered sets, csrc/knn_grid.h; raises where the kernel does not apply) | "sweep"
-    (every query against every point); identical results either way.  ``input_grid`` / ``query_grid``: GridSet of the
+    (every query against every point) | "binned" (k = 1, D = 2: the cloud in a uniform cell grid, csrc/knn_binned.hip; what
+    "auto" picks for the model's nearest-projected-point searches); identical results whichever runs.  ``input_grid`` / ``query_grid``: GridSet of the
     cloud / the queries when the caller holds one (a cloud is searched several times per pyramid level)."""
     _as_points(input_xyz, "k_nearest_neighbor", "input_xyz")
     _as_points(query_xyz, "k_nearest_neighbor", "query_xyz")
@@ -185,8 +193,16 @@ def k_nearest_neighbor_ties(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k:
     if algo == "grid" and not grid_ok:
         raise RuntimeError("k_nearest_neighbor: the grid kernel takes 2 <= k <= 31 (30 with tie handling), 64 k <= M <= 16384")
     use_grid = grid_ok and (algo == "grid" or (algo == "auto" and (input_grid is not None or (M >= _GRID_MIN_M and B * Q >= _GRID_MIN_QUERIES))))
+    use_binned = (algo in ("auto", "binned") and D == 2 and k == 1 and not use_grid and M >= 64
+                  and (algo == "binned" or (M >= _BINNED_MIN_M and B * Q >= _BINNED_MIN_QUERIES)))
+    if algo == "binned" and not use_binned:
+        raise RuntimeError("k_nearest_neighbor: the binned search takes k = 1, D = 2, M >= 64")
     with torch.cuda.device(input_xyz.device):
-        if use_grid:
+        if use_binned:  # (the result does not depend on the tie mode: k = 1 keeps the lowest index among equal distances)
+            work = torch.empty(lib.rpe_knn_nearest2d_workspace_bytes(B, M), dtype=torch.uint8, device=input_xyz.device)
+            rc = lib.rpe_knn_nearest2d(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(), B, M, Q, _ptr(idx),
+                                       _ptr(dist) if dist is not None else _NULL, _ptr(work), work.numel(), _lib.stream_of(input_xyz))
+        elif use_grid:
             gi = input_grid if input_grid is not None else GridSet(input_xyz)
             gq = query_grid if query_grid is not None else (gi if _same_view(input_xyz, query_xyz) else GridSet(query_xyz))
             assert gi.shape == (B, M, D) and gq.shape == (B, Q, D), "GridSet built from another point set"

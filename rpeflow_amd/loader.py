@@ -235,6 +235,11 @@ class InputPipeline:
                     else:
                         for s, sample in enumerate(src):
                             for k, v in sample.items():
+                                if self.copy_fraction < 1:
+                                    m = max(1, int(v.numel() * self.copy_fraction))
+                                    dev[k][s].view(-1)[:m].copy_(v.view(-1)[:m], non_blocking=True)
+                                    self.stats["bytes"] += m * v.element_size()
+                                    continue
                                 dev[k][s].copy_(v, non_blocking=True)
                                 self.stats["bytes"] += v.numel() * v.element_size()
                         self.stats["direct"] += 1
