@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 5
+#define RPE_ABI_VERSION 6
 
 #define RPE_EINVAL (-1)       /* bad size / null pointer */
 #define RPE_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
@@ -46,11 +46,11 @@ const char *rpe_error_string(int code);
  * (k_nearest_neighbor.cpp:3-4, kernels k_nearest_neighbor_kernel.cu:8-112) with
  * the arithmetic of the CPU fallback (wrapper.py:40-52,115-117):
  *   d = fl(fl(-2*dot + |q|^2) + |p|^2), dot = fma(q2,p2,fma(q1,p1,q0*p0)),
- * k smallest, ascending.  tie_mode says what happens to EQUAL distances (the reference is matmul + torch.topk on the
- * CPU, i.e. libstdc++'s partial_sort / nth_element + sort, restated in knn.hip; k <= 63):
+ * k smallest, ascending.  `mode` = one RPE_KNN_TIES_* value (what happens to EQUAL distances: the reference is matmul +
+ * torch.topk on the CPU, i.e. libstdc++'s partial_sort / nth_element + sort, restated in knn.hip; k <= 63), optionally OR-ed
+ * with one RPE_KNN_ALGO_* flag:
  *   RPE_KNN_TIES_TORCH  any tie among the k+1 best makes the query redo its selection exactly as torch.topk does it:
- *                       indices equal the reference's position for position (the few waves that redo run much longer:
- *                       +45 % on a 8192 -> 4096, k = 16 search, 1 % on the whole forward);
+ *                       indices equal the reference's position for position;
  *   RPE_KNN_TIES_SET    only a tie between the k-th and the (k+1)-th distance triggers the redo: the returned neighbour
  *                       SET still always equals the reference's, equal distances inside the top k stay in index order;
  *   RPE_KNN_TIES_INDEX  lowest index first everywhere (no redo).
@@ -58,17 +58,31 @@ const char *rpe_error_string(int code);
  *   input[b][m][d] = input[b*in_sb + m*in_sn + d*in_sd], same for query,
  * so channel-first callers need no transpose (wrapper.py:119-122 does one).
  * idx  [B,Q,k] int64 contiguous; dist [B,Q,k] fp32 contiguous or NULL.
- * Limits: 1 <= D <= 3, 1 <= k <= 64, k <= M (k = 64: index order whatever the mode).            */
+ * Limits: 1 <= D <= 3, 1 <= k <= 64, k <= M (k = 64: index order whatever the mode).
+ *
+ * `workspace`: optional scratch (NULL, or 16-byte aligned device memory of at least rpe_knn_workspace_bytes(B, M, Q, D, k, mode)
+ * bytes; uninitialised, free again when the call's kernels have run).  Results never depend on it; with it
+ *   - k = 1, D = 2 searches of large clouds (the nearest projected point of every pixel, RPEFlow_core.py:327-330) run on a
+ *     cloud binned into a uniform cell grid (csrc/knn_binned.hip: a wave's queries meet only the points of the cells around
+ *     them; exact for any queries, fast for spatially coherent query order such as a raster): two launches;
+ *   - the tied rows of a large k >= 2 search are redone by a second launch spread over the whole chip instead of by the waves
+ *     that found them at the end of the first (csrc/knn.hip, knn_tie_replay_kernel).
+ * RPE_KNN_ALGO_SWEEP: every query against every point whatever the sizes; RPE_KNN_ALGO_BINNED: the binned search or an error
+ * (RPE_EUNSUPPORTED unless k = 1, D = 2, M >= 64; RPE_EINVAL without enough workspace) -- for cross-checks.              */
 #define RPE_KNN_TIES_INDEX 0
 #define RPE_KNN_TIES_SET 1
 #define RPE_KNN_TIES_TORCH 3
+#define RPE_KNN_ALGO_SWEEP 0x100
+#define RPE_KNN_ALGO_BINNED 0x200
+int64_t rpe_knn_workspace_bytes(int B, int M, int Q, int D, int k, int mode);
 int rpe_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd,
             const float *query, int64_t q_sb, int64_t q_sn, int64_t q_sd,
-            int B, int M, int Q, int D, int k, int tie_mode,
-            int64_t *idx, float *dist, rpe_stream_t stream);
+            int B, int M, int Q, int D, int k, int mode,
+            int64_t *idx, float *dist, void *workspace, int64_t workspace_bytes, rpe_stream_t stream);
 
-/* Several searches with the same (B, D, k) in ONE launch: job i is rpe_knn(jobs[i]...) exactly.  The PointConv pyramid's
- * per-level searches (pointconv.py:46) depend on the sampled coordinates only and are issued together.            */
+/* Several searches with the same (B, D, k) in ONE call: job i is rpe_knn(jobs[i]...) exactly; jobs of one kind share a launch.
+ * The PointConv pyramid's per-level searches (pointconv.py:46) depend on the sampled coordinates only and are issued together.
+ * workspace: the jobs take rpe_knn_workspace_bytes(B, M_i, Q_i, D, k, mode) bytes each, in job order (pass the sum).       */
 #define RPE_KNN_MAX_JOBS 8
 typedef struct rpe_knn_job {
     const float *input;
@@ -79,40 +93,8 @@ typedef struct rpe_knn_job {
     int64_t *idx;                   /* [B,Q,k] */
     float *dist;                    /* [B,Q,k] or NULL */
 } rpe_knn_job;
-int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, int tie_mode, rpe_stream_t stream);
-
-/* k = 1, D = 2 on a cloud binned into a uniform cell grid (csrc/knn_binned.hip): the nearest projected point of every pixel
- * (RPEFlow_core.py:327-330 -> wrapper.py:106-127).  idx / dist are EXACTLY rpe_knn(..., D = 2, k = 1, any tie_mode)'s for any
- * queries (M >= 64); spatially coherent query order (a raster) is what makes it fast: a wave's 64 consecutive queries meet
- * only the points of the cells around their bounding box, every candidate evaluated with the arithmetic above, lowest index
- * among equal distances.  Two launches (bin the cloud, search); `workspace` (16-byte aligned device memory of
- * rpe_knn_nearest2d_workspace_bytes(B, M) bytes) holds the binned cloud between them and may be reused afterwards.        */
-int64_t rpe_knn_nearest2d_workspace_bytes(int B, int M);
-int rpe_knn_nearest2d(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd,
-                      const float *query, int64_t q_sb, int64_t q_sn, int64_t q_sd,
-                      int B, int M, int Q, int64_t *idx, float *dist,
-                      void *workspace, int64_t workspace_bytes, rpe_stream_t stream);
-
-/* The same search on spatially ordered point sets (k >= 2; csrc/knn_grid.h).  rpe_knn_grid_build puts a set [B,N,D] into
- * Morton-cell order: `sorted` [B][Npad/64][4][64] (one 1-KiB record per 64 points: coordinate rows, then |p|^2; Npad = N rounded up to 64; layout in csrc/knn_grid.h), `perm` [B][Npad] (original
- * index of every sorted position), `boxes` [B][Npad/64 + 1][8] (bounding box of every 64-point step); buffer sizes PER
- * BATCH ELEMENT from rpe_knn_grid_sizes.  rpe_knn_grid_search then returns exactly rpe_knn's idx / dist for the ORIGINAL
- * arrays (which it still takes: equal distances are resolved on them) while computing distances only to the steps
- * whose box can hold a neighbour.  One built set serves every search on that cloud; the queries are a built set too (the
- * cloud's own for a self search).  rpe_knn_grid_supported: 1 if (B, M, Q, D, k, tie_mode) is a case the kernel takes
- * (2 <= k, k + 1 <= 32, 64 k <= M <= 16384), else use rpe_knn.                                                        */
-int rpe_knn_grid_sizes(int N, int D, int64_t *sorted_floats, int64_t *perm_ints, int64_t *box_floats);
-int rpe_knn_grid_build(const float *pts, int64_t sb, int64_t sn, int64_t sd, int B, int N, int D, float *sorted, int32_t *perm,
-                       float *boxes, rpe_stream_t stream);
-int rpe_knn_grid_supported(int B, int M, int Q, int D, int k, int tie_mode);
-int rpe_knn_grid_search(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,
-                        int64_t q_sn, int64_t q_sd, int B, int M, int Q, int D, int k, int tie_mode,
-                        const float *in_sorted, const int32_t *in_perm, const float *in_boxes, const float *q_sorted,
-                        const int32_t *q_perm, int64_t *idx, float *dist, rpe_stream_t stream);
-
-/* Diagnostics: while `stats16` (16 zeroed uint64 in device memory) is set, every rpe_knn_grid_search launch adds per-wave counts
- * and clock cycles to it (csrc/knn_grid.h, g_grid_stats); NULL switches it off again.  Synchronous (hipMemcpyToSymbol).   */
-int rpe_knn_grid_set_stats(unsigned long long *stats16);
+int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, int mode, void *workspace, int64_t workspace_bytes,
+                  rpe_stream_t stream);
 
 /* ---- squared_distance (wrapper.py:40-52) ------------------------------------
  * out[b][i][j] = distance above between xyz1[b][i] and xyz2[b][j]; out contiguous. */
@@ -135,7 +117,6 @@ int rpe_fps(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
 #define RPE_FPS_AUTO 0
 #define RPE_FPS_PLAIN 1
 #define RPE_FPS_PRUNED 2
-#define RPE_FPS_PAIRED 3 /* the pruned kernel emitting two samples per synchronisation round where the sequential rule provably gives them */
 int rpe_fps_algo(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
                  int B, int N, int S, int64_t *idx, int algo, rpe_stream_t stream);
 
@@ -172,28 +153,24 @@ int rpe_gather_channel_last(const float *data, int64_t sb, int64_t sn, int64_t s
 
 /* rpe_pointwise_conv: a stride-1 1x1 convolution with its epilogue in one launch (csrc/pointwise.hip; models/utils.py:7-62,
  * models/restormer_arch.py:88-110):  y[b][o][p] = act(scale[o] * sum_c W[o][c] x[b][c][p] + shift[o]) (+ residual[b][o][p]).
- * x [B,Cin,P], y / residual [B,Cout,P] contiguous fp32; packed_weight [ceil(Cout/16)][ceil(Cin/4)][64]: entry (ot, kt, 16 k + i)
- * = W[16 ot + i][4 kt + k], zero outside (the MFMA A-fragment order); scale / shift / residual may be NULL; act 0 none,
- * 1 relu, 2 leaky_relu(slope).  Meant for the latency-bound layers (below ~0.5 GFLOP); deterministic.                  */
-int rpe_pointwise_conv(const float *x, int B, int Cin, int64_t P, const float *packed_weight, int Cout, const float *scale,
-                       const float *shift, int act, float slope, const float *residual, float *y, rpe_stream_t stream);
-/* The same with a batch stride for x (a channel slice of a wider tensor) and, with weight_batch_stride > 0, ONE PACKED WEIGHT
- * PER SAMPLE: y[b] = W[b] x[b] (+ ...), W[b] at packed_weight + b * weight_batch_stride -- the channel attention's per-sample
- * matrix M[b] (rpe_channel_attention_matrix_packed) applied to v[b] with the block's residual in the epilogue.          */
-int rpe_pointwise_conv_strided(const float *x, int64_t x_batch_stride, int B, int Cin, int64_t P, const float *packed_weight,
-                               int64_t weight_batch_stride, int Cout, const float *scale, const float *shift, int act, float slope,
-                               const float *residual, float *y, rpe_stream_t stream);
+ * x [B,Cin,P] with batch stride x_batch_stride floats (Cin * P for a dense tensor; larger for a channel slice of a wider one),
+ * y / residual [B,Cout,P] contiguous fp32; packed_weight [ceil(Cout/16)][ceil(Cin/4)][64]: entry (ot, kt, 16 k + i)
+ * = W[16 ot + i][4 kt + k], zero outside (the MFMA A-fragment order); weight_batch_stride 0: one weight for the batch, > 0: ONE
+ * PACKED WEIGHT PER SAMPLE, W[b] at packed_weight + b * weight_batch_stride -- the channel attention's per-sample matrix M[b]
+ * (rpe_channel_attention_matrix, packed = 1) applied to v[b] with the block's residual in the epilogue; scale / shift /
+ * residual may be NULL; act 0 none, 1 relu, 2 leaky_relu(slope).  Meant for the latency-bound layers (below ~0.5 GFLOP);
+ * deterministic.                                                                                                       */
+int rpe_pointwise_conv(const float *x, int64_t x_batch_stride, int B, int Cin, int64_t P, const float *packed_weight,
+                       int64_t weight_batch_stride, int Cout, const float *scale, const float *shift, int act, float slope,
+                       const float *residual, float *y, rpe_stream_t stream);
 /* rpe_im2col: cols [B, C*kh*kw, Ho*Wo] = torch.nn.functional.unfold(x [B,C,H,W], (kh,kw), dilation, padding, stride) for the whole
  * batch in one launch: the input side of the small convolutions that run as one deterministic GEMM instead of MIOpen's
- * atomically accumulating split-K kernels (rpeflow_amd/utils.py, wants_im2col).                                    */
+ * atomically accumulating split-K kernels (rpeflow_amd/utils.py, wants_im2col) -- with the per-channel epilogue of the layer
+ * that produced x applied to every value read: act(in_scale[c] * x + in_shift[c]), act 0 none / 1 ReLU / 2 LeakyReLU(in_slope),
+ * padding stays 0, so that a run of such convolutions (the context network's dilated layers, the coarsest level's estimators)
+ * needs no pass of its own for bias / BatchNorm / activation between two layers.  in_scale / in_shift may be NULL (1 / 0).  */
 int rpe_im2col(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
-               float *cols, rpe_stream_t stream);
-/* rpe_im2col_act: the same with the per-channel epilogue of the layer that produced x applied to every value read --
- *   act(in_scale[c] * x + in_shift[c]), act 0 none / 1 ReLU / 2 LeakyReLU(in_slope), padding stays 0 -- so that a run of im2col
- *   convolutions (the context network's dilated layers, the coarsest level's estimators) needs no pass of its own for bias /
- *   BatchNorm / activation between two layers.  in_scale / in_shift may be NULL (1 / 0).                                   */
-int rpe_im2col_act(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
-                   const float *in_scale, const float *in_shift, int in_act, float in_slope, float *cols, rpe_stream_t stream);
+               const float *in_scale, const float *in_shift, int in_act, float in_slope, float *cols, rpe_stream_t stream);
 
 /* ---- knn_interpolation after its KNN (models/utils.py:148-154) ------------------
  * w_j = 1/max(||in_xyz[:,knn_j] - q_xyz||_2, 1e-8), normalised over the k neighbours;
@@ -257,28 +234,19 @@ int rpe_ids_flow_inverse(const float *xyz, int64_t x_sb, int64_t x_sc, int64_t x
  *   out[b][0:2][p] = xy[b][:,i] - (p%W, p/W);  out[b][2][p] = mean_c(sample(feat_2d, xy_i)[c]*feat_2d[b][c][p]);
  *   out[b][3+c][p] = feat_3d[b][c][i].   feat_2d [B,C2,H,W] contiguous, out [B,C3+3,H,W].
  * workspace: B*N*(C2+C3) floats of scratch (per-point rows: the samples are taken once per
- * point, as the reference does, then gathered per pixel).                                  */
-int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
-                             const float *feat_2d, int C2, int H, int W,
+ * point, as the reference does, then gathered per pixel).
+ * sampled_2d [B,C2,N] through element strides (batch, channel, point), or NULL: what grid_sample_wrapper(feat_2d, xy) returned --
+ *   the 3-D fuser of the same (map, points) pair computes it anyway (RPEFlow_core.py:334-337, 394-395), and the per-point
+ *   bilinear taps are the expensive half of this operator.
+ * The two element-wise steps the 2-D correlation fuser puts behind the operator (RPEFlow_core.py:82-83) ride in the launch:
+ *   `subtract` [B, n_subtract, H*W] is subtracted from the LAST n_subtract projected channels ("projected 3-D flow minus the
+ *   2-D flow") and `append` [B, n_append, H*W] is copied behind the C3 + 3 channels (the cat with the event features):
+ *   out [B, C3 + 3 + n_append, H, W].  Either may be NULL with a count of 0.                                              */
+int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
+                             int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
                              const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
-                             const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream);
-/* The same with sample(feat_2d, xy) handed in: sampled_2d [B,C2,N] through element strides (batch, channel, point) is what
- * grid_sample_wrapper(feat_2d, xy) returned -- the 3-D fuser of the same (map, points) pair computes it anyway
- * (RPEFlow_core.py:334-337, 394-395), and the per-point bilinear taps are the expensive half of this operator.  NULL: as above. */
-int rpe_project_feat_nn_corr_sampled(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
-                                     const float *feat_2d, int C2, int H, int W,
-                                     const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
-                                     const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
-                                     const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream);
-/* rpe_project_feat_nn_corr_fused: the same with the two element-wise steps the 2-D correlation fuser puts behind it
- *   (RPEFlow_core.py:82-83) inside the launch: `subtract` [B, n_subtract, H*W] is subtracted from the LAST n_subtract projected
- *   channels ("projected 3-D flow minus the 2-D flow") and `append` [B, n_append, H*W] is copied behind the C3 + 3 channels
- *   (the cat with the event features): out [B, C3 + 3 + n_append, H, W].  Either may be NULL with a count of 0.          */
-int rpe_project_feat_nn_corr_fused(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
-                                   int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
-                                   const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
-                                   const int64_t *nn_idx, const float *subtract, int n_subtract, const float *append, int n_append,
-                                   int B, int N, float *workspace, float *out, rpe_stream_t stream);
+                             const int64_t *nn_idx, const float *subtract, int n_subtract, const float *append, int n_append,
+                             int B, int N, float *workspace, float *out, rpe_stream_t stream);
 
 /* ---- PointConv in one kernel (models/pointconv.py:33-61, 90-122) -----------------
  * rpe_pointconv_pack_rows: rows[b][m][:] = [xyz[b][:,m] | srcs[0][b][:,m] | ... | zeros] -- cat([xyz, features]) channel-last
@@ -365,13 +333,11 @@ int rpe_corr3d_n2n(const float *p2n_rows, const float *n_w1, const float *n_b1, 
 int rpe_dwconv3(const float *in0, int C0, const float *in1, int C1, const float *in2, int C2,
                 const float *weight, const float *bias, int B, int H, int W, int kh, int gate,
                 float *out, rpe_stream_t stream);
-int rpe_channel_layernorm(const float *x, const float *weight, const float *bias, int B, int C, int64_t P,
-                          float eps, float *out, rpe_stream_t stream);
-/* two tensors of one shape [B,C,P], each with its own affine parameters, in one launch: norm1x(x), norm1y(y) of the
- * cross blocks (restormer_arch.py:218, 298) */
-int rpe_channel_layernorm_pair(const float *x0, const float *weight0, const float *bias0, float *out0,
-                               const float *x1, const float *weight1, const float *bias1, float *out1,
-                               int B, int C, int64_t P, float eps, rpe_stream_t stream);
+/* (x1 .. out1: a second tensor of the same shape with its own affine parameters in the same launch -- norm1x(x), norm1y(y) of
+ * the cross blocks, restormer_arch.py:218, 298 -- or NULL)                                                                  */
+int rpe_channel_layernorm(const float *x0, const float *weight0, const float *bias0, float *out0,
+                          const float *x1, const float *weight1, const float *bias1, float *out1,
+                          int B, int C, int64_t P, float eps, rpe_stream_t stream);
 /* rpe_channel_attention_matrix: the attention core of Mutual_Attention{2D,3D}.forward (restormer_arch.py:184-203,
  *   265-282) up to and including project_out, as a per-batch C x C matrix (C = heads * c):
  *     attn_h = softmax_j( normalize(q_h) normalize(k_h)^T * temperature[h] ),  F.normalize over the P positions (eps),
@@ -380,14 +346,11 @@ int rpe_channel_layernorm_pair(const float *x0, const float *weight0, const floa
  *   q, k: [B][C][P] fp32 with row stride P and the given batch stride in floats (views into the qkv tensor).
  *   c <= 96.  workspace: rpe_channel_attention_workspace_floats(B, heads, c, P) floats.                         */
 int64_t rpe_channel_attention_workspace_floats(int B, int heads, int c, int64_t P);
+/*   packed = 1: every m_out[b] in rpe_pointwise_conv's weight-fragment order ([ceil(C/16)][ceil(C/4)][64] floats per sample, zero
+ *   outside): the block then ends with ONE rpe_pointwise_conv launch, out = residual + m[b] v[b].                            */
 int rpe_channel_attention_matrix(const float *q, const float *k, int64_t batch_stride, const float *temperature,
                                  const float *w_out, int B, int heads, int c, int64_t P, float eps,
-                                 float *workspace, float *m_out, rpe_stream_t stream);
-/* The same, with every m_out[b] written in rpe_pointwise_conv's weight-fragment order ([ceil(C/16)][ceil(C/4)][64] floats per
- *   sample, zero outside): the block then ends with ONE rpe_pointwise_conv_strided launch, out = residual + m[b] v[b].   */
-int rpe_channel_attention_matrix_packed(const float *q, const float *k, int64_t batch_stride, const float *temperature,
-                                        const float *w_out, int B, int heads, int c, int64_t P, float eps,
-                                        float *workspace, float *m_packed, rpe_stream_t stream);
+                                 float *workspace, float *m_out, int packed, rpe_stream_t stream);
 /* rpe_convex_upsample: RAFT-style convex up-sampling of a 2-D flow (models/utils.py:201-214):
  *   out[b][c][h*s+i][w*s+j] = sum_k softmax_k(mask[b][k*s*s + i*s + j][h][w]) * s * flow[b][c][h + k/3 - 1][w + k%3 - 1]
  *   (zero outside).  flow [B,2,H,W], mask [B,9*s*s,H,W], out [B,2,H*s,W*s]; s in {2,4,8}.                        */
@@ -435,13 +398,16 @@ int rpe_eval_accumulate(const float *flow2d, const float *target2d, int target2d
                         double *workspace, double *acc, rpe_stream_t stream);
 
 /* ---- diagnostics -------------------------------------------------------------
- * Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation
+ * Writes the GPU's constant-rate clock (100 MHz wall_clock64) to *slot when the stream reaches this point: a
+ * one-thread kernel, usable inside a captured HIP graph, for timelines of multi-stream replays that rocprofv3
+ * serialises (rpeflow_amd.model.Stamps, tools/stamp_timeline.py).                                             */
+int rpe_debug_stamp(unsigned long long *slot, rpe_stream_t stream);
+
+#ifdef RPE_EXPERIMENTAL /* only in a library built with -DRPE_EXPERIMENTAL (python -m rpeflow_amd.build --experimental) */
+/* Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation
  * kernel relies on: out[64*4] = D for A[lane]=lane, B[lane]=100*lane (one K).   */
 int rpe_probe_mfma4x4(float *out256, rpe_stream_t stream);
-/* Writes the GPU's constant-rate clock (100 MHz wall_clock64) to *slot when the stream reaches this point: a
- * one-thread kernel, usable inside a captured HIP graph, for timelines of multi-stream replays that rocprofv3
- * serialises.                                                                                               */
-int rpe_debug_stamp(unsigned long long *slot, rpe_stream_t stream);
+#endif
 
 #ifdef __cplusplus
 }

@@ -20,26 +20,21 @@ _c_ptr = ctypes.c_void_p
 # name -> argtypes, exactly the prototypes of include/rpeflow_hip.h
 _PROTOTYPES = {
     "rpe_abi_version": [],
+    "rpe_knn_workspace_bytes": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int],
     "rpe_knn": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
-                _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
+                _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_i64, _c_ptr],
     "rpe_squared_distance": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                              _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_fps": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_fps_algo": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_ptr, _c_int, _c_ptr],
     "rpe_correlation2d_forward": [_c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                                   _c_float, _c_int, _c_ptr, _c_ptr],
-    "rpe_probe_mfma4x4": [_c_ptr, _c_ptr],
     "rpe_dwconv3": [_c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int,
                     _c_ptr, _c_ptr],
-    "rpe_channel_layernorm": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_float, _c_ptr, _c_ptr],
-    "rpe_channel_layernorm_pair": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_float,
-                                   _c_ptr],
+    "rpe_channel_layernorm": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_float,
+                              _c_ptr],
     "rpe_channel_attention_matrix": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_i64, _c_float,
-                                     _c_ptr, _c_ptr, _c_ptr],
-    "rpe_channel_attention_matrix_packed": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_i64, _c_float,
-                                            _c_ptr, _c_ptr, _c_ptr],
-    "rpe_pointwise_conv_strided": [_c_ptr, _c_i64, _c_int, _c_int, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_float,
-                                   _c_ptr, _c_ptr, _c_ptr],
+                                     _c_ptr, _c_ptr, _c_int, _c_ptr],
     "rpe_channel_attention_workspace_floats": [_c_int, _c_int, _c_int, _c_i64],
     "rpe_convex_upsample": [_c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_events_to_voxel": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int, _c_int, _c_i64,
@@ -51,22 +46,13 @@ _PROTOTYPES = {
                                         _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
     "rpe_corr3d_n2n": [_c_ptr] * 7 + [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_correlation2d_backward": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
-    "rpe_knn_multi": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr],
-    "rpe_knn_nearest2d_workspace_bytes": [_c_int, _c_int],
-    "rpe_knn_nearest2d": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_ptr, _c_ptr,
-                          _c_ptr, _c_i64, _c_ptr],
+    "rpe_knn_multi": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr],
     "rpe_debug_stamp": [_c_ptr, _c_ptr],
-    "rpe_knn_grid_set_stats": [_c_ptr],
-    "rpe_knn_grid_sizes": [_c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
-    "rpe_knn_grid_build": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
-    "rpe_knn_grid_supported": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_int],
-    "rpe_knn_grid_search": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                            _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     "rpe_gather_channel_first": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_gather_channel_last": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
-    "rpe_pointwise_conv": [_c_ptr, _c_int, _c_int, _c_i64, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_float, _c_ptr, _c_ptr, _c_ptr],
-    "rpe_im2col": [_c_ptr] + [_c_int] * 12 + [_c_ptr, _c_ptr],
-    "rpe_im2col_act": [_c_ptr] + [_c_int] * 12 + [_c_ptr, _c_ptr, _c_int, _c_float, _c_ptr, _c_ptr],
+    "rpe_pointwise_conv": [_c_ptr, _c_i64, _c_int, _c_int, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_float,
+                           _c_ptr, _c_ptr, _c_ptr],
+    "rpe_im2col": [_c_ptr] + [_c_int] * 12 + [_c_ptr, _c_ptr, _c_int, _c_float, _c_ptr, _c_ptr],
     "rpe_knn_interpolate": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
                             _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
     "rpe_resize_frames": [_c_ptr, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
@@ -74,12 +60,8 @@ _PROTOTYPES = {
     "rpe_upsample2x_pair": [_c_ptr, _c_int, _c_float, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_bilinear_sample": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
                             _c_int, _c_int, _c_ptr, _c_ptr],
-    "rpe_project_feat_nn_corr": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int,
-                                 _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
-    "rpe_project_feat_nn_corr_sampled": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64,
-                                         _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
-    "rpe_project_feat_nn_corr_fused": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64,
-                                       _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
+    "rpe_project_feat_nn_corr": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64,
+                                 _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_pointconv_pack_rows": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_pointconv_fused": [_c_ptr, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                             _c_float, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -95,8 +77,11 @@ _PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 5  # RPE_ABI_VERSION of include/rpeflow_hip.h
+ABI_VERSION = 6  # RPE_ABI_VERSION of include/rpeflow_hip.h
 KNN_TIES = {"torch": 3, "set": 1, "index": 0}  # RPE_KNN_TIES_* (how equal distances are resolved)
+KNN_ALGO = {"auto": 0, "sweep": 0x100, "binned": 0x200}  # RPE_KNN_ALGO_* (OR-ed into the mode)
+# entry points only a library built with -DRPE_EXPERIMENTAL has (python -m rpeflow_amd.build --experimental)
+_EXPERIMENTAL = {"rpe_probe_mfma4x4": [_c_ptr, _c_ptr]}
 
 
 class KnnJob(ctypes.Structure):
@@ -123,7 +108,10 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = _c_int
         handle.rpe_channel_attention_workspace_floats.restype = _c_i64
-        handle.rpe_knn_nearest2d_workspace_bytes.restype = _c_i64
+        handle.rpe_knn_workspace_bytes.restype = _c_i64
+        for name, argtypes in _EXPERIMENTAL.items():
+            if hasattr(handle, name):
+                getattr(handle, name).argtypes, getattr(handle, name).restype = argtypes, _c_int
         handle.rpe_error_string.argtypes = [_c_int]
         handle.rpe_error_string.restype = ctypes.c_char_p
         if handle.rpe_abi_version() != ABI_VERSION:

@@ -19,6 +19,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
 # per source: knn.hip's matrix kernel consumes every MFMA result on the VALU right away, so its accumulators belong in
 # VGPRs (the default puts them in AGPRs and copies 16 registers per step)
 FILE_FLAGS = {"knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# RPE_EXPERIMENTAL=1 (or --experimental): also the entry points include/rpeflow_hip.h lists under #ifdef RPE_EXPERIMENTAL
+# (kernel probes for development); the default library exports only what rpeflow_amd calls
+EXPERIMENTAL = ["-DRPE_EXPERIMENTAL"] if os.environ.get("RPE_EXPERIMENTAL") else []
 
 
 def sources():
@@ -45,7 +48,7 @@ def _hipcc():
 
 
 def _command(src):
-    return [_hipcc()] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-I", INCLUDE, "-I", SRC_DIR, "-c", src, "-o", _obj(src)]
+    return [_hipcc()] + FLAGS + EXPERIMENTAL + FILE_FLAGS.get(os.path.basename(src), []) + ["-I", INCLUDE, "-I", SRC_DIR, "-c", src, "-o", _obj(src)]
 
 
 def _stamp(src):
@@ -99,4 +102,6 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     import sys
+    if "--experimental" in sys.argv:
+        EXPERIMENTAL[:] = ["-DRPE_EXPERIMENTAL"]
     print(build(force="--force" in sys.argv, verbose=True))

@@ -289,12 +289,6 @@ int attention_matrix(const float *q, const float *k, int64_t batch_stride, const
 
 RPE_API int rpe_channel_attention_matrix(const float *q, const float *k, int64_t batch_stride, const float *temperature,
                                          const float *w_out, int B, int heads, int c, int64_t P, float eps, float *workspace,
-                                         float *m_out, rpe_stream_t stream) {
-    return attention_matrix(q, k, batch_stride, temperature, w_out, B, heads, c, P, eps, workspace, m_out, false, stream);
-}
-
-RPE_API int rpe_channel_attention_matrix_packed(const float *q, const float *k, int64_t batch_stride, const float *temperature,
-                                                const float *w_out, int B, int heads, int c, int64_t P, float eps, float *workspace,
-                                                float *m_packed, rpe_stream_t stream) {
-    return attention_matrix(q, k, batch_stride, temperature, w_out, B, heads, c, P, eps, workspace, m_packed, true, stream);
+                                         float *m_out, int packed, rpe_stream_t stream) {
+    return attention_matrix(q, k, batch_stride, temperature, w_out, B, heads, c, P, eps, workspace, m_out, packed != 0, stream);
 }

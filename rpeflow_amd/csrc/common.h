@@ -49,3 +49,8 @@ __device__ __forceinline__ float rpe_pair_dist(const float (&qm2)[3], float qq, 
     t = t + pp;
     return t;
 }
+
+// k = 1, D = 2 on a binned cloud (knn_binned.hip), reached through rpe_knn's workspace argument; not exported
+int64_t rpe_nearest2d_workspace_bytes(int B, int M);
+int rpe_nearest2d(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb, int64_t q_sn,
+                  int64_t q_sd, int B, int M, int Q, int64_t *idx, float *dist, void *workspace, hipStream_t stream);

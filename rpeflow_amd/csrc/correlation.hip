@@ -214,9 +214,6 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_kernel(const float *_
 // per workgroup); RY = 4 (432 accumulators) does not survive hipcc's AGPR/VGPR split.
 // Requires W % 4 == 0, C % CK == 0 and 16-byte aligned inputs (whole float4 pieces in or out of
 // the image); anything else takes corr_mfma_kernel.
-#ifndef RPE_CORR_PROBE
-#define RPE_CORR_PROBE 0  // timing probes, never in the library: 1 no DMA, 2 no MFMA steps, 3 no output stores, 4 no ring barrier, 5 one B read per step, 6 no B reads, 7 = 1+5, 8 = 1+6, 9 DMA from the zero word only, 10 every chunk re-reads chunk 0 (cache hits), 12 = 2+9
-#endif
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
@@ -297,12 +294,12 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
 
     auto issue_piece = [&](int chunk, int slot_index, int t) {  // t is a compile-time constant at every call site
         float *slot = lds + slot_index * G::SLOT;
-        const int64_t cbase = RPE_CORR_PROBE == 10 ? 0 : (int64_t)chunk * CK * HW;
+        const int64_t cbase = (int64_t)chunk * CK * HW;
         const int q = wave + NW * t;
         // both addresses are formed unconditionally and selected: no branch in the chunk body
         const float *inside = (q >= G::PIECES1 ? g2 : g1) + cbase + max(off[t], 0);
-        const float *src = (off[t] >= 0 && RPE_CORR_PROBE != 9 && RPE_CORR_PROBE != 12) ? inside : zero;
-        if constexpr (RPE_CORR_PROBE != 1 && RPE_CORR_PROBE != 7 && RPE_CORR_PROBE != 8) __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(slot + q * 256), 16, 0, 0);
+        const float *src = off[t] >= 0 ? inside : zero;
+        __builtin_amdgcn_global_load_lds((glb_void_t *)src, (lds_void_t *)(slot + q * 256), 16, 0, 0);
     };
     auto issue = [&](int chunk, int slot_index) {
 #pragma unroll
@@ -329,12 +326,11 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
         // any more -- so the count is a constant and the chunk body has no branch (which lets hipcc count its
         // lgkmcnt waits instead of draining the LDS queue at every basic-block boundary).
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * G::PPW) : "memory");
-        if constexpr (RPE_CORR_PROBE != 4) __builtin_amdgcn_s_barrier();  // ... for every wave; and everyone is done reading chunk ch-1
+        __builtin_amdgcn_s_barrier();  // ... for every wave; and everyone is done reading chunk ch-1
         const int next = min(ch + AHEAD, nchunks - 1);
         const int next_slot = (ch + AHEAD) % NSLOT;
         constexpr bool more = true;
-        if ((!(PD > 0 && SPREAD) || RPE_CORR_PROBE == 2 || RPE_CORR_PROBE == 12) && more) issue(next, next_slot);  // SPREAD: issued piece by piece among the MFMA steps below
-        if constexpr (RPE_CORR_PROBE == 2 || RPE_CORR_PROBE == 12) continue;
+        if (!(PD > 0 && SPREAD) && more) issue(next, next_slot);  // SPREAD: issued piece by piece among the MFMA steps below
 
         const int slot_id = ch % NSLOT;
         const float *l1 = lds + slot_id * G::SLOT + (wave * RY) * TX + lane;
@@ -354,8 +350,6 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
                     }
 #pragma unroll
                     for (int s = 0; s < 3; ++s) {
-                        if constexpr (RPE_CORR_PROBE == 6 || RPE_CORR_PROBE == 8) { br[t % (PD + 1)][s] = (float)(t + s); continue; }
-                        if constexpr (RPE_CORR_PROBE == 5 || RPE_CORR_PROBE == 7) { if (s > 0) { br[t % (PD + 1)][s] = br[t % (PD + 1)][0]; continue; } }
                         br[t % (PD + 1)][s] = l2[(c * G::TY2 + r) * PX2 + 4 * s];
                     }
                 };
@@ -410,7 +404,7 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
                 }
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's tile is written
             __builtin_amdgcn_wave_barrier();
-            if (y < H && x0 + lane < W && RPE_CORR_PROBE != 3) {
+            if (y < H && x0 + lane < W) {
                 float *o = out + ((int64_t)b * ND * ND + dy * ND) * HW + (int64_t)y * W + x0 + lane;
 #pragma unroll
                 for (int d = 0; d < ND; ++d) o[(int64_t)d * HW] = tile_lds[d * TX + lane];
@@ -435,6 +429,7 @@ int launch_mfma_dma(const float *in1, const float *in2, int B, int C, int H, int
 }
 
 
+#ifdef RPE_EXPERIMENTAL
 __global__ void probe_mfma4x4_kernel(float *out) {
     const int lane = threadIdx.x;
     f32x4 d = {0.f, 0.f, 0.f, 0.f};
@@ -442,6 +437,8 @@ __global__ void probe_mfma4x4_kernel(float *out) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[lane * 4 + i] = d[i];
 }
+
+#endif
 
 template <int RY, int NW, int CK>
 void launch_mfma(const float *in1, const float *in2, int B, int C, int H, int W, float slope, float *out, hipStream_t st) {
@@ -491,8 +488,10 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
     return rpe_launch_status();
 }
 
+#ifdef RPE_EXPERIMENTAL
 RPE_API int rpe_probe_mfma4x4(float *out256, rpe_stream_t stream) {
     if (!out256) return RPE_EINVAL;
     hipLaunchKernelGGL(probe_mfma4x4_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out256);
     return rpe_launch_status();
 }
+#endif

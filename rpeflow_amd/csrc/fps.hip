@@ -19,9 +19,6 @@
 
 namespace {
 
-#ifndef RPE_FPS_AUTO_PAIRED
-#define RPE_FPS_AUTO_PAIRED 0  // rpe_fps's pruned choice stays the one-sample kernel: the paired form measures 2 % slower
-#endif
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / RPE_WAVE;  // 16
 
@@ -398,287 +395,10 @@ __global__ __launch_bounds__(kThreads) void fps_pruned2_kernel(const float *__re
     }
 }
 
-// ---- fps_paired_kernel: fps_pruned2_kernel emitting two samples per synchronisation round where provable ---------------------------------------
-// One Morton cluster per wave; (a) every wave publishes its candidate's COORDINATES with its
-// partial, so the winner's coordinates are three v_readlane away instead of an LDS lookup, and (b) the skip test is
-// evaluated for all 16 candidates at once -- lane l tests candidate l against this wave's box -- while the DPP
-// reduction that picks the winner is in flight; the winner's lane then selects its bit.  A skipping wave's iteration
-// is: read 16 partials, reduce, readlane, republish.  The start needs no special case: every valid point begins at
-// 1e10, all waves tie, the lowest original index (0) wins.
-//
-// PAIRED (round 3): two samples per barrier round where that is provably what the sequential rule gives.  Every wave also
-// publishes the SECOND-largest running distance among its points (excluding its candidate).  After the barrier all waves see
-// the winner c1 (value v1, wave w1) and the best candidate of the OTHER waves, c2 (value v2, wave w2).  If (a) no other
-// candidate holds v2, (b) w1's second-largest value is < v2 and (c) c1 does not lower c2's running distance
-// (fl(|c2 - c1|^2) >= v2, rounded as the update rounds it), then after c1's update every point of w1 is <= its old
-// second-largest < v2, every other wave's maximum was < v2 and can only have dropped, and c2 -- the lowest index holding v2
-// in its wave -- still holds v2: c2 IS the next sample, whatever else c1's update does.  Both indices are written and every
-// wave applies both updates (each only if the sample can reach its box) in one recompute.  Otherwise the round emits one
-// sample, as before.  The indices are identical by construction; the GPU tests cross-check PAIRED, PRUNED and PLAIN.
 template <int PPT>
-__global__ __launch_bounds__(kThreads) void fps_paired_kernel(const float *__restrict__ xyz, int64_t sb, int64_t sn, int64_t sd,
-                                                               int N, int S, int64_t *__restrict__ idx) {
-    constexpr bool PAIRED = true;  // (the one-sample form is fps_pruned2_kernel above, kept verbatim: restructuring it for both cost 3 %)
-    static_assert(PPT % 2 == 0, "packed path needs an even number of points per thread");
-    constexpr int NP = PPT * kThreads;
-    constexpr int H = PPT / 2;
-    extern __shared__ unsigned long long sortbuf[];
-    __shared__ float red[6][kWaves];
-    __shared__ int part[2][6][kWaves];  // [parity][value bits, index, x, y, z, second-largest value bits][wave]
-    const int tid = threadIdx.x, lane = rpe_lane();
-    const int wave = rpe_uniform(tid >> 6);
-    const int b = blockIdx.x;
-    xyz += (int64_t)b * sb;
-    idx += (int64_t)b * S;
-
-    // ---- 1. bounding box of the cloud, 2. Morton keys + bitonic sort (as fps_pruned_kernel)
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < N; i += kThreads) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float v = xyz[(int64_t)i * sn + d * sd];
-            lo[d] = fminf(lo[d], v);
-            hi[d] = fmaxf(hi[d], v);
-        }
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float l = wave_minf(lo[d]), h = wave_max(hi[d]);
-        if (lane == 0) { red[d][wave] = l; red[3 + d][wave] = h; }
-    }
-    __syncthreads();
-    float clo[3], scale[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        float l = red[d][0], h = red[3 + d][0];
-        for (int w = 1; w < kWaves; ++w) { l = fminf(l, red[d][w]); h = fmaxf(h, red[3 + d][w]); }
-        clo[d] = l;
-        scale[d] = h > l ? 1023.0f / (h - l) : 0.f;
-    }
-    for (int i = tid; i < NP; i += kThreads) {
-        unsigned long long e = ~0ull;
-        if (i < N) {
-            unsigned key = 0;
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const float v = xyz[(int64_t)i * sn + d * sd];
-                int q = (int)((v - clo[d]) * scale[d]);
-                q = q < 0 ? 0 : (q > 1023 ? 1023 : q);
-                key |= spread10((unsigned)q) << d;
-            }
-            e = ((unsigned long long)key << 32) | (unsigned)i;
-        }
-        sortbuf[i] = e;
-    }
-    __syncthreads();
-    for (int k = 2; k <= NP; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int p = tid; p < NP / 2; p += kThreads) {
-                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
-                const unsigned long long a = sortbuf[i], c = sortbuf[l];
-                const bool up = (i & k) == 0;
-                if ((a > c) == up) { sortbuf[i] = c; sortbuf[l] = a; }
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- 3. this thread's points (row j of wave w = sorted positions w*64*PPT + j*64 + lane) and the wave's box
-    f32x2 px[H], py[H], pz[H];
-    int md[PPT], oi[PPT];
-    float l3[3] = {INFINITY, INFINITY, INFINITY}, h3[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-    for (int j = 0; j < PPT; ++j) {
-        const unsigned o = (unsigned)(sortbuf[wave * (RPE_WAVE * PPT) + j * RPE_WAVE + lane] & 0xffffffffu);
-        const bool valid = o != 0xffffffffu;
-        oi[j] = valid ? (int)o : 0x7fffffff;
-        const float *a = xyz + (int64_t)(valid ? o : 0) * sn;
-        const float x = a[0], y = a[sd], z = a[2 * sd];
-        px[j >> 1][j & 1] = x;
-        py[j >> 1][j & 1] = y;
-        pz[j >> 1][j & 1] = z;
-        md[j] = valid ? __float_as_int(1e10f) : -1;
-        if (valid) {
-            l3[0] = fminf(l3[0], x); h3[0] = fmaxf(h3[0], x);
-            l3[1] = fminf(l3[1], y); h3[1] = fmaxf(h3[1], y);
-            l3[2] = fminf(l3[2], z); h3[2] = fmaxf(h3[2], z);
-        }
-    }
-    float blo[3], bhi[3];  // wave-uniform
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        blo[d] = wave_minf(l3[d]);
-        bhi[d] = wave_max(h3[d]);
-    }
-
-    // the wave's candidate (largest running distance, lowest original index holding it, that point's coordinates)
-    int wmax, widx, wsec = -1;
-    float wx, wy, wz;
-    auto candidate = [&](int tmax) {
-        wmax = wave_max_i32(tmax);
-        unsigned long long m[PPT];
-        int holders = 0;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            m[j] = __builtin_amdgcn_ballot_w64(md[j] == wmax);
-            holders += (int)__builtin_popcountll(m[j]);
-        }
-        if (holders != 1) {  // several points share the maximum (the start, duplicates): lowest original index among them
-            int v = 0x7fffffff;
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) v = md[j] == wmax ? min(v, oi[j]) : v;
-            const int best = wave_min_i32(v);
-#pragma unroll
-            for (int j = 0; j < PPT; ++j) m[j] = __builtin_amdgcn_ballot_w64(md[j] == wmax && oi[j] == best);
-        }
-        widx = 0x7fffffff;
-        wx = wy = wz = 0.f;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j)
-            if (m[j]) {  // wave-uniform; exactly one j has a (single) bit set unless the wave is empty
-                const int l = (int)__builtin_ctzll(m[j]);
-                widx = __builtin_amdgcn_readlane(oi[j], l);
-                wx = rpe_readlane(px[j >> 1][j & 1], l);
-                wy = rpe_readlane(py[j >> 1][j & 1], l);
-                wz = rpe_readlane(pz[j >> 1][j & 1], l);
-            }
-        if (PAIRED) {  // the largest running distance among the wave's OTHER points
-            if (holders != 1) {
-                wsec = wmax;  // another point holds the maximum too (or the wave is empty: -1)
-            } else {
-                int t2 = -1;
-#pragma unroll
-                for (int j = 0; j < PPT; ++j) t2 = max(t2, ((m[j] >> lane) & 1ull) ? -1 : md[j]);
-                wsec = wave_max_i32(t2);
-            }
-        }
-    };
-    {
-        int t = -1;
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) t = max(t, md[j]);
-        candidate(t);
-    }
-    __syncthreads();  // the sort buffer is dead; part[] is a separate array
-
-    for (int s = 0, round = 0;; ++round) {
-        const int par = round & 1;
-        if (lane == 0) {
-            part[par][0][wave] = wmax;
-            part[par][1][wave] = widx;
-            part[par][2][wave] = __float_as_int(wx);
-            part[par][3][wave] = __float_as_int(wy);
-            part[par][4][wave] = __float_as_int(wz);
-            if (PAIRED) part[par][5][wave] = wsec;
-        }
-        __syncthreads();
-        const int l16 = lane & (kWaves - 1);
-        const int pv = part[par][0][l16], pi = part[par][1][l16];
-        const float qx = __int_as_float(part[par][2][l16]), qy = __int_as_float(part[par][3][l16]), qz = __int_as_float(part[par][4][l16]);
-        const int psec = PAIRED ? part[par][5][l16] : 0;
-        // lane l: would candidate l, as the next sample, lower any running distance of THIS wave's points?
-        const float ex = fmaxf(fmaxf(blo[0] - qx, qx - bhi[0]), 0.f), ey = fmaxf(fmaxf(blo[1] - qy, qy - bhi[1]), 0.f),
-                    ez = fmaxf(fmaxf(blo[2] - qz, qz - bhi[2]), 0.f);
-        const float lb = ((ex * ex + ey * ey) + ez * ez) * 0.99999f;
-        const unsigned long long needmask = __builtin_amdgcn_ballot_w64(__float_as_int(lb) <= wmax);
-        int bmax;
-        {
-            int r = row_max16_i32(pv);
-            asm volatile("s_nop 1\n\tv_readlane_b32 %0, %1, 15" : "=s"(bmax) : "v"(r));
-        }
-        unsigned long long tied = __builtin_amdgcn_ballot_w64(pv == bmax) & 0xffffull;
-        int win = (int)__builtin_ctzll(tied), cur = __builtin_amdgcn_readlane(pi, win);
-        for (tied &= tied - 1; tied; tied &= tied - 1) {  // two waves tie on the maximum: lowest original index
-            const int l = (int)__builtin_ctzll(tied), c = __builtin_amdgcn_readlane(pi, l);
-            if (c < cur) { cur = c; win = l; }
-        }
-        if (tid == 0) idx[s] = (int64_t)cur;
-        if (s == S - 1) break;
-        float cx = 0.f, cy = 0.f, cz = 0.f;
-        if (PAIRED) cx = rpe_readlane(qx, win), cy = rpe_readlane(qy, win), cz = rpe_readlane(qz, win);
-        bool pair = false;
-        int win2 = 0;
-#ifdef RPE_FPS_PROBE
-        int why = 0;
-#endif
-        float c2x = 0.f, c2y = 0.f, c2z = 0.f;
-        if (PAIRED) {
-            const int pv2 = l16 == win ? -1 : pv;
-            int b2;
-            {
-                int r = row_max16_i32(pv2);
-                asm volatile("s_nop 1\n\tv_readlane_b32 %0, %1, 15" : "=s"(b2) : "v"(r));
-            }
-            const unsigned long long hold2 = __builtin_amdgcn_ballot_w64(pv2 == b2) & 0xffffull;
-#ifdef RPE_FPS_PROBE
-            why = 1;
-#endif
-            if (b2 >= 0 && (hold2 & (hold2 - 1)) == 0ull) {  // a valid runner-up held by exactly one other wave
-                win2 = (int)__builtin_ctzll(hold2);
-                const int sec1 = __builtin_amdgcn_readlane(psec, win);
-                c2x = rpe_readlane(qx, win2), c2y = rpe_readlane(qy, win2), c2z = rpe_readlane(qz, win2);
-                const float dx = c2x - cx, dy = c2y - cy, dz = c2z - cz;  // as the update computes it for the point c2
-                const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
-                float nd = xx + yy;
-                nd = nd + zz;
-                pair = sec1 < b2 && __float_as_int(nd) >= b2;
-#ifdef RPE_FPS_PROBE
-                why = pair ? 0 : (sec1 >= b2 ? 2 : 3);
-#endif
-            }
-        }
-#ifdef RPE_FPS_PROBE
-        if (tid == 0 && s >= 8) { idx[0] += 1; idx[1 + why] += 1; }  // rounds; paired, not unique, second-best too high, c1 reaches c2
-#endif
-        if (pair) {
-            if (tid == 0) idx[s + 1] = (int64_t)__builtin_amdgcn_readlane(pi, win2);
-            if (s + 1 == S - 1) break;
-        }
-        const bool need1 = (needmask >> win) & 1ull, need2 = pair && ((needmask >> win2) & 1ull);  // wave-uniform
-        if (need1 || need2) {
-            if (!PAIRED) cx = rpe_readlane(qx, win), cy = rpe_readlane(qy, win), cz = rpe_readlane(qz, win);  // (only waves that recompute need them)
-            // (one of the two may not reach this wave's box: its update would change nothing, so its sample is replaced by the other)
-            const float ax = need1 ? cx : c2x, ay = need1 ? cy : c2y, az = need1 ? cz : c2z;
-            const f32x2 cx2 = {ax, ax}, cy2 = {ay, ay}, cz2 = {az, az};
-            int t = -1;
-            if (need1 && need2) {
-                const f32x2 ex2 = {c2x, c2x}, ey2 = {c2y, c2y}, ez2 = {c2z, c2z};
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
-                    const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
-                    f32x2 nd = xx + yy;
-                    nd = nd + zz;
-                    const f32x2 fx = px[h] - ex2, fy = py[h] - ey2, fz = pz[h] - ez2;
-                    const f32x2 x2 = fx * fx, y2 = fy * fy, z2 = fz * fz;
-                    f32x2 ne = x2 + y2;
-                    ne = ne + z2;
-                    md[2 * h] = min(md[2 * h], min(__float_as_int(nd[0]), __float_as_int(ne[0])));
-                    md[2 * h + 1] = min(md[2 * h + 1], min(__float_as_int(nd[1]), __float_as_int(ne[1])));
-                    t = max(t, max(md[2 * h], md[2 * h + 1]));
-                }
-            } else {
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const f32x2 dx = px[h] - cx2, dy = py[h] - cy2, dz = pz[h] - cz2;
-                    const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
-                    f32x2 nd = xx + yy;
-                    nd = nd + zz;
-                    md[2 * h] = min(md[2 * h], __float_as_int(nd[0]));
-                    md[2 * h + 1] = min(md[2 * h + 1], __float_as_int(nd[1]));
-                    t = max(t, max(md[2 * h], md[2 * h + 1]));
-                }
-            }
-            candidate(t);
-        }
-        s += pair ? 2 : 1;
-    }
-}
-
-template <int PPT, bool PAIRED>
 int launch_fps_pruned2(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, hipStream_t st) {
     const size_t shmem = sizeof(unsigned long long) * (size_t)PPT * kThreads;
-    auto kern = PAIRED ? fps_paired_kernel<PPT> : fps_pruned2_kernel<PPT>;
+    auto kern = fps_pruned2_kernel<PPT>;
     if (shmem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         if (e != hipSuccess) return (int)e;
@@ -707,25 +427,19 @@ int launch_fps_plain(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B
 RPE_API int rpe_fps_algo(const float *xyz, int64_t sb, int64_t sn, int64_t sd, int B, int N, int S, int64_t *idx, int algo,
                          rpe_stream_t stream) {
     if (!xyz || !idx || B < 0 || N <= 0 || S < 0 || S > N) return RPE_EINVAL;
-    if (algo != RPE_FPS_AUTO && algo != RPE_FPS_PLAIN && algo != RPE_FPS_PRUNED && algo != RPE_FPS_PAIRED) return RPE_EINVAL;
+    if (algo != RPE_FPS_AUTO && algo != RPE_FPS_PLAIN && algo != RPE_FPS_PRUNED) return RPE_EINVAL;
     if (B == 0 || S == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int ppt = (N + kThreads - 1) / kThreads;
     const bool can_prune = N > kThreads && N <= 16 * kThreads;
-    if ((algo == RPE_FPS_PRUNED || algo == RPE_FPS_PAIRED) && !can_prune) return RPE_EUNSUPPORTED;
+    if (algo == RPE_FPS_PRUNED && !can_prune) return RPE_EUNSUPPORTED;
     // auto: the Morton sort of the pruned kernels costs ~100 us per launch; it pays from a few thousand samples on
     const bool auto_pruned = algo == RPE_FPS_AUTO && can_prune && N >= 8 * kThreads && S >= 2048;
-    if (algo == RPE_FPS_PAIRED || (auto_pruned && RPE_FPS_AUTO_PAIRED)) {
-        if (ppt <= 2) return launch_fps_pruned2<2, true>(xyz, sb, sn, sd, B, N, S, idx, st);
-        if (ppt <= 4) return launch_fps_pruned2<4, true>(xyz, sb, sn, sd, B, N, S, idx, st);
-        if (ppt <= 8) return launch_fps_pruned2<8, true>(xyz, sb, sn, sd, B, N, S, idx, st);
-        return launch_fps_pruned2<16, true>(xyz, sb, sn, sd, B, N, S, idx, st);
-    }
     if (algo == RPE_FPS_PRUNED || auto_pruned) {
-        if (ppt <= 2) return launch_fps_pruned2<2, false>(xyz, sb, sn, sd, B, N, S, idx, st);
-        if (ppt <= 4) return launch_fps_pruned2<4, false>(xyz, sb, sn, sd, B, N, S, idx, st);
-        if (ppt <= 8) return launch_fps_pruned2<8, false>(xyz, sb, sn, sd, B, N, S, idx, st);
-        return launch_fps_pruned2<16, false>(xyz, sb, sn, sd, B, N, S, idx, st);
+        if (ppt <= 2) return launch_fps_pruned2<2>(xyz, sb, sn, sd, B, N, S, idx, st);
+        if (ppt <= 4) return launch_fps_pruned2<4>(xyz, sb, sn, sd, B, N, S, idx, st);
+        if (ppt <= 8) return launch_fps_pruned2<8>(xyz, sb, sn, sd, B, N, S, idx, st);
+        return launch_fps_pruned2<16>(xyz, sb, sn, sd, B, N, S, idx, st);
     }
     if (ppt <= 2) return launch_fps_plain<2>(xyz, sb, sn, sd, B, N, S, idx, st);
     if (ppt <= 4) return launch_fps_plain<4>(xyz, sb, sn, sd, B, N, S, idx, st);

@@ -412,8 +412,8 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x
 }
 }  // namespace
 
-RPE_API int rpe_im2col_act(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
-                           const float *in_scale, const float *in_shift, int in_act, float in_slope, float *cols, rpe_stream_t stream) {
+RPE_API int rpe_im2col(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
+                       const float *in_scale, const float *in_shift, int in_act, float in_slope, float *cols, rpe_stream_t stream) {
     if (in_act < 0 || in_act > 2) return RPE_EINVAL;
     if (!x || !cols || B < 0 || C < 1 || H < 1 || W < 1 || kh < 1 || kw < 1 || sh < 1 || sw < 1 || ph < 0 || pw < 0 || dh < 1 || dw < 1)
         return RPE_EINVAL;
@@ -425,11 +425,6 @@ RPE_API int rpe_im2col_act(const float *x, int B, int C, int H, int W, int kh, i
     hipLaunchKernelGGL(im2col_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, Ho, Wo, in_scale, in_shift,
                        in_act, in_slope, cols);
     return rpe_launch_status();
-}
-
-RPE_API int rpe_im2col(const float *x, int B, int C, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw,
-                       float *cols, rpe_stream_t stream) {
-    return rpe_im2col_act(x, B, C, H, W, kh, kw, sh, sw, ph, pw, dh, dw, nullptr, nullptr, 0, 0.f, cols, stream);
 }
 
 RPE_API int rpe_gather_channel_first(const float *data, int64_t sb, int64_t sc, int64_t sn, const int64_t *idx, int B, int C,
@@ -527,7 +522,7 @@ RPE_API int rpe_upsample2x_pair(const float *a, int Ca, float scale_a, const flo
     return rpe_launch_status();
 }
 
-RPE_API int rpe_project_feat_nn_corr_fused(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
+RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
                                            int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
                                            const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
                                            const int64_t *nn_idx, const float *subtract, int n_subtract, const float *append, int n_append,
@@ -544,19 +539,4 @@ RPE_API int rpe_project_feat_nn_corr_fused(const float *xy, int64_t xy_sb, int64
     hipLaunchKernelGGL(project_rows_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2,
                        H, W, C3, N, workspace, nn_idx, subtract, n_subtract, append, n_append, out);
     return rpe_launch_status();
-}
-
-RPE_API int rpe_project_feat_nn_corr_sampled(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
-                                             int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
-                                             const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
-                                             const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream) {
-    return rpe_project_feat_nn_corr_fused(xy, xy_sb, xy_sd, xy_sn, feat_2d, C2, H, W, sampled_2d, sm_sb, sm_sc, sm_sn, feat_3d, f3_sb, f3_sc, f3_sn,
-                                          C3, nn_idx, nullptr, 0, nullptr, 0, B, N, workspace, out, stream);
-}
-
-RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
-                                     int H, int W, const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
-                                     const int64_t *nn_idx, int B, int N, float *workspace, float *out, rpe_stream_t stream) {
-    return rpe_project_feat_nn_corr_sampled(xy, xy_sb, xy_sd, xy_sn, feat_2d, C2, H, W, nullptr, 0, 0, 0, feat_3d, f3_sb, f3_sc, f3_sn, C3, nn_idx,
-                                            B, N, workspace, out, stream);
 }

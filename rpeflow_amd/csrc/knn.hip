@@ -987,8 +987,19 @@ __device__ __forceinline__ void bitonic64_cols(knn_f32x16 &v, int lane) {
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_kernel(KnnJobs jobs, int k, int exact_ties) {
+// QUEUE_OUT: the workgroup's tied rows are not redone here but handed to knn_tie_replay_kernel (launched right behind this
+// kernel) through the caller's workspace: count[block] and rows[block][.] are written by EVERY workgroup, so the workspace
+// needs no initialisation.
+struct TieOut {
+    int *count;  // [B * ceil(Q / 64)]
+    int *rows;   // [B * ceil(Q / 64)][64]: query indices
+};
+struct TieOuts {
+    TieOut job[RPE_KNN_MAX_JOBS];
+};
+
+template <int D, bool QUEUE_OUT>
+__global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_kernel(KnnJobs jobs, int k, int exact_ties, TieOuts touts) {
     __shared__ MfmaBlockLds lds;
     const rpe_knn_job &J = jobs.job[blockIdx.z];
     const float *__restrict__ inp = J.input;
@@ -1151,6 +1162,13 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_kernel(Knn
         int Li;
         const int n = rpe_readlane(n_query, q);
         if (((full_lanes >> q) & 0x0001000100010001ull) != 0ull || n > RPE_WAVE) {  // a lane list of this query filled up
+            if (QUEUE_OUT && exact_ties == RPE_KNN_TIES_TORCH) {
+                // torch.topk's order is what the replay kernel computes for ANY row (it is the reference's algorithm on the
+                // row's distances): the row goes there instead of through the serial sweep, whose wave ran on alone after
+                // every other wave of the launch had finished (+12 us on 8 x (8192 -> 4096), k = 16)
+                if (lane == 0) tq.query[atomicAdd(&tq.n, 1)] = qi;
+                continue;
+            }
             serial_select<D>(inp, in_sn, in_sd, M, qm2, qq, kk, lane, Ld, Li);
         } else {
             const unsigned long long e = lds.list[wave][0][q * RPE_WAVE + lane];
@@ -1165,10 +1183,195 @@ __global__ __launch_bounds__(kWavesPerBlock * RPE_WAVE) void knn_mfma_kernel(Knn
             if (dist) dist[o] = Ld;
         }
     }
-    if (exact_ties) drain_ties<D>(&tq, J, b, k, lane, wave);
+    if constexpr (QUEUE_OUT) {
+        __syncthreads();
+        const TieOut &T = touts.job[blockIdx.z];
+        const int blk = b * ((Q + kWavesPerBlock * kMq - 1) / (kWavesPerBlock * kMq)) + blockIdx.x;
+        const int n = tq.n;
+        if (threadIdx.x == 0) T.count[blk] = n;
+        if ((int)threadIdx.x < n) T.rows[blk * (kWavesPerBlock * kMq) + threadIdx.x] = tq.query[threadIdx.x];
+    } else {
+        if (exact_ties) drain_ties<D>(&tq, J, b, k, lane, wave);
+    }
 }
 
-#include "knn_grid.h"
+// ---- the matrix kernel's tied rows, redone by a second launch ------------------------------------------------------------
+// In knn_mfma_kernel a tied row is replayed by one wave after the workgroup's sweeps, and the launch ends with the last such
+// wave (~45 us behind a 124 us sweep on 8 x (8192 -> 4096), k = 16).  Here the tied rows of the WHOLE launch (~1.4 % of the
+// rows of a real cloud) are shared out over a grid of their own, one row per workgroup at a time: its four waves first put the
+// row's M distances into LDS together (the scan that took the lone wave 32 load-wait-compare rounds), then one wave replays
+// libstdc++'s __heap_select / __sort_heap on them exactly as heap_replay_static does -- same distances, same order, same sifts.
+// Every workgroup scans the per-workgroup counts the sweep kernel left (at most kReplayMaxBlocks of them) and takes the rows
+// t = blockIdx.x, blockIdx.x + gridDim.x, ... of the concatenated queues: no atomics, no initialised memory, a fixed order.
+constexpr int kReplayMaxM = 16384;
+constexpr int kReplayMaxBlocks = 4096;
+constexpr int kReplayGrid = 1024;
+constexpr int kReplayThreads = 256;
+
+template <int K>
+__device__ __forceinline__ void heap_replay_lds(const float *ld, int M, int lane, float &Ld, int &Li) {
+    unsigned kv = heap_key(INFINITY);
+    int iv = 0;
+    float top = INFINITY;
+    constexpr int kTiles = 4;
+    for (int base0 = 0; base0 < M; base0 += kTiles * RPE_WAVE) {
+        float d[kTiles];
+        unsigned long long m[kTiles];
+#pragma unroll
+        for (int u = 0; u < kTiles; ++u) {
+            const int i = base0 + u * RPE_WAVE + lane;
+            d[u] = i < M ? ld[i] : INFINITY;
+        }
+        if (base0 == 0) {
+            kv = heap_key(d[0]);
+            iv = lane;
+            if constexpr (K >= 2) heap_make<K, (K - 2) / 2>(kv, iv);
+            top = heap_dist((unsigned)__builtin_amdgcn_readlane((int)kv, 0));
+        }
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int u = 0; u < kTiles; ++u) {
+            m[u] = __ballot((base0 > 0 || u > 0 || lane >= K) && d[u] < top);
+            any |= m[u];
+        }
+        if (!any) continue;
+#pragma unroll
+        for (int u = 0; u < kTiles; ++u) {
+            unsigned long long mu = m[u] & __ballot(d[u] < top);
+            while (mu) {
+                const int l = __builtin_ctzll(mu);
+                heap_sift<0, K>(kv, iv, heap_key(rpe_readlane(d[u], l)), base0 + u * RPE_WAVE + l);
+                top = heap_dist((unsigned)__builtin_amdgcn_readlane((int)kv, 0));
+                mu &= (~1ull << l) & __ballot(d[u] < top);
+            }
+        }
+    }
+    if constexpr (K >= 2) heap_sort<K - 1>(kv, iv);
+    Ld = heap_dist(kv);
+    Li = iv;
+}
+
+// the same for any k (LaneHeap: dynamic lanes)
+__device__ __forceinline__ void heap_replay_lds_any(const float *ld, int M, int k, int lane, float &Ld, int &Li) {
+    LaneHeap h;
+    h.v = INFINITY;
+    h.i = 0;
+    float top = INFINITY;
+    for (int base = 0; base < M; base += RPE_WAVE) {
+        const float d = base + lane < M ? ld[base + lane] : INFINITY;
+        if (base == 0) {
+            h.v = d;
+            h.i = lane;
+            for (int parent = (k - 2) / 2;; --parent) {
+                h.adjust(parent, k, h.val(parent), rpe_readlane(h.i, parent), lane);
+                if (parent == 0) break;
+            }
+            top = h.val(0);
+        }
+        unsigned long long mu = __ballot((base > 0 || lane >= k) && d < top);
+        while (mu) {
+            const int l = __builtin_ctzll(mu);
+            h.adjust(0, k, rpe_readlane(d, l), base + l, lane);
+            top = h.val(0);
+            mu &= (~1ull << l) & __ballot(d < top);
+        }
+    }
+    for (int last = k - 1; last >= 1; --last) {
+        const float lv = h.val(last);
+        const int li = rpe_readlane(h.i, last);
+        h.move(last, 0, lane);
+        h.adjust(0, last, lv, li, lane);
+    }
+    Ld = h.v;
+    Li = h.i;
+}
+
+template <int D>
+__global__ __launch_bounds__(kReplayThreads) void knn_tie_replay_kernel(KnnJobs jobs, TieOuts touts, int B, int k) {
+    extern __shared__ float replay_lds[];  // [nblk + 1] ints: exclusive prefix of the counts; then M distances
+    __shared__ int wave_sum[kReplayThreads / RPE_WAVE];
+    const rpe_knn_job &J = jobs.job[blockIdx.y];
+    const TieOut &T = touts.job[blockIdx.y];
+    const int M = J.M, Q = J.Q;
+    const int per_block = kWavesPerBlock * kMq;
+    const int nbx = (Q + per_block - 1) / per_block, nblk = nbx * B;
+    int *prefix = reinterpret_cast<int *>(replay_lds);
+    float *ld = replay_lds + ((nblk + 1 + 3) & ~3);
+    const int tid = threadIdx.x, lane = rpe_lane(), wave = tid >> 6;
+
+    // exclusive scan of count[0 .. nblk): every thread owns `per` consecutive entries
+    const int per = (nblk + kReplayThreads - 1) / kReplayThreads;  // <= 16
+    int sum = 0;
+    for (int j = 0; j < per; ++j) {
+        const int c = tid * per + j;
+        sum += c < nblk ? T.count[c] : 0;
+    }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < RPE_WAVE; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == RPE_WAVE - 1) wave_sum[wave] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wave_sum[w];
+    int total = 0;
+    for (int w = 0; w < kReplayThreads / RPE_WAVE; ++w) total += wave_sum[w];
+    for (int j = 0; j < per; ++j) {
+        const int c = tid * per + j;
+        if (c < nblk) {
+            prefix[c] = run;
+            run += T.count[c];
+        }
+    }
+    if (tid == 0) prefix[nblk] = total;
+    __syncthreads();
+
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        int lo = 0, hi = nblk;  // the source workgroup: the last one whose prefix is <= t
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (prefix[mid] <= t) lo = mid;
+            else hi = mid;
+        }
+        const int src = rpe_uniform(lo);
+        const int qi = rpe_uniform(T.rows[src * per_block + (t - prefix[src])]);
+        const int b = src / nbx;
+        const float *inp = J.input + (int64_t)b * J.in_sb;
+        float q[3], qm2[3];
+        load_point<D>(J.query + (int64_t)b * J.q_sb, J.q_sn, J.q_sd, qi, q);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) q[d] = rpe_uniform(q[d]);
+        const float qq = rpe_sqnorm<D>(q);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) qm2[d] = -2.0f * q[d];
+        constexpr int kAhead = 16;  // points per thread requested together: a row of 8192 is two memory round trips for the workgroup
+        for (int i0 = tid; i0 < M; i0 += kAhead * kReplayThreads) {
+            float p[kAhead][3];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) load_point<D>(inp, J.in_sn, J.in_sd, min(i0 + u * kReplayThreads, M - 1), p[u]);
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u)
+                if (i0 + u * kReplayThreads < M) ld[i0 + u * kReplayThreads] = rpe_pair_dist<D>(qm2, qq, p[u], rpe_sqnorm<D>(p[u]));
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float Ld;
+            int Li;
+            if (k == 16) heap_replay_lds<16>(ld, M, lane, Ld, Li);
+            else if (k == 3) heap_replay_lds<3>(ld, M, lane, Ld, Li);
+            else heap_replay_lds_any(ld, M, k, lane, Ld, Li);
+            if (lane < k) {
+                const int64_t o = ((int64_t)b * Q + qi) * k + lane;
+                J.idx[o] = (int64_t)Li;
+                if (J.dist) J.dist[o] = Ld;
+            }
+        }
+        __syncthreads();  // (the distances are overwritten by the next row)
+    }
+}
+
 
 // ---- k == 1 on large clouds, many queries: the same matrix sweep, a running (minimum, index) per lane ------------------------
 // A lane sees its query's points in index order (register 4 b + r = point 16 b + 4 g + r of the step), so a strict '<'
@@ -1358,11 +1561,14 @@ int launch_knn_d(int qw, const KnnJobs &jobs, int njobs, int max_q, int min_m, i
     }
 }
 
-// the jobs of one launch group (all through the insertion / lane-minimum kernels, or all through the matrix kernel)
-int launch_group(const rpe_knn_job *const *jobs, int njobs, bool matrix, int B, int D, int k, int tie_mode, hipStream_t st) {
+// the jobs of one launch group (all through the insertion / lane-minimum kernels, or all through the matrix kernel).
+// ``ws``: per job, workspace for the matrix kernel's tied rows (all non-null: they are replayed by a second launch) or null.
+int launch_group(const rpe_knn_job *const *jobs, char *const *ws, int njobs, bool matrix, int B, int D, int k, int tie_mode, hipStream_t st) {
     KnnJobs packed;
     int max_q = 0, min_m = 0x7fffffff, max_m = 0;
     long total_q = 0;
+    bool replay = matrix && k >= 2 && tie_mode != RPE_KNN_TIES_INDEX && k < RPE_WAVE;
+    TieOuts touts{};
     for (int i = 0; i < njobs; ++i) {
         const rpe_knn_job &j = *jobs[i];
         packed.job[i] = j;
@@ -1370,6 +1576,9 @@ int launch_group(const rpe_knn_job *const *jobs, int njobs, bool matrix, int B, 
         min_m = j.M < min_m ? j.M : min_m;
         max_m = j.M > max_m ? j.M : max_m;
         total_q += j.Q;
+        const int64_t nblk = (int64_t)B * ((j.Q + kWavesPerBlock * kMq - 1) / (kWavesPerBlock * kMq));
+        replay = replay && ws && ws[i] && nblk <= kReplayMaxBlocks && j.M <= kReplayMaxM;
+        if (replay) touts.job[i] = TieOut{reinterpret_cast<int *>(ws[i]), reinterpret_cast<int *>(ws[i]) + ((nblk + 3) & ~3ll)};
     }
     if (max_q == 0) return 0;
     if (matrix) {
@@ -1379,9 +1588,29 @@ int launch_group(const rpe_knn_job *const *jobs, int njobs, bool matrix, int B, 
             if (D == 3) hipLaunchKernelGGL(knn_mfma_nearest_kernel<3>, grid, block, 0, st, packed);
             else if (D == 2) hipLaunchKernelGGL(knn_mfma_nearest_kernel<2>, grid, block, 0, st, packed);
             else hipLaunchKernelGGL(knn_mfma_nearest_kernel<1>, grid, block, 0, st, packed);
-        } else if (D == 3) hipLaunchKernelGGL(knn_mfma_kernel<3>, grid, block, 0, st, packed, k, tie_mode);
-        else if (D == 2) hipLaunchKernelGGL(knn_mfma_kernel<2>, grid, block, 0, st, packed, k, tie_mode);
-        else hipLaunchKernelGGL(knn_mfma_kernel<1>, grid, block, 0, st, packed, k, tie_mode);
+            return rpe_launch_status();
+        }
+        if (!replay) {
+            if (D == 3) hipLaunchKernelGGL((knn_mfma_kernel<3, false>), grid, block, 0, st, packed, k, tie_mode, touts);
+            else if (D == 2) hipLaunchKernelGGL((knn_mfma_kernel<2, false>), grid, block, 0, st, packed, k, tie_mode, touts);
+            else hipLaunchKernelGGL((knn_mfma_kernel<1, false>), grid, block, 0, st, packed, k, tie_mode, touts);
+            return rpe_launch_status();
+        }
+        if (D == 3) hipLaunchKernelGGL((knn_mfma_kernel<3, true>), grid, block, 0, st, packed, k, tie_mode, touts);
+        else if (D == 2) hipLaunchKernelGGL((knn_mfma_kernel<2, true>), grid, block, 0, st, packed, k, tie_mode, touts);
+        else hipLaunchKernelGGL((knn_mfma_kernel<1, true>), grid, block, 0, st, packed, k, tie_mode, touts);
+        int rc = rpe_launch_status();
+        if (rc) return rc;
+        const size_t lds = (((size_t)kReplayMaxBlocks + 4) + (size_t)max_m) * sizeof(float);
+        const void *kern = D == 3 ? (const void *)knn_tie_replay_kernel<3> : D == 2 ? (const void *)knn_tie_replay_kernel<2> : (const void *)knn_tie_replay_kernel<1>;
+        if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        dim3 rgrid(kReplayGrid, njobs), rblock(kReplayThreads);
+        if (D == 3) hipLaunchKernelGGL(knn_tie_replay_kernel<3>, rgrid, rblock, lds, st, packed, touts, B, k);
+        else if (D == 2) hipLaunchKernelGGL(knn_tie_replay_kernel<2>, rgrid, rblock, lds, st, packed, touts, B, k);
+        else hipLaunchKernelGGL(knn_tie_replay_kernel<1>, rgrid, rblock, lds, st, packed, touts, B, k);
         return rpe_launch_status();
     }
     const int qw = pick_qw(B, (int)total_q);
@@ -1390,38 +1619,86 @@ int launch_group(const rpe_knn_job *const *jobs, int njobs, bool matrix, int B, 
     return launch_knn_d<1>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
 }
 
+// which kernels take a search (the same rules size the workspace)
+bool takes_matrix(int B, int M, int Q, int k) {
+    return k < RPE_WAVE && M >= kMatrixMinM && (long)M >= 64L * k && (long)B * Q >= kMatrixMinQueries;
+}
+// the binned nearest-point search (knn_binned.hip: k = 1, D = 2) against the sweeps -- two launches (8 us to bin the clouds),
+// then waves that meet ~50 points instead of the whole cloud.  Kernel time, both frames of a batch of 4: 4096 points /
+// 144 x 240 queries 8 + 22 us against 201; 2048 / 72 x 120: 8 + 13 against 34; 1024 / 36 x 60: 8 + 10 against 10.
+bool takes_binned(int B, int M, int Q, int D, int k) { return D == 2 && k == 1 && M >= 2048 && (long)B * Q >= 16384; }
+
+int64_t job_workspace_bytes(int B, int M, int Q, int D, int k, int mode) {
+    if (B <= 0 || M <= 0 || Q <= 0) return 0;
+    if (D == 2 && k == 1 && M >= 64 && ((mode & RPE_KNN_ALGO_BINNED) || (takes_binned(B, M, Q, D, k) && !(mode & RPE_KNN_ALGO_SWEEP))))
+        return rpe_nearest2d_workspace_bytes(B, M);
+    if (k >= 2 && takes_matrix(B, M, Q, k) && (mode & 3) != RPE_KNN_TIES_INDEX && M <= kReplayMaxM) {
+        const int64_t nblk = (int64_t)B * ((Q + kWavesPerBlock * kMq - 1) / (kWavesPerBlock * kMq));
+        if (nblk <= kReplayMaxBlocks) return ((((nblk + 3) & ~3ll) + nblk * (kWavesPerBlock * kMq)) * 4 + 15) & ~15ll;
+    }
+    return 0;
+}
+
 }  // namespace
 
-RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, int tie_mode, rpe_stream_t stream) {
+RPE_API int64_t rpe_knn_workspace_bytes(int B, int M, int Q, int D, int k, int mode) { return job_workspace_bytes(B, M, Q, D, k, mode); }
+
+RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int k, int mode, void *workspace, int64_t workspace_bytes,
+                          rpe_stream_t stream) {
     if (!jobs || njobs < 1 || njobs > RPE_KNN_MAX_JOBS || B < 0 || D < 1 || D > 3 || k < 1) return RPE_EINVAL;
-    if (tie_mode != RPE_KNN_TIES_TORCH && tie_mode != RPE_KNN_TIES_SET && tie_mode != RPE_KNN_TIES_INDEX) return RPE_EINVAL;
+    const int tie_mode = mode & 3;
+    if ((mode & ~(3 | RPE_KNN_ALGO_SWEEP | RPE_KNN_ALGO_BINNED)) || tie_mode == 2 || ((mode & RPE_KNN_ALGO_SWEEP) && (mode & RPE_KNN_ALGO_BINNED)))
+        return RPE_EINVAL;
     if (k > RPE_WAVE) return RPE_EUNSUPPORTED;
     if (B > 65535) return RPE_EUNSUPPORTED;
-    // a cloud of at least kMatrixMinM points in topk's partial_sort regime (64 k <= M), enough queries: the matrix kernels
-    const rpe_knn_job *big[RPE_KNN_MAX_JOBS], *rest[RPE_KNN_MAX_JOBS];
-    int nbig = 0, nrest = 0;
+    if (workspace && ((reinterpret_cast<uintptr_t>(workspace) & 15) || workspace_bytes < 0)) return RPE_EINVAL;
+    // a cloud of at least kMatrixMinM points in topk's partial_sort regime (64 k <= M), enough queries: the matrix kernels;
+    // k = 1, D = 2 on a large cloud with workspace: the binned search; everything else: insertion / lane-minimum kernels
+    const rpe_knn_job *big[RPE_KNN_MAX_JOBS], *rest[RPE_KNN_MAX_JOBS], *binned[RPE_KNN_MAX_JOBS];
+    char *big_ws[RPE_KNN_MAX_JOBS], *binned_ws[RPE_KNN_MAX_JOBS];
+    int nbig = 0, nrest = 0, nbinned = 0;
+    char *ws = static_cast<char *>(workspace);
+    int64_t left = workspace ? workspace_bytes : 0;
+    bool all_big_ws = true;
     for (int i = 0; i < njobs; ++i) {
         const rpe_knn_job &j = jobs[i];
         if (!j.input || !j.query || !j.idx || j.M <= 0 || j.Q < 0 || k > j.M) return RPE_EINVAL;
-        if (k < RPE_WAVE && j.M >= kMatrixMinM && (long)j.M >= 64L * k && (long)B * j.Q >= kMatrixMinQueries) big[nbig++] = &j;
-        else rest[nrest++] = &j;
+        const int64_t need = job_workspace_bytes(B, j.M, j.Q, D, k, mode);  // jobs take their shares in order
+        char *mine = (need > 0 && left >= need) ? ws : nullptr;
+        if (mine) ws += need, left -= need;
+        const bool want_binned = D == 2 && k == 1 && j.M >= 64 && B > 0 && j.Q > 0 &&
+                                 ((mode & RPE_KNN_ALGO_BINNED) || (takes_binned(B, j.M, j.Q, D, k) && !(mode & RPE_KNN_ALGO_SWEEP)));
+        if ((mode & RPE_KNN_ALGO_BINNED) && B > 0 && j.Q > 0 && !(want_binned && mine)) return (D == 2 && k == 1 && j.M >= 64) ? RPE_EINVAL : RPE_EUNSUPPORTED;
+        if (want_binned && mine) {
+            binned[nbinned] = &j, binned_ws[nbinned++] = mine;
+        } else if (takes_matrix(B, j.M, j.Q, k)) {
+            big[nbig] = &j, big_ws[nbig++] = mine;
+            all_big_ws = all_big_ws && mine;
+        } else {
+            rest[nrest++] = &j;
+        }
     }
     if (B == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (nbig) {
-        const int rc = launch_group(big, nbig, true, B, D, k, tie_mode, st);
+    for (int i = 0; i < nbinned; ++i) {
+        const rpe_knn_job &j = *binned[i];
+        const int rc = rpe_nearest2d(j.input, j.in_sb, j.in_sn, j.in_sd, j.query, j.q_sb, j.q_sn, j.q_sd, B, j.M, j.Q, j.idx, j.dist, binned_ws[i], st);
         if (rc) return rc;
     }
-    return nrest ? launch_group(rest, nrest, false, B, D, k, tie_mode, st) : 0;
+    if (nbig) {
+        const int rc = launch_group(big, all_big_ws ? big_ws : nullptr, nbig, true, B, D, k, tie_mode, st);
+        if (rc) return rc;
+    }
+    return nrest ? launch_group(rest, nullptr, nrest, false, B, D, k, tie_mode, st) : 0;
 }
 
 RPE_API int rpe_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,
-                    int64_t q_sn, int64_t q_sd, int B, int M, int Q, int D, int k, int tie_mode, int64_t *idx, float *dist,
-                    rpe_stream_t stream) {
+                    int64_t q_sn, int64_t q_sd, int B, int M, int Q, int D, int k, int mode, int64_t *idx, float *dist,
+                    void *workspace, int64_t workspace_bytes, rpe_stream_t stream) {
     if (!input || !query || !idx || B < 0 || M <= 0 || Q < 0 || D < 1 || D > 3) return RPE_EINVAL;
     if (k < 1 || k > M) return RPE_EINVAL;
     const rpe_knn_job job{input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, M, Q, idx, dist};
-    return rpe_knn_multi(&job, 1, B, D, k, tie_mode, stream);
+    return rpe_knn_multi(&job, 1, B, D, k, mode, workspace, workspace_bytes, stream);
 }
 
 RPE_API int rpe_squared_distance(const float *xyz1, int64_t a_sb, int64_t a_sn, int64_t a_sd, const float *xyz2,
@@ -1439,61 +1716,4 @@ RPE_API int rpe_squared_distance(const float *xyz1, int64_t a_sb, int64_t a_sn, 
     else
         hipLaunchKernelGGL(sqdist_kernel<1>, grid, block, 0, st, xyz1, a_sb, a_sn, a_sd, xyz2, b_sb, b_sn, b_sd, N1, N2, out);
     return rpe_launch_status();
-}
-
-/* ---- spatially ordered clouds (knn_grid.h) --------------------------------------------------------------------------- */
-RPE_API int rpe_knn_grid_sizes(int N, int D, int64_t *sorted_floats, int64_t *perm_ints, int64_t *box_floats) {
-    if (N < 1 || D < 1 || D > 3 || !sorted_floats || !perm_ints || !box_floats) return RPE_EINVAL;
-    const int64_t npad = ((int64_t)N + 63) & ~63ll;
-    *sorted_floats = 4 * npad;
-    *perm_ints = npad;
-    *box_floats = (npad / 64 + 1) * kGridBoxFloats;
-    return 0;
-}
-
-RPE_API int rpe_knn_grid_build(const float *pts, int64_t sb, int64_t sn, int64_t sd, int B, int N, int D, float *sorted, int32_t *perm,
-                               float *boxes, rpe_stream_t stream) {
-    if (!pts || !sorted || !perm || !boxes || B < 0 || N < 1 || D < 1 || D > 3) return RPE_EINVAL;
-    if (B > 65535) return RPE_EUNSUPPORTED;
-    if (B == 0) return 0;
-    GridBuildJobs jobs;
-    jobs.job[0] = GridBuildJob{pts, sb, sn, sd, N, sorted, perm, boxes};
-    dim3 grid(B, 1), block(kGridBuildThreads);
-    hipStream_t st = (hipStream_t)stream;
-    if (D == 3) hipLaunchKernelGGL(knn_grid_build_kernel<3>, grid, block, 0, st, jobs);
-    else if (D == 2) hipLaunchKernelGGL(knn_grid_build_kernel<2>, grid, block, 0, st, jobs);
-    else hipLaunchKernelGGL(knn_grid_build_kernel<1>, grid, block, 0, st, jobs);
-    return rpe_launch_status();
-}
-
-RPE_API int rpe_knn_grid_supported(int B, int M, int Q, int D, int k, int tie_mode) {
-    const int kk = (tie_mode != RPE_KNN_TIES_INDEX && k < M && k < RPE_WAVE) ? k + 1 : k;
-    return D >= 1 && D <= 3 && k >= 2 && kk <= 32 && M >= 64 * k && M >= 256 && M <= kGridMaxM && Q >= 1 && B >= 1 && B <= 65535;
-}
-
-RPE_API int rpe_knn_grid_search(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,
-                                int64_t q_sn, int64_t q_sd, int B, int M, int Q, int D, int k, int tie_mode,
-                                const float *in_sorted, const int32_t *in_perm, const float *in_boxes, const float *q_sorted,
-                                const int32_t *q_perm, int64_t *idx, float *dist, rpe_stream_t stream) {
-    if (!input || !query || !idx || !in_sorted || !in_perm || !in_boxes || !q_sorted || !q_perm) return RPE_EINVAL;
-    if (tie_mode != RPE_KNN_TIES_TORCH && tie_mode != RPE_KNN_TIES_SET && tie_mode != RPE_KNN_TIES_INDEX) return RPE_EINVAL;
-    if (B < 0 || M <= 0 || Q < 0 || k < 1 || k > M) return RPE_EINVAL;
-    if (B == 0 || Q == 0) return 0;
-    if (!rpe_knn_grid_supported(B, M, Q, D, k, tie_mode)) return RPE_EUNSUPPORTED;
-    GridJobs jobs;
-    jobs.job[0].j = rpe_knn_job{input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, M, Q, idx, dist};
-    jobs.job[0].in = rpe_grid_set{in_sorted, in_perm, in_boxes};
-    jobs.job[0].q = rpe_grid_set{q_sorted, q_perm, nullptr};
-    const int per_block = kWavesPerBlock * kMq;
-    dim3 grid((Q + per_block - 1) / per_block, B, 1), block(kWavesPerBlock * RPE_WAVE);
-    hipStream_t st = (hipStream_t)stream;
-    const size_t lds = sizeof(GridBlockLds);
-    if (D == 3) hipLaunchKernelGGL(knn_grid_kernel<3>, grid, block, lds, st, jobs, k, tie_mode);
-    else if (D == 2) hipLaunchKernelGGL(knn_grid_kernel<2>, grid, block, lds, st, jobs, k, tie_mode);
-    else hipLaunchKernelGGL(knn_grid_kernel<1>, grid, block, lds, st, jobs, k, tie_mode);
-    return rpe_launch_status();
-}
-
-RPE_API int rpe_knn_grid_set_stats(unsigned long long *stats16) {
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_grid_stats), &stats16, sizeof(stats16));
 }

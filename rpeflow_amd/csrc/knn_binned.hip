@@ -1,4 +1,4 @@
-// k_nearest_neighbor, k = 1, D = 2, on a cloud binned into a uniform cell grid: the model's nearest-projected-point search
+// k_nearest_neighbor, k = 1, D = 2, on a cloud binned into a uniform cell grid (reached through rpe_knn's workspace): the model's nearest-projected-point search
 // (RPEFlow_core.py:327-330 through wrapper.py:106-127: every pixel of a feature map asks for the nearest of N projected
 // points; 34 560 x 4096 pairs per sample at pyramid level 1, twice per level).  The sweeping kernels of knn.hip evaluate
 // every pair; here a wave's 64 queries only meet the points of the cells around them.
@@ -91,7 +91,8 @@ __global__ __launch_bounds__(kBuildThreads) void nearest2d_build_kernel(const fl
     float mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
     const int ns = Q < kBuildThreads ? Q : kBuildThreads;
     if (tid < ns) {
-        const int qi = ns > 1 ? (int)((int64_t)tid * (Q - 1) / (ns - 1)) : 0;
+        const int step = ns > 1 ? (Q - 1) / (ns - 1) : 0;  // (32-bit, wave-uniform: no 64-bit division per thread)
+        const int qi = tid == ns - 1 ? Q - 1 : tid * step;
         const float x = qry[(int64_t)qi * q_sn], y = qry[(int64_t)qi * q_sn + q_sd];
         if (finite2(x, y)) mnx = mxx = x, mny = mxy = y;
     }
@@ -386,19 +387,15 @@ __global__ __launch_bounds__(256) void nearest2d_search_kernel(const float *__re
 
 }  // namespace
 
-RPE_API int64_t rpe_knn_nearest2d_workspace_bytes(int B, int M) {
+int64_t rpe_nearest2d_workspace_bytes(int B, int M) {
     if (B < 0 || M < 1) return 0;
-    return (int64_t)B * ws_stride_bytes(M);
+    return ((int64_t)B * ws_stride_bytes(M) + 15) & ~15ll;
 }
 
-RPE_API int rpe_knn_nearest2d(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb,
-                              int64_t q_sn, int64_t q_sd, int B, int M, int Q, int64_t *idx, float *dist, void *workspace,
-                              int64_t workspace_bytes, rpe_stream_t stream) {
-    if (!input || !query || !idx || !workspace || B < 0 || M < 64 || Q < 0) return RPE_EINVAL;  // (M < 64: torch.topk's other regime)
-    if (workspace_bytes < rpe_knn_nearest2d_workspace_bytes(B, M) || ((uintptr_t)workspace & 15)) return RPE_EINVAL;
-    if (B > 65535) return RPE_EUNSUPPORTED;
+// (arguments checked by rpe_knn_multi; the workspace holds rpe_nearest2d_workspace_bytes(B, M) bytes, 16-byte aligned)
+int rpe_nearest2d(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd, const float *query, int64_t q_sb, int64_t q_sn,
+                  int64_t q_sd, int B, int M, int Q, int64_t *idx, float *dist, void *workspace, hipStream_t st) {
     if (B == 0 || Q == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
     const int64_t stride = ws_stride_bytes(M);
     hipLaunchKernelGGL(nearest2d_build_kernel, dim3(B), dim3(kBuildThreads), 0, st, input, in_sb, in_sn, in_sd, query, q_sb, q_sn, q_sd, M, Q,
                        (char *)workspace, stride);

@@ -205,9 +205,9 @@ int launch_pw(const PwArgs &a, int B, bool vec, hipStream_t st) {
 
 }  // namespace
 
-RPE_API int rpe_pointwise_conv_strided(const float *x, int64_t x_batch_stride, int B, int Cin, int64_t P, const float *packed_weight,
-                                       int64_t weight_batch_stride, int Cout, const float *scale, const float *shift, int act, float slope,
-                                       const float *residual, float *y, rpe_stream_t stream) {
+RPE_API int rpe_pointwise_conv(const float *x, int64_t x_batch_stride, int B, int Cin, int64_t P, const float *packed_weight,
+                               int64_t weight_batch_stride, int Cout, const float *scale, const float *shift, int act, float slope,
+                               const float *residual, float *y, rpe_stream_t stream) {
     if (!x || !packed_weight || !y || B < 0 || Cin < 1 || Cout < 1 || P < 0 || act < 0 || act > 2) return RPE_EINVAL;
     if (x_batch_stride < (int64_t)Cin * P || weight_batch_stride < 0) return RPE_EINVAL;
     if (B == 0 || P == 0) return 0;
@@ -231,9 +231,4 @@ RPE_API int rpe_pointwise_conv_strided(const float *x, int64_t x_batch_stride, i
     if (a.n_otiles >= 16 && wgs1 >= 4 * 1024) return launch_pw<4>(a, B, vec, st);
     if (a.n_otiles >= 8 && wgs1 >= 2 * 1024) return launch_pw<2>(a, B, vec, st);
     return launch_pw<1>(a, B, vec, st);
-}
-
-RPE_API int rpe_pointwise_conv(const float *x, int B, int Cin, int64_t P, const float *packed_weight, int Cout, const float *scale,
-                               const float *shift, int act, float slope, const float *residual, float *y, rpe_stream_t stream) {
-    return rpe_pointwise_conv_strided(x, (int64_t)Cin * P, B, Cin, P, packed_weight, 0, Cout, scale, shift, act, slope, residual, y, stream);
 }

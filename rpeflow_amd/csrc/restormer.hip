@@ -403,17 +403,15 @@ static int launch_layernorm(const NormJobs &jobs, int njobs, int B, int C, int64
     return rpe_launch_status();
 }
 
-RPE_API int rpe_channel_layernorm(const float *x, const float *weight, const float *bias, int B, int C, int64_t P, float eps,
-                                  float *out, rpe_stream_t stream) {
-    if (!x || !weight || !out || B < 0 || C < 1 || P < 0) return RPE_EINVAL;
-    NormJobs jobs{{x, x}, {weight, weight}, {bias, bias}, {out, out}};
-    return launch_layernorm(jobs, 1, B, C, P, eps, (hipStream_t)stream);
-}
-
-RPE_API int rpe_channel_layernorm_pair(const float *x0, const float *weight0, const float *bias0, float *out0, const float *x1,
-                                       const float *weight1, const float *bias1, float *out1, int B, int C, int64_t P, float eps,
-                                       rpe_stream_t stream) {
-    if (!x0 || !weight0 || !out0 || !x1 || !weight1 || !out1 || B < 0 || C < 1 || P < 0) return RPE_EINVAL;
+RPE_API int rpe_channel_layernorm(const float *x0, const float *weight0, const float *bias0, float *out0, const float *x1,
+                                  const float *weight1, const float *bias1, float *out1, int B, int C, int64_t P, float eps,
+                                  rpe_stream_t stream) {
+    if (!x0 || !weight0 || !out0 || B < 0 || C < 1 || P < 0) return RPE_EINVAL;
+    if (!x1) {  // one map
+        NormJobs jobs{{x0, x0}, {weight0, weight0}, {bias0, bias0}, {out0, out0}};
+        return launch_layernorm(jobs, 1, B, C, P, eps, (hipStream_t)stream);
+    }
+    if (!weight1 || !out1) return RPE_EINVAL;
     NormJobs jobs{{x0, x1}, {weight0, weight1}, {bias0, bias1}, {out0, out1}};
     return launch_layernorm(jobs, 2, B, C, P, eps, (hipStream_t)stream);
 }

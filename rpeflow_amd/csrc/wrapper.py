@@ -128,49 +128,22 @@ def k_nearest_neighbor(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int,
     return k_nearest_neighbor_ties(input_xyz, query_xyz, k, cpp_impl=cpp_impl, ties="torch")
 
 
-class GridSet:
-    """A point set [B,N,D] in Morton-cell order (rpe_knn_grid_build, csrc/knn_grid.h): the spatial order
-    k_nearest_neighbor's grid kernel searches in.  One built set serves every search on that cloud -- as the cloud or as
-    the queries; ``points`` is the channel-last view it was built from (kept: equal distances are resolved on it)."""
-
-    def __init__(self, points):
-        B, N, D = points.shape
-        npad = (N + 63) // 64 * 64
-        self.points, self.shape = points, (B, N, D)
-        self.sorted = torch.empty((B, npad // 64, 4, 64), dtype=torch.float32, device=points.device)  # step records, csrc/knn_grid.h
-        self.perm = torch.empty((B, npad), dtype=torch.int32, device=points.device)
-        self.boxes = torch.empty((B, npad // 64 + 1, 8), dtype=torch.float32, device=points.device)
-        with torch.cuda.device(points.device):
-            rc = _lib.lib().rpe_knn_grid_build(_ptr(points), *points.stride(), B, N, D, _ptr(self.sorted), _ptr(self.perm),
-                                               _ptr(self.boxes), _lib.stream_of(points))
-        _lib.check(rc, "knn_grid_build")
-
-
-def _same_view(a, b):
-    return a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
-
-
-# the grid kernel's regime (measured against the sweeping kernels, B = 4 / 8): k >= 2 searches of clouds from 1024 points with
-# at least 16384 queries a launch -- where rpe_knn would run the matrix-pipe sweep
-_GRID_MIN_M, _GRID_MIN_QUERIES = 1 << 30, 16384  # (not yet faster than the sweep anywhere: explicit algo="grid" only)
-
-
-# the binned nearest-point search (csrc/knn_binned.hip: k = 1, D = 2) against the sweeping kernels: two launches (8 us to bin
-# the clouds, then a search whose waves meet ~50 points instead of the whole cloud).  Measured, both frames of a batch of 4
-# (tools/knn2d_bench.py, kernel time): 4096 points / 144 x 240 queries 8 + 22 us against 201; 2048 / 72 x 120: 8 + 13 against 34;
-# 1024 / 36 x 60: 8 + 10 against 10 -- from 2048 points on
-_BINNED_MIN_M, _BINNED_MIN_QUERIES = 2048, 16384
+def _knn_workspace(lib, sizes, D, k, mode, device):
+    """Scratch for rpe_knn / rpe_knn_multi (include/rpeflow_hip.h): the binned cloud of a k = 1, D = 2 search, the tied-row
+    queues of a large k >= 2 search; a fresh uninitialised tensor per call (inside a graph capture it comes from the graph's
+    pool), None when the search needs none."""
+    need = sum(lib.rpe_knn_workspace_bytes(B, M, Q, D, int(k), mode) for B, M, Q in sizes)
+    return torch.empty(need, dtype=torch.uint8, device=device) if need > 0 else None
 
 
 def k_nearest_neighbor_ties(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k: int, cpp_impl=True, ties="torch", algo="auto",
-                            input_grid=None, query_grid=None, return_distances=False):
+                            return_distances=False):
     """k_nearest_neighbor with the treatment of EQUAL distances chosen per call (no global state): "torch" -- as above;
     "set" -- the reference's neighbour SET, equal distances inside it in index order (cheaper); "index" -- lowest index
     first (RPE_KNN_TIES_* of include/rpeflow_hip.h).
-    ``algo``: "auto" | "grid" (spatially ordered sets, csrc/knn_grid.h; raises where the kernel does not apply) | "sweep"
-    (every query against every point) | "binned" (k = 1, D = 2: the cloud in a uniform cell grid, csrc/knn_binned.hip; what
-    "auto" picks for the model's nearest-projected-point searches); identical results whichever runs.  ``input_grid`` / ``query_grid``: GridSet of the
-    cloud / the queries when the caller holds one (a cloud is searched several times per pyramid level)."""
+    ``algo``: "auto" | "sweep" (every query against every point) | "binned" (k = 1, D = 2: the cloud in a uniform cell grid,
+    csrc/knn_binned.hip; what "auto" picks for the model's nearest-projected-point searches; raises where it does not apply);
+    identical results whichever runs."""
     _as_points(input_xyz, "k_nearest_neighbor", "input_xyz")
     _as_points(query_xyz, "k_nearest_neighbor", "query_xyz")
     if input_xyz.shape[1] <= 3:  # channel_first to channel_last (a view; the kernel takes strides)
@@ -188,38 +161,22 @@ def k_nearest_neighbor_ties(input_xyz: torch.Tensor, query_xyz: torch.Tensor, k:
         raise RuntimeError("selected index k out of range")  # what the fallback's topk raises
     idx = torch.empty((B, Q, k), dtype=torch.int64, device=input_xyz.device)
     dist = torch.empty((B, Q, k), dtype=torch.float32, device=input_xyz.device) if return_distances else None
-    lib, mode = _lib.lib(), _lib.KNN_TIES[ties]
-    grid_ok = B > 0 and Q > 0 and bool(lib.rpe_knn_grid_supported(B, M, Q, D, int(k), mode))
-    if algo == "grid" and not grid_ok:
-        raise RuntimeError("k_nearest_neighbor: the grid kernel takes 2 <= k <= 31 (30 with tie handling), 64 k <= M <= 16384")
-    use_grid = grid_ok and (algo == "grid" or (algo == "auto" and (input_grid is not None or (M >= _GRID_MIN_M and B * Q >= _GRID_MIN_QUERIES))))
-    use_binned = (algo in ("auto", "binned") and D == 2 and k == 1 and not use_grid and M >= 64
-                  and (algo == "binned" or (M >= _BINNED_MIN_M and B * Q >= _BINNED_MIN_QUERIES)))
-    if algo == "binned" and not use_binned:
+    lib, mode = _lib.lib(), _lib.KNN_TIES[ties] | _lib.KNN_ALGO[algo]
+    if algo == "binned" and not (D == 2 and k == 1 and M >= 64):
         raise RuntimeError("k_nearest_neighbor: the binned search takes k = 1, D = 2, M >= 64")
     with torch.cuda.device(input_xyz.device):
-        if use_binned:  # (the result does not depend on the tie mode: k = 1 keeps the lowest index among equal distances)
-            work = torch.empty(lib.rpe_knn_nearest2d_workspace_bytes(B, M), dtype=torch.uint8, device=input_xyz.device)
-            rc = lib.rpe_knn_nearest2d(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(), B, M, Q, _ptr(idx),
-                                       _ptr(dist) if dist is not None else _NULL, _ptr(work), work.numel(), _lib.stream_of(input_xyz))
-        elif use_grid:
-            gi = input_grid if input_grid is not None else GridSet(input_xyz)
-            gq = query_grid if query_grid is not None else (gi if _same_view(input_xyz, query_xyz) else GridSet(query_xyz))
-            assert gi.shape == (B, M, D) and gq.shape == (B, Q, D), "GridSet built from another point set"
-            rc = lib.rpe_knn_grid_search(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(), B, M, Q, D, int(k), mode,
-                                         _ptr(gi.sorted), _ptr(gi.perm), _ptr(gi.boxes), _ptr(gq.sorted), _ptr(gq.perm), _ptr(idx),
-                                         _ptr(dist) if dist is not None else _NULL, _lib.stream_of(input_xyz))
-        else:
-            rc = lib.rpe_knn(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(),
-                             B, M, Q, D, int(k), mode, _ptr(idx), _ptr(dist) if dist is not None else _NULL, _lib.stream_of(input_xyz))
+        work = _knn_workspace(lib, [(B, M, Q)], D, k, mode, input_xyz.device)
+        rc = lib.rpe_knn(_ptr(input_xyz), *input_xyz.stride(), _ptr(query_xyz), *query_xyz.stride(), B, M, Q, D, int(k), mode, _ptr(idx),
+                         _ptr(dist) if dist is not None else _NULL, _ptr(work) if work is not None else _NULL,
+                         work.numel() if work is not None else 0, _lib.stream_of(input_xyz))
     _lib.check(rc, "k_nearest_neighbor")
     return (idx, dist) if return_distances else idx
 
 
 def k_nearest_neighbor_multi(pairs, k: int, ties="torch"):
     """[(input_xyz, query_xyz), ...] with one batch size, dimension and k -> [idx, ...], each exactly
-    k_nearest_neighbor(input_xyz, query_xyz, k), from ONE launch (at most 8 pairs)."""
-    jobs, outs, keep = (_lib.KnnJob * len(pairs))(), [], []
+    k_nearest_neighbor(input_xyz, query_xyz, k), from ONE call (at most 8 pairs; searches of one kind share a launch)."""
+    jobs, outs, keep, sizes = (_lib.KnnJob * len(pairs))(), [], [], []
     B = D = None
     for i, (inp, qry) in enumerate(pairs):
         _as_points(inp, "k_nearest_neighbor", "input_xyz")
@@ -238,8 +195,12 @@ def k_nearest_neighbor_multi(pairs, k: int, ties="torch"):
                               idx.data_ptr(), None)
         outs.append(idx)
         keep += [inp, qry]
+        sizes.append((B, inp.shape[1], qry.shape[1]))
+    lib, mode = _lib.lib(), _lib.KNN_TIES[ties]
     with torch.cuda.device(outs[0].device):
-        rc = _lib.lib().rpe_knn_multi(ctypes.byref(jobs), len(pairs), B, D, int(k), _lib.KNN_TIES[ties], _lib.stream_of(outs[0]))
+        work = _knn_workspace(lib, sizes, D, k, mode, outs[0].device)
+        rc = lib.rpe_knn_multi(ctypes.byref(jobs), len(pairs), B, D, int(k), mode, _ptr(work) if work is not None else _NULL,
+                               work.numel() if work is not None else 0, _lib.stream_of(outs[0]))
     _lib.check(rc, "k_nearest_neighbor_multi")
     return outs
 

@@ -48,7 +48,8 @@ def channel_layernorm(x, weight, bias=None, eps=1e-5):
     w = weight.detach().contiguous().float()
     b = bias.detach().contiguous().float() if bias is not None else None
     with torch.cuda.device(x.device):
-        rc = _lib.lib().rpe_channel_layernorm(_ptr(x), _ptr(w), _ptr(b), B, C, P, float(eps), _ptr(out), _lib.stream_of(x))
+        rc = _lib.lib().rpe_channel_layernorm(_ptr(x), _ptr(w), _ptr(b), _ptr(out), _NULL, _NULL, _NULL, _NULL, B, C, P, float(eps),
+                                              _lib.stream_of(x))
     _lib.check(rc, "channel_layernorm")
     return out
 
@@ -64,8 +65,8 @@ def channel_layernorm_pair(x, wx, bx, y, wy, by, eps=1e-5):
     f = lambda t: t.detach().contiguous().float() if t is not None else None
     wx, bx, wy, by = f(wx), f(bx), f(wy), f(by)
     with torch.cuda.device(x.device):
-        rc = _lib.lib().rpe_channel_layernorm_pair(_ptr(x), _ptr(wx), _ptr(bx), _ptr(ox), _ptr(y), _ptr(wy), _ptr(by), _ptr(oy),
-                                                   B, C, P, float(eps), _lib.stream_of(x))
+        rc = _lib.lib().rpe_channel_layernorm(_ptr(x), _ptr(wx), _ptr(bx), _ptr(ox), _ptr(y), _ptr(wy), _ptr(by), _ptr(oy),
+                                              B, C, P, float(eps), _lib.stream_of(x))
     _lib.check(rc, "channel_layernorm_pair")
     return ox, oy
 
@@ -131,10 +132,9 @@ def channel_attention_matrix(qkv, heads, temperature, w_out, eps=1e-12, packed=F
     ws = torch.empty(L.rpe_channel_attention_workspace_floats(B, heads, c, P), dtype=torch.float32, device=qkv.device)
     m = torch.empty((B, (C + 15) // 16, (C + 3) // 4, 64) if packed else (B, C, C), dtype=torch.float32, device=qkv.device)
     q_ptr = qkv.data_ptr()
-    fn = L.rpe_channel_attention_matrix_packed if packed else L.rpe_channel_attention_matrix
     with torch.cuda.device(qkv.device):
-        rc = fn(ctypes.c_void_p(q_ptr), ctypes.c_void_p(q_ptr + 4 * C * P), 3 * C * P, _ptr(t), _ptr(w),
-                B, heads, c, P, float(eps), _ptr(ws), _ptr(m), _lib.stream_of(qkv))
+        rc = L.rpe_channel_attention_matrix(ctypes.c_void_p(q_ptr), ctypes.c_void_p(q_ptr + 4 * C * P), 3 * C * P, _ptr(t), _ptr(w),
+                                            B, heads, c, P, float(eps), _ptr(ws), _ptr(m), int(bool(packed)), _lib.stream_of(qkv))
     _lib.check(rc, "channel_attention_matrix")
     return m
 
@@ -148,9 +148,9 @@ def attention_apply(qkv, m_packed, residual=None, bias=None):
     res = None if residual is None else (residual if (residual.dtype == torch.float32 and residual.is_contiguous()) else residual.float().contiguous())
     out = torch.empty((B, C) + tuple(qkv.shape[2:]), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
-        rc = _lib.lib().rpe_pointwise_conv_strided(ctypes.c_void_p(qkv.data_ptr() + 4 * 2 * C * P), 3 * C * P, B, C, P, _ptr(m_packed),
-                                                   m_packed[0].numel(), C, _NULL, _ptr(bias.float().contiguous()) if bias is not None else _NULL,
-                                                   0, 0.1, _ptr(res) if res is not None else _NULL, _ptr(out), _lib.stream_of(qkv))
+        rc = _lib.lib().rpe_pointwise_conv(ctypes.c_void_p(qkv.data_ptr() + 4 * 2 * C * P), 3 * C * P, B, C, P, _ptr(m_packed),
+                                           m_packed[0].numel(), C, _NULL, _ptr(bias.float().contiguous()) if bias is not None else _NULL,
+                                           0, 0.1, _ptr(res) if res is not None else _NULL, _ptr(out), _lib.stream_of(qkv))
     _lib.check(rc, "attention_apply")
     return out
 

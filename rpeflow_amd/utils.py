@@ -112,7 +112,7 @@ def pointwise_conv(x, weight, bias=None, stride=1, residual=None, inplace=False,
         xf = _f32(xf).contiguous()
         res = None if residual is None else _f32(residual).reshape(B, cout, P).contiguous()
         out = res if (inplace and res is not None and res.data_ptr() == residual.data_ptr()) else torch.empty((B, cout, P), dtype=torch.float32, device=x.device)
-        _launch(xf, "pointwise_conv", _lib.lib().rpe_pointwise_conv, _ptr(xf), B, C, P, _ptr(_pw_packed_weight(weight)), cout,
+        _launch(xf, "pointwise_conv", _lib.lib().rpe_pointwise_conv, _ptr(xf), C * P, B, C, P, _ptr(_pw_packed_weight(weight)), 0, cout,
                 _ptr(scale) if scale is not None else _NULL, _ptr(shift.contiguous()) if shift is not None else _NULL,
                 _ACT_CODE[kind], 0.1, _ptr(res) if res is not None else _NULL, _ptr(out))
         return out.reshape((B, cout) + tuple(spatial))
@@ -211,7 +211,7 @@ def im2col_conv(x, weight, bias, stride, padding, dilation, epilogue=None, pendi
         x = _f32(x).contiguous()  # the kernel indexes a dense [B, C, H, W]: channels_last or channel-sliced inputs are copied once
         cols = torch.empty((B, k[1] * k[2] * k[3], ho * wo), dtype=torch.float32, device=x.device)
         scale, shift, act = pending if pending is not None else (None, None, None)
-        _launch(x, "im2col", _lib.lib().rpe_im2col_act, _ptr(x), B, k[1], H, W, k[2], k[3], stride[0], stride[1], padding[0], padding[1],
+        _launch(x, "im2col", _lib.lib().rpe_im2col, _ptr(x), B, k[1], H, W, k[2], k[3], stride[0], stride[1], padding[0], padding[1],
                 dilation[0], dilation[1], _ptr(scale), _ptr(shift), {None: 0, "relu": 1, "leaky_relu": 2}[act], 0.1, _ptr(cols))
     else:
         assert pending is None
@@ -632,7 +632,7 @@ def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=
         sampled_2d = _f32(sampled_2d)
         assert sampled_2d.shape == (B, C2, N)
         sm_strides = sampled_2d.stride()
-    _launch(feat_2d, "project_feat_with_nn_corr", _lib.lib().rpe_project_feat_nn_corr_fused,
+    _launch(feat_2d, "project_feat_with_nn_corr", _lib.lib().rpe_project_feat_nn_corr,
             _ptr(xy), *xy.stride(), _ptr(feat_2d), C2, H, W, _ptr(sampled_2d), *sm_strides, _ptr(feat_3d), *feat_3d.stride(), C3,
             _ptr(nn_indices), _ptr(subtract_last), n_sub, _ptr(append), n_app, B, N, _ptr(rows), _ptr(out))
     return out

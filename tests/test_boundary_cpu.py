@@ -14,19 +14,47 @@ import rpeflow_amd.csrc as ops
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
+def declared_symbols(experimental=False):
+    """Entry points include/rpeflow_hip.h declares: the default library's, or those of the #ifdef RPE_EXPERIMENTAL blocks."""
     text = open(os.path.join(ROOT, "include", "rpeflow_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rpe_[a-z0-9_]+)\s*\(", text)))
+    blocks = re.findall(r"#ifdef RPE_EXPERIMENTAL(.*?)#endif", text, flags=re.S)
+    if not experimental:
+        text = re.sub(r"#ifdef RPE_EXPERIMENTAL.*?#endif", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rpe_[a-z0-9_]+)\s*\(", "".join(blocks) if experimental else text)))
+
+
+def exported_symbols():
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if " T rpe_" in line)
 
 
 def test_library_builds_and_exports_header_symbols():
+    """The default library exports EXACTLY what the header declares outside its RPE_EXPERIMENTAL blocks -- no kept experiments
+    (round-3 review: ~50 entry points, a dozen dispatched nowhere) -- and at most 40 entry points."""
+    assert not os.environ.get("RPE_EXPERIMENTAL"), "this test checks the default build"
     build.build()
     handle = ctypes.CDLL(_lib.LIB_PATH)
     names = declared_symbols()
     assert "rpe_knn" in names and "rpe_fps" in names and "rpe_correlation2d_forward" in names
     for name in names:
         assert hasattr(handle, name), f"{name} declared in rpeflow_hip.h but not exported"
+    assert exported_symbols() == names, set(exported_symbols()) ^ set(names)
+    assert len(names) <= 40
+    assert declared_symbols(experimental=True) == sorted(_lib._EXPERIMENTAL)
+
+
+def test_every_entry_point_is_called_by_the_package():
+    """... and each of them is what rpeflow_amd itself calls (rpe_fps_algo: the kernel-choice form of rpe_fps the parity tests
+    use to cross-check the two sampling kernels on the same cloud)."""
+    text = ""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rpeflow_amd")):
+        for f in files:
+            if f.endswith(".py") and f != "_lib.py":
+                text += open(os.path.join(dirpath, f)).read()
+    unused = [n for n in declared_symbols() if not re.search(r"\b%s\b" % n, text)]
+    assert set(unused) <= {"rpe_abi_version", "rpe_error_string", "rpe_fps_algo"}, unused
 
 
 def test_ctypes_prototypes_cover_the_header():

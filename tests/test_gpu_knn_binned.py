@@ -1,4 +1,4 @@
-"""k_nearest_neighbor, k = 1, D = 2 on the binned cloud (csrc/knn_binned.hip, rpe_knn_nearest2d) -- what the model's
+"""k_nearest_neighbor, k = 1, D = 2 on the binned cloud (csrc/knn_binned.hip, reached through rpe_knn's workspace) -- what the model's
 nearest-projected-point searches run through (RPEFlow_core.py:327-330 -> wrapper.py:106-127).  The kernel prunes by cell
 geometry, so every test asks for EXACT agreement -- indices and distance bit patterns -- with the sweeping kernels (every
 pair evaluated), the oracle and the reference goldens, on raster and non-raster queries and on clouds built to break a pruning
@@ -198,17 +198,32 @@ def test_ids_range_clouds_with_rounding_level_ties():
     assert_same(dev(far), dev(grid + np.float32(3000.0)), "large offset")
 
 
-def test_workspace_is_checked():
+def test_workspace_contract():
+    """rpe_knn's optional workspace: results never depend on it; too little of it means the sweep ("auto") or an error (when
+    the binned search was asked for explicitly); a misaligned pointer is refused."""
     from rpeflow_amd import _lib
     lib = _lib.lib()
-    pts, qry = dev(I.pixel_cloud(I.rng(1), 1, 256, 9, 15)), dev(raster(1, 9, 15))
-    idx = torch.empty((1, 135, 1), dtype=torch.int64, device=DEV)
-    need = lib.rpe_knn_nearest2d_workspace_bytes(1, 256)
-    assert need >= 16 * 256
-    work = torch.empty(need, dtype=torch.uint8, device=DEV)
-    args = (pts.data_ptr(), *pts.stride(), qry.data_ptr(), *qry.stride(), 1, 256, 135, idx.data_ptr(), None)
-    assert lib.rpe_knn_nearest2d(*args, work.data_ptr(), need - 1, None) == -1
-    assert lib.rpe_knn_nearest2d(*args, None, need, None) == -1
-    assert lib.rpe_knn_nearest2d(*args, work.data_ptr(), need, None) == 0
-    torch.cuda.synchronize()
-    assert torch.equal(idx, W.k_nearest_neighbor_ties(pts, qry, 1, algo="sweep"))
+    r = I.rng(1)
+    pts, qry = dev(I.pixel_cloud(r, 8, 2048, 72, 120)), dev(raster(8, 72, 120))
+    want = W.k_nearest_neighbor_ties(pts, qry, 1, algo="sweep")
+    B, M, Q = 8, 2048, 72 * 120
+    need = lib.rpe_knn_workspace_bytes(B, M, Q, 2, 1, 3)
+    assert need >= 16 * M * B and lib.rpe_knn_workspace_bytes(B, M, Q, 2, 1, 3 | 0x100) == 0  # (forced sweep: none)
+    assert lib.rpe_knn_workspace_bytes(B, 256, 135, 2, 1, 3) == 0 and lib.rpe_knn_workspace_bytes(B, 256, 135, 2, 1, 3 | 0x200) > 0
+    work = torch.empty(need + 16, dtype=torch.uint8, device=DEV)
+
+    def call(mode, ptr, nbytes):
+        idx = torch.full((B, Q, 1), -7, dtype=torch.int64, device=DEV)
+        rc = lib.rpe_knn(pts.data_ptr(), *pts.stride(), qry.data_ptr(), *qry.stride(), B, M, Q, 2, 1, mode, idx.data_ptr(), None, ptr, nbytes, None)
+        torch.cuda.synchronize()
+        return rc, idx
+
+    for mode, ptr, nbytes in ((3, work.data_ptr(), need), (3, None, 0), (3, work.data_ptr(), need - 16), (3 | 0x100, work.data_ptr(), need),
+                              (3 | 0x200, work.data_ptr(), need), (0, work.data_ptr(), need)):
+        rc, idx = call(mode, ptr, nbytes)
+        assert rc == 0 and torch.equal(idx, want), (mode, nbytes)
+    assert call(3 | 0x200, work.data_ptr(), need - 16)[0] == -1   # binned demanded, workspace too small
+    assert call(3 | 0x200, None, 0)[0] == -1
+    assert call(3, work.data_ptr() + 4, need)[0] == -1            # misaligned
+    assert call(3 | 0x300, work.data_ptr(), need)[0] == -1        # both algorithm flags
+    assert call(2, None, 0)[0] == -1                              # not a tie mode

@@ -35,7 +35,10 @@ def test_library_is_loaded_from_tree():
 
 
 def test_mfma_4x4x1_layout_probe():
-    """The correlation kernel assumes: A lane 4g+i, B lane 4g+j -> D register i, lane 4g+j."""
+    """The correlation kernel assumes: A lane 4g+i, B lane 4g+j -> D register i, lane 4g+j.  (A development probe: only a
+    library built with -DRPE_EXPERIMENTAL exports it; the correlation goldens test the same assumption end to end.)"""
+    if not hasattr(_lib.lib(), "rpe_probe_mfma4x4"):
+        pytest.skip("default build: rpe_probe_mfma4x4 is an RPE_EXPERIMENTAL entry point")
     out = torch.zeros(256, device=DEV)
     _lib.check(_lib.lib().rpe_probe_mfma4x4(out.data_ptr(), None), "probe")
     d = out.cpu().numpy().reshape(64, 4)
@@ -161,6 +164,41 @@ def test_knn_nearest_pixel_search_full_size():
     assert_bits_equal(dist[:, rows], od)
 
 
+@pytest.mark.parametrize("B,M,Q,D,k,kind", [(8, 8192, 4096, 3, 16, "ids"), (2, 1500, 8200, 3, 17, "lattice"), (1, 2048, 16384, 3, 16, "lattice"),
+                                              (4, 1100, 4100, 2, 3, "lattice"), (4, 4096, 8192, 3, 3, "ids"), (2, 1030, 8192, 1, 2, "lattice"),
+                                              (3, 16384, 5500, 3, 5, "ids"), (1, 16448, 16384, 3, 16, "ids"), (70, 1024, 4100, 3, 16, "ids")])
+def test_knn_tied_rows_replayed_by_the_second_launch(B, M, Q, D, k, kind):
+    """With workspace the matrix kernel hands its tied rows to knn_tie_replay_kernel (a grid of its own: the row's distances
+    put into LDS by four waves, libstdc++'s heap code replayed on them by one); without, it redoes them itself at the end of the
+    launch.  Same rows, same arithmetic, same restatement: indices and distances bit for bit, in every tie mode -- on lattice
+    clouds (every row tied), IDS-range clouds (~1 % tied), a cloud at the LDS limit (16384 points), one beyond it and a launch
+    with more workgroups than the replay kernel scans (both: the in-kernel path even with workspace)."""
+    r = I.rng(9700 + M + k)
+    if kind == "lattice":
+        inp, qry = r.integers(0, 6, (B, M, D)).astype(np.float32), r.integers(0, 6, (B, Q, D)).astype(np.float32)
+    else:
+        inp, qry = I.ids_cloud(r, B, M, D), I.ids_cloud(r, B, Q, D)
+    ti, tq = dev(inp), dev(qry)
+    lib = _lib.lib()
+    for ties in ("torch", "set", "index"):
+        mode = _lib.KNN_TIES[ties]
+        got_i, got_d = W.k_nearest_neighbor_with_distances(ti, tq, k, ties=ties)  # (allocates the workspace)
+        idx = torch.empty((B, Q, k), dtype=torch.int64, device=DEV)
+        dist = torch.empty((B, Q, k), dtype=torch.float32, device=DEV)
+        _lib.check(lib.rpe_knn(ti.data_ptr(), *ti.stride(), tq.data_ptr(), *tq.stride(), B, M, Q, D, k, mode, idx.data_ptr(), dist.data_ptr(),
+                               None, 0, None), "rpe_knn without workspace")
+        torch.cuda.synchronize()
+        assert torch.equal(got_i, idx), (ties, int((got_i != idx).sum()))
+        assert torch.equal(got_d.view(torch.int32), dist.view(torch.int32)), ties
+    need = lib.rpe_knn_workspace_bytes(B, M, Q, D, k, 3)
+    assert (need > 0) == (M <= 16384 and B * ((Q + 63) // 64) <= 4096) and lib.rpe_knn_workspace_bytes(B, M, Q, D, k, 0) == 0
+    rows = r.choice(Q, 40, replace=False)
+    oi, od = O.k_nearest_neighbor(inp[:1], qry[:1, rows], k, return_dists=True)
+    got_i, got_d = W.k_nearest_neighbor_with_distances(ti, tq, k)  # ... and both equal the reference's order (oracle, sampled rows)
+    assert np.array_equal(got_i[:1, rows].cpu().numpy(), oi)
+    assert_bits_equal(got_d[:1, rows].cpu().numpy(), od)
+
+
 def test_knn_errors():
     x = torch.rand(1, 10, 3, device=DEV)
     with pytest.raises(RuntimeError):  # fallback's topk: k > M
@@ -191,10 +229,9 @@ def _fps_algo(xyz, S, algo):
     return idx.cpu().numpy()
 
 
-@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("algo", [1, 2])
 def test_fps_both_kernels_agree(golden_dir, algo):
-    """The plain kernel, the cluster-skipping kernel and its paired form (two samples per synchronisation round where the
-    sequential rule provably gives them) return identical samples, whichever one rpe_fps would pick."""
+    """The plain kernel and the cluster-skipping kernel return identical samples, whichever one rpe_fps would pick."""
     for name in K.FPS_CASES:
         xyz, S = K.fps_inputs(name)
         got = _fps_algo(xyz, S, algo)
@@ -208,10 +245,9 @@ def test_fps_both_kernels_agree(golden_dir, algo):
 
 
 @pytest.mark.parametrize("kind", ["duplicates", "lattice", "clusters", "odd_and_even_lengths"])
-def test_fps_paired_kernel_on_tie_heavy_clouds(kind):
-    """The paired kernel's speculation must hold back wherever equal running distances make the runner-up ambiguous: clouds
-    with every point twice, integer lattices (hundreds of equal distances), two far-apart clusters (the runner-up of one round
-    is usually the winner of the next), and sample counts of both parities (the last round may emit one or two)."""
+def test_fps_pruned_kernel_on_tie_heavy_clouds(kind):
+    """The cluster-skipping kernel where equal running distances abound: clouds with every point twice, integer lattices
+    (hundreds of equal distances), two far-apart clusters, and sample counts of both parities."""
     r = I.rng(8400)
     if kind == "duplicates":
         base = I.ids_cloud(r, 2, 1500)
@@ -226,7 +262,7 @@ def test_fps_paired_kernel_on_tie_heavy_clouds(kind):
         clouds = [(xyz, S) for S in (1, 2, 3, 1000, 1001, 4099)]
     for xyz, S in clouds:
         want = O.furthest_point_sampling(xyz, S)
-        for algo in (2, 3):
+        for algo in (1, 2):
             assert np.array_equal(_fps_algo(xyz, S, algo), want), (kind, S, algo)
 
 

@@ -1,4 +1,4 @@
-"""Sum kernel durations of a rocprofv3 kernel trace between the two marker kernels (probe_mfma4x4) of tools/prof_forward.py.
+"""Sum kernel durations of a rocprofv3 kernel trace between the two marker kernels (the stamp kernel of rpe_debug_stamp) of tools/prof_forward.py.
 Usage: python tools/trace_window.py <kernel_trace.csv> <steps>"""
 import collections
 import csv
@@ -7,7 +7,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2])
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "probe_mfma4x4" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "stamp" in r["Kernel_Name"]]
 lo, hi = marks[-2], marks[-1]
 win = rows[lo + 1:hi]
 agg = collections.defaultdict(lambda: [0, 0])
