@@ -89,6 +89,65 @@ def parse():
     return p.parse_args()
 
 
+NOMINAL_SCLK_MHZ = 2400.0   # MI355X_MICROARCH.md: peak engine clock
+HBM_COPY_GBS = 6290.0       # MI355X_MICROARCH.md: what a device-to-device copy reaches of the 8 TB/s
+
+
+class ClockSampler:
+    """Shader clock while a kernel loop runs: amdgpu's hwmon freq1_input, else one `rocm-smi --showclocks --json` call (0.3-1 s:
+    the loop it samples has to run that long).  None where neither can be read (a container without the sysfs node or the tool)."""
+
+    def __init__(self):
+        import glob
+        self.path = next((c for c in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")) if os.access(c, os.R_OK)), None)
+        self.samples, self.thread, self.stop = [], None, False
+
+    def _run(self):
+        import subprocess
+        while not self.stop:
+            mhz = None
+            try:
+                if self.path:
+                    mhz = float(open(self.path).read()) / 1e6
+                    time.sleep(0.01)
+                else:
+                    out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+                    for k, v in next(iter(json.loads(out).values())).items():
+                        if k.startswith("sclk clock speed"):
+                            mhz = float(str(v).strip("()").lower().replace("mhz", ""))
+            except Exception:  # noqa: BLE001 -- no clock reading on this machine
+                return
+            if mhz:
+                self.samples.append(mhz)
+
+    def __enter__(self):
+        import threading
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        self.thread.join(timeout=6)
+
+    def mean(self):
+        return round(sum(self.samples) / len(self.samples), 1) if self.samples else None
+
+
+def pmc_traffic(suffix):
+    """(HBM bytes per launch, file) from the newest PMC summary committed under profiles/ (rocprofv3 cannot run inside this
+    process; the passes are `tools/profile_round*.sh`'s, collected as MI355X_MICROARCH.md prescribes)."""
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith(suffix):
+            return int(json.load(open(os.path.join(ROOT, "profiles", name)))["derived"]["hbm_traffic_bytes"]), "profiles/" + name
+    return None, None
+
+
+def clocked(frac, sclk):
+    """Extra fields of a roofline object: the clock the loop ran at and the fraction scaled to the nominal clock."""
+    return {"sclk_MHz": sclk, "frac_at_nominal_clock": round(frac * NOMINAL_SCLK_MHZ / sclk, 4) if sclk else None}
+
+
 def corr_microbench(dev, iters=40):
     """BASELINE config 2: correlation2d 1x256x544x960, md=4, fp32, NCHW in/out."""
     import rpeflow_amd.csrc as ops
@@ -104,15 +163,19 @@ def corr_microbench(dev, iters=40):
     e.record()
     torch.cuda.synchronize()
     us = s.elapsed_time(e) / iters * 1e3
+    with ClockSampler() as clock:  # the same loop again, long enough for a clock reading (untimed)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < (0.25 if clock.path else 1.5):
+            for _ in range(20):
+                ops.correlation2d(a, b, 4)
+            torch.cuda.synchronize()
     alg = 2 * a.numel() * 4 + 81 * H * W * 4  # 1 238 753 280 B
     gbs = alg / us / 1e3
-    traffic = None  # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process)
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-        if name.endswith("corr_microbench_pmc.json"):
-            traffic = int(json.load(open(os.path.join(ROOT, "profiles", name)))["derived"]["hbm_traffic_bytes"])
-            break
+    traffic, source = pmc_traffic("corr_microbench_pmc.json")
+    frac = gbs / HBM_PEAK_GBS
     return {"kernel": "corr_mfma_dma_kernel<2,8,2,3,3,true>", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "us_per_launch": round(us, 1),
+            "frac": round(frac, 4), "traffic": traffic, "traffic_source": source, "us_per_launch": round(us, 1),
+            **clocked(frac, clock.mean()), "frac_of_measured_copy_bw": round(gbs / HBM_COPY_GBS, 4),
             "algorithmic_bytes": alg, "workload": "correlation2d 1x256x544x960 md=4 fp32 NCHW (BASELINE config 2)"}
 
 
@@ -134,6 +197,12 @@ def knn_microbench(dev, iters=30):
     e.record()
     torch.cuda.synchronize()
     us = s.elapsed_time(e) / iters * 1e3
+    with ClockSampler() as clock:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < (0.25 if clock.path else 1.5):
+            for _ in range(20):
+                ops.k_nearest_neighbor(cloud, query, k)
+            torch.cuda.synchronize()
     from rpeflow_amd.csrc.wrapper import k_nearest_neighbor_ties
     for _ in range(5):
         k_nearest_neighbor_ties(cloud, query, k, ties="index")
@@ -145,20 +214,15 @@ def knn_microbench(dev, iters=30):
     us_index = s.elapsed_time(e) / iters * 1e3
     pairs = B * M * Q
     tflops = pairs * (2 * D + 3) / us / 1e6
-    return {"kernel": "knn_mfma_kernel<3> (+ the workgroup's tied queries redone the libstdc++ way)", "bound": "mfma", "achieved": round(tflops, 2),
-            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": pmc_traffic("knn16_pmc.json"),
-            "us_per_launch": round(us, 1), "pairs_per_s": round(pairs / us * 1e6), "algorithmic_bytes": 4 * B * D * (M + Q) + 8 * B * Q * k,
+    traffic, source = pmc_traffic("knn16_pmc.json")
+    frac = tflops / MFMA_F32_PEAK_TFLOPS
+    return {"kernel": "knn_mfma_kernel<3, true> + knn_tie_replay_kernel<3> (the sweep, then its tied rows redone the libstdc++ way by a second launch)",
+            "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(frac, 4),
+            "traffic": traffic, "traffic_source": source, **clocked(frac, clock.mean()),
+            "us_per_launch": round(us, 1), "launches": 2, "pairs_per_s": round(pairs / us * 1e6), "algorithmic_bytes": 4 * B * D * (M + Q) + 8 * B * Q * k,
             "us_per_launch_lowest_index_ties": round(us_index, 1),  # the same search without the libstdc++ restatement of equal distances
             "frac_lowest_index_ties": round(pairs * (2 * D + 3) / us_index / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
             "workload": "k_nearest_neighbor 3-D, 8 x (8192 -> 4096), k = 16, fp32, indices as torch.topk returns them"}
-
-
-def pmc_traffic(suffix):
-    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process)."""
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-        if name.endswith(suffix):
-            return int(json.load(open(os.path.join(ROOT, "profiles", name)))["derived"]["hbm_traffic_bytes"])
-    return None
 
 
 usable_cores = runtime.usable_cores  # affinity mask capped by the cgroup CPU quota (the GPU box grants 16 of 256 cores)
@@ -536,7 +600,8 @@ def main():
             "roofline": {"kernel": "fps_pruned2_kernel (furthest_point_sampling, 2B clouds 8192 -> 4096)", "bound": "latency",
                          "achieved": round(fps_bytes / fps_us / 1e3, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(fps_bytes / fps_us / 1e3 / HBM_PEAK_GBS, 6), "algorithmic_bytes": fps_bytes,
-                         "traffic": pmc_traffic("fps_pmc.json"), "us_per_launch": round(fps_us, 1), "launches_per_step": 1,
+                         "traffic": pmc_traffic("fps_pmc.json")[0], "traffic_source": pmc_traffic("fps_pmc.json")[1],
+                         "us_per_launch": round(fps_us, 1), "launches_per_step": 1,
                          "us_per_iteration": round(fps_us / 4095, 4), "iteration_sync_floor_us": 0.41,
                          "note": "the dominant single kernel of the step.  FPS is 4095 DEPENDENT sampling iterations per cloud "
                                  "(SURVEY.md 8d), one workgroup per cloud: bound by the per-iteration reduce-barrier-broadcast latency, "

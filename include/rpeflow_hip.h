@@ -127,7 +127,8 @@ int rpe_fps_algo(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
  *   out[b][(dy+md)*(2md+1)+(dx+md)][y][x] = (1/C) sum_c in1[b][c][y][x]*in2[b][c][y+dy][x+dx]
  * zero outside the image.  in1,in2 [B,C,H,W] contiguous; out [B,(2md+1)^2,H,W].
  * leaky_slope != 0 fuses the caller's leaky_relu (RPEFlow_core.py:362); pass 0
- * for the plain operator.  algo: 0 = pick; 1 = direct (any md); 2 = MFMA tiles, register-staged (md == 4);
+ * for the plain operator.  algo: 0 = pick; 1 = direct (any md); 3 = small maps (md <= 4: 64 flattened pixels x one displacement
+ * row a workgroup, channels split over its waves); 2 = MFMA tiles, register-staged (md == 4);
  * 4 / 7 = MFMA tiles behind an LDS-DMA ring, 4 / 8 waves a workgroup (md == 4, W % 4 == 0, C % 4 / C % 2 == 0, 16-byte
  * aligned inputs).  All give the same values to fp32 re-association; tests cross-check them.                        */
 int rpe_correlation2d_forward(const float *in1, const float *in2, int B, int C, int H, int W, int md,

@@ -62,6 +62,72 @@ __global__ __launch_bounds__(256) void corr_direct_kernel(const float *__restric
     out[((int64_t)b * n * n + d) * HW + (int64_t)y * W + x] = s;
 }
 
+// ---- small maps (the three coarse pyramid levels: 9 x 15 ... 36 x 60 pixels, 96 ... 192 channels) --------------------------
+// A few hundred pixels: one thread per output element is a handful of half-empty waves, each walking all C channels as a chain
+// of memory round trips (18 x 30, C = 128, B = 4: 23 us for 22 MFLOP, on the decoder's critical path).  Here a workgroup takes
+// 64 consecutive pixels (rows flattened: no lanes lost to a 15- or 30-pixel row) and ONE displacement row dy; its CG waves
+// split the channels, every lane keeps the 2 md + 1 sums of its dy row -- one in1 value against 2 md + 1 neighbouring in2 values
+// per channel, several channels' loads in flight -- and the waves' partial sums meet in LDS.  md <= 4.
+constexpr int kSmallND = 9;
+
+template <int CG>
+__global__ __launch_bounds__(CG * RPE_WAVE) void corr_small_kernel(const float *__restrict__ in1, const float *__restrict__ in2, int C, int H,
+                                                                   int W, int md, float slope, float *__restrict__ out) {
+    __shared__ float red[CG][kSmallND][RPE_WAVE];
+    const int lane = rpe_lane(), grp = threadIdx.x >> 6;
+    const int n = 2 * md + 1;
+    const int HW = H * W;
+    const int p = blockIdx.x * RPE_WAVE + lane, dyi = blockIdx.y, b = blockIdx.z;
+    const int y = p / W, x = p - y * W;
+    const int y2 = y + dyi - md;
+    const bool row_ok = p < HW && y2 >= 0 && y2 < H;
+    unsigned ok = 0;  // bit j: the pixel (y2, x + j - md) lies inside the image
+#pragma unroll
+    for (int j = 0; j < kSmallND; ++j) ok |= (row_ok && j < n && x + j - md >= 0 && x + j - md < W) ? (1u << j) : 0u;
+    const int cpg = (C + CG - 1) / CG;
+    const int c0 = grp * cpg, c1 = min(C, c0 + cpg);
+    const float *a = in1 + (int64_t)b * C * HW + p;
+    const float *v = in2 + (int64_t)b * C * HW + (int64_t)y2 * W + (x - md);
+    float acc[kSmallND];
+#pragma unroll
+    for (int j = 0; j < kSmallND; ++j) acc[j] = 0.f;
+    constexpr int CU = 4;  // channels per trip
+    for (int c = c0; c < c1; c += CU) {
+        float av[CU], vv[CU][kSmallND];
+#pragma unroll
+        for (int u = 0; u < CU; ++u) {
+            const bool cok = c + u < c1;
+            av[u] = (cok && ok) ? a[(int64_t)(c + u) * HW] : 0.f;
+#pragma unroll
+            for (int j = 0; j < kSmallND; ++j) vv[u][j] = (cok && ((ok >> j) & 1u)) ? v[(int64_t)(c + u) * HW + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < CU; ++u)
+#pragma unroll
+            for (int j = 0; j < kSmallND; ++j) acc[j] = __fmaf_rn(av[u], vv[u][j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kSmallND; ++j) red[grp][j][lane] = acc[j];
+    __syncthreads();
+    for (int t = threadIdx.x; t < n * RPE_WAVE; t += CG * RPE_WAVE) {
+        const int j = t >> 6, l = t & (RPE_WAVE - 1);
+        const int q = blockIdx.x * RPE_WAVE + l;
+        if (q >= HW) continue;
+        float sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < CG; ++g) sum += red[g][j][l];
+        sum = sum / (float)C;
+        if (slope != 0.f) sum = sum >= 0.f ? sum : sum * slope;
+        out[((int64_t)b * n * n + dyi * n + j) * HW + q] = sum;
+    }
+}
+
+template <int CG>
+void launch_corr_small(const float *in1, const float *in2, int B, int C, int H, int W, int md, float slope, float *out, hipStream_t st) {
+    const int n = 2 * md + 1;
+    dim3 grid((H * W + RPE_WAVE - 1) / RPE_WAVE, n, B), block(CG * RPE_WAVE);
+    hipLaunchKernelGGL(corr_small_kernel<CG>, grid, block, 0, st, in1, in2, C, H, W, md, slope, out);
+}
 
 // ---- MFMA kernel ---------------------------------------------------------------
 constexpr int MD = 4;       // max displacement this kernel is built for
@@ -467,6 +533,7 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
         if (dma_ok && C % 2 == 0 && px >= 144 * 240) algo = 7;
         else if (dma_ok && C % 4 == 0 && px >= 72 * 120) algo = 4;
         else if (md == MD && px >= 72 * 120) algo = 2;
+        else if (md <= 4 && B <= 65535) algo = 3;
         else algo = 1;
     }
     if (algo == 2) {
@@ -478,6 +545,11 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
         int rc = algo == 4 ? launch_mfma_dma<2, 4, 4, 3, 4, true>(in1, in2, B, C, H, W, leaky_slope, out, st)
                            : launch_mfma_dma<2, 8, 2, 3, 3, true>(in1, in2, B, C, H, W, leaky_slope, out, st);
         if (rc) return rc;
+    } else if (algo == 3) {  // small maps: 64 flattened pixels x one displacement row a workgroup, the channels split over its waves
+        if (md > 4 || B > 65535) return RPE_EUNSUPPORTED;
+        if (C <= 48) launch_corr_small<4>(in1, in2, B, C, H, W, md, leaky_slope, out, st);
+        else if (C <= 128) launch_corr_small<8>(in1, in2, B, C, H, W, md, leaky_slope, out, st);
+        else launch_corr_small<16>(in1, in2, B, C, H, W, md, leaky_slope, out, st);
     } else if (algo == 1) {
         if ((int64_t)B * n * n > 65535 || H > 65535) return RPE_EUNSUPPORTED;
         dim3 grid((W + 255) / 256, H, B * n * n), block(256);

@@ -357,6 +357,84 @@ __global__ __launch_bounds__(256) void project_rows_kernel(const float *__restri
     for (; c < n_tail; ++c) ot[(int64_t)c * HW] = tp[(int64_t)c * HW];
 }
 
+// The same on the coarse maps (a few hundred to a few thousand pixels): one thread per pixel is a handful of waves, each
+// walking C2 + C3 channels as a chain of memory round trips (18 x 30: 18 us, four calls per level on the decoder's critical
+// path).  A workgroup takes 64 pixels and splits the channels over its CG waves: every wave sums its slice of the correlation
+// term and copies its slice of the projected and appended channels; the partial sums meet in LDS.
+template <int CG>
+__global__ __launch_bounds__(CG * 64) void project_rows_small_kernel(const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
+                                                                     const float *__restrict__ feat2d, int C2, int H, int W, int C3, int N,
+                                                                     const float *__restrict__ rows, const int64_t *__restrict__ nn,
+                                                                     const float *__restrict__ sub, int n_sub, const float *__restrict__ tail,
+                                                                     int n_tail, float *__restrict__ out) {
+    __shared__ float red[CG][64];
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int HW = H * W;
+    const int p = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const bool valid = p < HW;
+    const int pc = valid ? p : HW - 1;  // (lanes past the end read the last pixel and store nothing)
+    const int64_t i = nn[(int64_t)b * HW + pc];
+    const float *row = rows + ((int64_t)b * N + i) * (C2 + C3);
+    const float *f2 = feat2d + (int64_t)b * C2 * HW + pc;
+    float *o = out + (int64_t)b * (C3 + 3 + n_tail) * HW + pc;
+    constexpr int CU = 8;
+    {  // this wave's slice of the correlation term
+        const int per = (C2 + CG - 1) / CG, c0 = grp * per, c1 = min(C2, c0 + per);
+        float s = 0.f;
+        for (int c = c0; c < c1; c += CU) {
+            float r[CU], f[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int cc = min(c + u, c1 - 1);
+                r[u] = row[cc];
+                f[u] = f2[(int64_t)cc * HW];
+            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u) s += c + u < c1 ? r[u] * f[u] : 0.f;
+        }
+        red[grp][lane] = s;
+    }
+    {  // ... of the projected 3-D channels (the last n_sub of them minus `sub`)
+        const int per = (C3 + CG - 1) / CG, c0 = grp * per, c1 = min(C3, c0 + per);
+        const float *sp = n_sub > 0 ? sub + ((int64_t)b * n_sub - (C3 - n_sub)) * HW + pc : row;  // channel c of the projected ones: sp[c * HW], c >= C3 - n_sub
+        for (int c = c0; c < c1; c += CU) {
+            float r[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) {
+                const int cc = min(c + u, c1 - 1);
+                r[u] = row[C2 + cc];
+                if (cc >= C3 - n_sub) r[u] = r[u] - sp[(int64_t)cc * HW];
+            }
+#pragma unroll
+            for (int u = 0; u < CU; ++u)
+                if (valid && c + u < c1) o[(int64_t)(3 + c + u) * HW] = r[u];
+        }
+    }
+    {  // ... of the appended channels
+        const int per = (n_tail + CG - 1) / CG, c0 = grp * per, c1 = min(n_tail, c0 + per);
+        const float *tp = tail + (int64_t)b * n_tail * HW + pc;
+        float *ot = o + (int64_t)(3 + C3) * HW;
+        for (int c = c0; c < c1; c += CU) {
+            float r[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) r[u] = tp[(int64_t)min(c + u, c1 - 1) * HW];
+#pragma unroll
+            for (int u = 0; u < CU; ++u)
+                if (valid && c + u < c1) ot[(int64_t)(c + u) * HW] = r[u];
+        }
+    }
+    __syncthreads();
+    if (grp == 0 && valid) {
+        const float px = xy[(int64_t)b * xy_sb + i * xy_sn], py = xy[(int64_t)b * xy_sb + xy_sd + i * xy_sn];
+        o[0] = px - (float)(p % W);
+        o[HW] = py - (float)(p / W);
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < CG; ++g) s += red[g][lane];
+        o[2 * (int64_t)HW] = s / (float)C2;
+    }
+}
+
 int channel_split(int C, long items, int B);
 int channel_split(int C, long items, int B) {
     // enough blocks to fill 256 CUs without making each thread's channel loop trivial
@@ -536,6 +614,11 @@ RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_
     const int cpb = 8;  // channels per thread: 32-byte row segments, (C2+C3)/8 times the threads
     hipLaunchKernelGGL(point_rows_kernel, dim3((N + 255) / 256, (C2 + C3 + cpb - 1) / cpb, B), dim3(256), 0, st, xy, xy_sb, xy_sd,
                        xy_sn, feat_2d, C2, H, W, feat_3d, f3_sb, f3_sc, f3_sn, C3, N, cpb, sampled_2d, sm_sb, sm_sc, sm_sn, workspace);
+    if ((int64_t)B * H * W <= 16384) {  // the coarse levels (up to 36 x 60 at batch 4): channels split over eight waves
+        hipLaunchKernelGGL(project_rows_small_kernel<8>, dim3((H * W + 63) / 64, B), dim3(8 * 64), 0, st, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2,
+                           H, W, C3, N, workspace, nn_idx, subtract, n_subtract, append, n_append, out);
+        return rpe_launch_status();
+    }
     hipLaunchKernelGGL(project_rows_kernel, dim3((H * W + 255) / 256, B), dim3(256), 0, st, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2,
                        H, W, C3, N, workspace, nn_idx, subtract, n_subtract, append, n_append, out);
     return rpe_launch_status();

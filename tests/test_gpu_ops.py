@@ -289,6 +289,8 @@ DMA_ALGOS = (4, 7)  # LDS-DMA ring variants of the MFMA kernel (4 / 8 waves): ne
 
 def corr_algos(C, Wd, md):
     algos = [1]
+    if md <= 4:
+        algos.append(3)  # the small-map kernel (any shape, md <= 4)
     if md == 4:
         algos.append(2)
         if Wd % 4 == 0:
