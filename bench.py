@@ -143,9 +143,12 @@ def pmc_traffic(suffix):
     return None, None
 
 
-def clocked(frac, sclk):
-    """Extra fields of a roofline object: the clock the loop ran at and the fraction scaled to the nominal clock."""
-    return {"sclk_MHz": sclk, "frac_at_nominal_clock": round(frac * NOMINAL_SCLK_MHZ / sclk, 4) if sclk else None}
+def clocked(frac, clock):
+    """Extra fields of a roofline object: the shader clock read while the loop ran (mean, range and count of the readings: under
+    the power cap the firmware moves between levels and a reading is one instant) and the fraction scaled to the nominal clock."""
+    sclk = clock.mean()
+    return {"sclk_MHz": sclk, "sclk_MHz_range": [min(clock.samples), max(clock.samples)] if clock.samples else None,
+            "sclk_readings": len(clock.samples), "frac_at_nominal_clock": round(frac * NOMINAL_SCLK_MHZ / sclk, 4) if sclk else None}
 
 
 def corr_microbench(dev, iters=40):
@@ -165,7 +168,7 @@ def corr_microbench(dev, iters=40):
     us = s.elapsed_time(e) / iters * 1e3
     with ClockSampler() as clock:  # the same loop again, long enough for a clock reading (untimed)
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < (0.25 if clock.path else 1.5):
+        while time.perf_counter() - t0 < (0.25 if clock.path else 2.5):
             for _ in range(20):
                 ops.correlation2d(a, b, 4)
             torch.cuda.synchronize()
@@ -175,7 +178,7 @@ def corr_microbench(dev, iters=40):
     frac = gbs / HBM_PEAK_GBS
     return {"kernel": "corr_mfma_dma_kernel<2,8,2,3,3,true>", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(frac, 4), "traffic": traffic, "traffic_source": source, "us_per_launch": round(us, 1),
-            **clocked(frac, clock.mean()), "frac_of_measured_copy_bw": round(gbs / HBM_COPY_GBS, 4),
+            **clocked(frac, clock), "frac_of_measured_copy_bw": round(gbs / HBM_COPY_GBS, 4),
             "algorithmic_bytes": alg, "workload": "correlation2d 1x256x544x960 md=4 fp32 NCHW (BASELINE config 2)"}
 
 
@@ -199,7 +202,7 @@ def knn_microbench(dev, iters=30):
     us = s.elapsed_time(e) / iters * 1e3
     with ClockSampler() as clock:
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < (0.25 if clock.path else 1.5):
+        while time.perf_counter() - t0 < (0.25 if clock.path else 2.5):
             for _ in range(20):
                 ops.k_nearest_neighbor(cloud, query, k)
             torch.cuda.synchronize()
@@ -214,11 +217,14 @@ def knn_microbench(dev, iters=30):
     us_index = s.elapsed_time(e) / iters * 1e3
     pairs = B * M * Q
     tflops = pairs * (2 * D + 3) / us / 1e6
-    traffic, source = pmc_traffic("knn16_pmc.json")
+    traffic, source = pmc_traffic("knn16_pmc.json")  # the sweep kernel ...
+    replay_traffic, replay_source = pmc_traffic("knn16_replay_pmc.json")  # ... and the tied rows' second launch
+    if traffic is not None and replay_traffic is not None and replay_source[:12] == source[:12]:  # (same round's passes)
+        traffic, source = traffic + replay_traffic, source + " + " + replay_source
     frac = tflops / MFMA_F32_PEAK_TFLOPS
     return {"kernel": "knn_mfma_kernel<3, true> + knn_tie_replay_kernel<3> (the sweep, then its tied rows redone the libstdc++ way by a second launch)",
             "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(frac, 4),
-            "traffic": traffic, "traffic_source": source, **clocked(frac, clock.mean()),
+            "traffic": traffic, "traffic_source": source, **clocked(frac, clock),
             "us_per_launch": round(us, 1), "launches": 2, "pairs_per_s": round(pairs / us * 1e6), "algorithmic_bytes": 4 * B * D * (M + Q) + 8 * B * Q * k,
             "us_per_launch_lowest_index_ties": round(us_index, 1),  # the same search without the libstdc++ restatement of equal distances
             "frac_lowest_index_ties": round(pairs * (2 * D + 3) / us_index / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),

@@ -1,5 +1,5 @@
 """Single hot-path operators at the forward's level-1 shapes, for rocprofv3 --pmc / --kernel-trace runs.
-Usage: python3 tools/prof_ops.py <pointconv|knn16|knn3|corr3d> [iters]"""
+Usage: python3 tools/prof_ops.py <pointconv|knn16|knn3|knn2d|corr3d> [iters]"""
 import os
 import sys
 
@@ -30,6 +30,13 @@ with torch.no_grad():
             p = torch.rand(4, 3, 4096, device=dev) * 30
             q = torch.rand(4, 3, 4096, device=dev) * 30
         step = lambda: k_nearest_neighbor(p, q, k)
+    elif which == "knn2d":  # the nearest projected point of every pixel at level 1, both frames of a batch of 4 (RPEFlow_core.py:327-330)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from tests import inputs as I
+        r = I.rng(0)
+        p = torch.from_numpy(I.pixel_cloud(r, 8, 4096, 144, 240)).to(dev).transpose(1, 2).contiguous()
+        q = torch.from_numpy(I.pixel_grid(8, 144, 240)).to(dev).transpose(1, 2).contiguous()
+        step = lambda: k_nearest_neighbor(p, q, 1)
     elif which == "corr3d":  # Correlation3D at level 1: B=4, N=4096, C=32
         from rpeflow_amd.pwc3d_core import Correlation3D
         m = Correlation3D(32, 32).to(dev).eval()
