@@ -1357,11 +1357,17 @@ __global__ __launch_bounds__(kReplayThreads) void knn_tie_replay_kernel(KnnJobs 
         }
         __syncthreads();
         if (wave == 0) {
-            float Ld;
-            int Li;
+            float Ld = 0.f;
+            int Li = 0;
+#if defined(RPE_REPLAY_PROBE)  // timing probe, never in the library: everything but the heap replay (7 of the kernel's 45 us)
+            Ld = ld[lane];
+#else
+            // (the heap in SCALAR registers -- a decision tree of s_cmp / s_mov over compile-time positions -- was tried here, where
+            // the wave holds nothing else: 522 SGPR spills at the tree's joins, 80 us against 45)
             if (k == 16) heap_replay_lds<16>(ld, M, lane, Ld, Li);
             else if (k == 3) heap_replay_lds<3>(ld, M, lane, Ld, Li);
             else heap_replay_lds_any(ld, M, k, lane, Ld, Li);
+#endif
             if (lane < k) {
                 const int64_t o = ((int64_t)b * Q + qi) * k + lane;
                 J.idx[o] = (int64_t)Li;
