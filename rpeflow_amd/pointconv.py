@@ -9,6 +9,13 @@ gather, weight net, the 16 x (C+3) weighted sums, nn.Linear, bias, eval-mode
 BatchNorm and the activation (csrc/pointconv_fused.hip).  None of the
 reference's intermediates (pointconv.py:49-57; [B,Q,16,C+3] and [B,Q,16(C+3)]
 are 208 MB each at pyramid level 1) is ever written to memory.
+
+The fused kernel is built for what every shipped configuration uses (k = 16,
+leaky_relu, no norm or eval-mode BatchNorm, inference).  Everything else the
+reference's constructor accepts -- any k, ``instance_norm``, ``relu`` / no
+activation, BatchNorm in training mode, inputs that require grad -- takes the
+reference's own op sequence (pointconv.py:43-58) on the GPU: the HIP neighbour
+search and gathers, library GEMMs, the norm / activation modules themselves.
 """
 import ctypes
 
@@ -17,7 +24,7 @@ import torch.nn as nn
 
 from . import _lib
 from .csrc import k_nearest_neighbor
-from .utils import MLP2d, _act, _norm, affine_epilogue
+from .utils import MLP2d, _act, _inference_only, _norm, affine_epilogue, batch_indexing_channel_first, batch_indexing_channel_last
 
 _ACT = {None: 0, "relu": 1, "leaky_relu": 2}
 
@@ -69,16 +76,27 @@ def pack_linear(weight, C):
     return w, n_tiles
 
 
+def gather_channel_first(data, idx):
+    """batch_indexing_channel_first (utils.py:119-137): the HIP gather, or torch.gather where a gradient has to flow."""
+    if torch.is_grad_enabled() and data.requires_grad:
+        B, C = data.shape[:2]
+        return torch.gather(data, 2, idx.reshape(B, 1, -1).expand(-1, C, -1)).view([B, C] + list(idx.shape[1:]))
+    return batch_indexing_channel_first(data, idx)
+
+
+def gather_channel_last(data, idx):
+    """batch_indexing_channel_last (utils.py:101-116), likewise."""
+    if torch.is_grad_enabled() and data.requires_grad:
+        B, _, C = data.shape
+        return torch.gather(data, 1, idx.reshape(B, -1, 1).expand(-1, -1, C)).view([B] + list(idx.shape[1:]) + [C])
+    return batch_indexing_channel_last(data, idx)
+
+
 class _PointConv(nn.Module):
     def __init__(self, in_channels, out_channels, norm=None, activation="leaky_relu", k=16):
         super().__init__()
-        if k != 16:
-            raise NotImplementedError("rpeflow_amd PointConv is built for k=16 (conf/*/*.yaml pwc3d.k)")
-        if activation != "leaky_relu":
-            raise NotImplementedError("rpeflow_amd PointConv fuses the weight net's leaky_relu(0.1)")
-        if norm not in (None, "batch_norm"):
-            raise NotImplementedError("rpeflow_amd PointConv fuses eval-mode BatchNorm only (conf/*/*.yaml norms)")
         self.k = k
+        self.fusable = k == 16 and activation == "leaky_relu" and norm in (None, "batch_norm")  # what pointconv_fused.hip is built for
         self.in_channels, self.out_channels = in_channels, out_channels
         self.weight_net = MLP2d(3, [8, 16], activation=activation)  # pointconv.py:12
         self.linear = nn.Linear(16 * (in_channels + 3), out_channels)  # pointconv.py:13
@@ -99,14 +117,35 @@ class _PointConv(nn.Module):
                 lp=lp, n_tiles=n_tiles))
         return self._packed[1]
 
-    def _run(self, packed, query_xyz, knn_indices, out_rows):
+    def _general(self, xyz, features, query_xyz, knn_indices, out_rows):
+        """pointconv.py:43-58 op for op (any k / norm / activation, training-mode norms, autograd)."""
+        if isinstance(features, PackedRows):
+            features = features.rows[:, :, 3:3 + features.channels].transpose(1, 2)
+        elif isinstance(features, (list, tuple)):
+            features = torch.cat(list(features), dim=1)
+        batch_size, n_samples = xyz.shape[0], query_xyz.shape[2]
+        feats_cl = torch.cat([xyz, features], dim=1).transpose(1, 2)            # [B, M, C + 3]
+        knn_indices = knn_indices[:, :, :self.k]
+        knn_xyz_norm = gather_channel_first(xyz, knn_indices) - query_xyz[:, :, :, None]   # [B, 3, Q, k]
+        weights = self.weight_net(knn_xyz_norm).transpose(1, 2)                # [B, Q, 16, k]
+        knn_features = gather_channel_last(feats_cl, knn_indices)              # [B, Q, k, C + 3]
+        weighted = torch.matmul(weights, knn_features).reshape(batch_size, n_samples, -1)
+        out = self.activation_fn(self.norm_fn(self.linear(weighted).float().transpose(1, 2)))
+        return pack_rows(query_xyz, out) if out_rows else out
+
+    def _forward(self, xyz, features, query_xyz, knn_indices, out_rows):
+        epi = affine_epilogue(self, self.linear.bias, self.norm_fn, self.activation_fn) if self.fusable else None
+        raw = [features.rows] if isinstance(features, PackedRows) else list(features) if isinstance(features, (list, tuple)) else [features]
+        if epi is None or not _inference_only(xyz, query_xyz, *raw, *self.parameters()):
+            return self._general(xyz, features, query_xyz, knn_indices, out_rows)
+        packed = features if isinstance(features, PackedRows) else pack_rows(xyz, features)
+        return self._run(packed, query_xyz, knn_indices, out_rows, epi)
+
+    def _run(self, packed, query_xyz, knn_indices, out_rows, epi):
         rows = packed.rows
         _lib.require_gpu(rows, query_xyz, knn_indices, op="PointConv")
         if packed.channels != self.in_channels:
             raise RuntimeError("PointConv: %d feature channels given, layer built for %d" % (packed.channels, self.in_channels))
-        epi = affine_epilogue(self, self.linear.bias, self.norm_fn, self.activation_fn)
-        if epi is None:
-            raise NotImplementedError("rpeflow_amd PointConv is inference-only: BatchNorm must be in eval mode")
         scale, shift, kind = epi
         w = self._weights()
         B, M, CFp = rows.shape
@@ -140,8 +179,7 @@ class PointConvDownSampling(_PointConv):
         pointconv.py:46).  ``out_rows``: return PackedRows over the SAMPLED points instead of [B,Cout,Q]."""
         if knn_indices is None:
             knn_indices = k_nearest_neighbor(xyz, sampled_xyz, self.k)  # [B,Q,k]
-        packed = features if isinstance(features, PackedRows) else pack_rows(xyz, features)
-        return self._run(packed, sampled_xyz, knn_indices, out_rows)
+        return self._forward(xyz, features, sampled_xyz, knn_indices, out_rows)
 
 
 class PointConvNoSampling(_PointConv):
@@ -154,5 +192,4 @@ class PointConvNoSampling(_PointConv):
             assert knn_indices.shape[2] >= self.k
         else:
             knn_indices = k_nearest_neighbor(xyz, xyz, self.k)
-        packed = features if isinstance(features, PackedRows) else pack_rows(xyz, features)
-        return self._run(packed, xyz, knn_indices, out_rows)
+        return self._forward(xyz, features, xyz, knn_indices, out_rows)

@@ -60,11 +60,11 @@ class FeaturePyramid3D(nn.Module):
 
 
 def _pad_channels(c):
-    """Channel counts the Correlation3D kernels are instantiated for (16 * T, T in 1, 2, 4, 6, 8, 12)."""
+    """Channel counts the Correlation3D kernels are instantiated for (16 * T, T in 1, 2, 4, 6, 8, 12); None: wider than that."""
     for cp in (16, 32, 64, 96, 128, 192):
         if c <= cp:
             return cp
-    raise NotImplementedError("rpeflow_amd Correlation3D: out_channels <= 192 (got %d)" % c)
+    return None
 
 
 class Correlation3D(nn.Module):
@@ -77,13 +77,14 @@ class Correlation3D(nn.Module):
     pair, and the [B, 2C+3, N, k] tensor is never built.  Behind the neighbour search the
     rest is two kernels (csrc/corr3d_fused.hip): gather + rel block + second layer on MFMA +
     weight_net2 + k-sum, then the second hop.  Results differ from the reference by fp32
-    re-association only."""
+    re-association only.  The kernels are built for k = 16 and up to 192 output channels (every shipped
+    configuration); any other k or width, and inputs that require grad, take the reference's own op
+    sequence on the GPU (HIP neighbour search and gathers, library convolutions)."""
 
     def __init__(self, in_channels, out_channels, k=16):
         super().__init__()
-        if k != 16:
-            raise NotImplementedError("rpeflow_amd Correlation3D is built for k=16 (conf/*/*.yaml pwc3d.k)")
         self.k = k
+        self.fusable = k == 16 and _pad_channels(out_channels) is not None
         self.cost_mlp = MLP2d(3 + 2 * in_channels, [out_channels, out_channels], activation="leaky_relu")
         self.weight_net1 = MLP2d(3, [8, 8, out_channels], activation="relu")
         self.weight_net2 = MLP2d(3, [8, 8, out_channels], activation="relu")
@@ -127,7 +128,10 @@ class Correlation3D(nn.Module):
         return self._cache[1]
 
     def project_stacked(self, feat_both):
-        """project() for the two clouds' features stacked on the batch axis ([2B,C,N], cloud 1 first): ONE batched GEMM."""
+        """project() for the two clouds' features stacked on the batch axis ([2B,C,N], cloud 1 first): ONE batched GEMM.
+        None where the fused kernels do not apply (forward() then runs the reference's op sequence and needs no projection)."""
+        if not self.fusable:
+            return None
         w = self._weights()
         batch_size = feat_both.shape[0] // 2
         wt = w["w_ab_t"].repeat_interleave(batch_size, dim=0)
@@ -138,6 +142,8 @@ class Correlation3D(nn.Module):
     def project(self, feat1, feat2):
         """(p1_rows [B,N,Cp], p2_rows [B,M,Cp]): the feat1 / feat2 blocks of cost_mlp's first layer per point, channel-last.
         Depends on the features only; callers that know them early pass the result to forward(projected=...)."""
+        if not self.fusable:
+            return None
         if feat1.shape[2] == feat2.shape[2]:
             return self.project_stacked(torch.cat([feat1, feat2], dim=0))
         w = self._weights()
@@ -146,10 +152,27 @@ class Correlation3D(nn.Module):
         p2 = torch.matmul(feat2.float().transpose(1, 2), w["w_ab_t"][1])
         return p1, p2
 
+    def _general(self, xyz1, feat1, xyz2, feat2, knn_indices_1in1):
+        """pwc3d_core.py:81-117 op for op."""
+        from .pointconv import gather_channel_first as gather
+        batch_size, in_channels, n_points = feat1.shape
+        knn_1in2 = k_nearest_neighbor(input_xyz=xyz2, query_xyz=xyz1, k=self.k)
+        rel2 = gather(xyz2, knn_1in2) - xyz1.view(batch_size, 3, n_points, 1)
+        cat = torch.cat([feat1[:, :, :, None].expand(batch_size, in_channels, n_points, self.k), gather(feat2, knn_1in2), rel2], dim=1)
+        p2n_cost = torch.sum(self.weight_net2(rel2) * self.cost_mlp(cat), dim=3)
+        if knn_indices_1in1 is not None:
+            assert knn_indices_1in1.shape == torch.Size([batch_size, n_points, self.k])
+        else:
+            knn_indices_1in1 = k_nearest_neighbor(input_xyz=xyz1, query_xyz=xyz1, k=self.k)
+        rel1 = gather(xyz1, knn_indices_1in1) - xyz1.view(batch_size, 3, n_points, 1)
+        return torch.sum(self.weight_net1(rel1) * gather(p2n_cost, knn_indices_1in1), dim=3)
+
     def forward(self, xyz1, feat1, xyz2, feat2, knn_indices_1in1=None, projected=None):
         from . import _lib
-        from .utils import _ptr
+        from .utils import _inference_only, _ptr
         _lib.require_gpu(xyz1, feat1, xyz2, feat2, op="Correlation3D")
+        if not self.fusable or not _inference_only(xyz1, feat1, xyz2, feat2, *self.parameters()):
+            return self._general(xyz1, feat1, xyz2, feat2, knn_indices_1in1)
         batch_size, _, n_points = feat1.shape
         m_points = xyz2.shape[2]
         w = self._weights()

@@ -130,6 +130,19 @@ BLOCK_CASES = {
 }
 
 
+# the same modules OUTSIDE the configuration the fused kernels are built for (any k, instance_norm, relu / no activation,
+# training-mode BatchNorm, wide Correlation3D): rpeflow_amd runs the reference's op sequence on the GPU there
+GENERAL_CASES = {
+    "pointconv_down_k9_instnorm_relu": dict(kind="down", B=2, M=300, Q=120, C=13, Cout=20, k=9, norm="instance_norm", activation="relu", train=False, seed=611),
+    "pointconv_nosample_k20_none": dict(kind="nosample", B=2, M=150, Q=150, C=29, Cout=17, k=20, norm=None, activation=None, train=False, seed=612),
+    "pointconv_nosample_k16_bn_train": dict(kind="nosample", B=3, M=200, Q=200, C=10, Cout=12, k=16, norm="batch_norm", activation="leaky_relu", train=True, seed=613),
+    "correlation3d_k5": dict(kind="corr", B=2, N=140, C=12, Cout=12, k=5, seed=614),
+    "correlation3d_wide200": dict(kind="corr", B=1, N=90, C=6, Cout=200, k=16, seed=615),
+}
+for _name, _c in GENERAL_CASES.items():
+    BLOCK_CASES[_name] = dict(_c, **({"N": _c["M"]} if "M" in _c else {}))
+
+
 def block_inputs(name):
     c = BLOCK_CASES[name]
     r = I.rng(c["seed"])
@@ -137,7 +150,7 @@ def block_inputs(name):
     if name.startswith("pointconv"):
         xyz = cl(I.ids_cloud(r, c["B"], c["M"]))
         feat = r.standard_normal((c["B"], c["C"], c["M"]), dtype=np.float32)
-        sampled = xyz[:, :, : c["Q"]].copy() if name == "pointconv_down" else None
+        sampled = xyz[:, :, : c["Q"]].copy() if name.startswith("pointconv_down") else None
         return dict(xyz=xyz, feat=feat, sampled=sampled)
     if name == "flow_estimator3d":
         return dict(xyz=cl(I.ids_cloud(r, c["B"], c["N"])), feat=r.standard_normal((c["B"], c["channels"][0], c["N"]), dtype=np.float32))

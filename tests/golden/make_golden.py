@@ -157,6 +157,36 @@ def gen_blocks():
          **{"index1_%d" % i: v.numpy() for i, v in enumerate(idx1)}, **{"index2_%d" % i: v.numpy() for i, v in enumerate(idx2)})
 
 
+def gen_blocks_general():
+    """The PointConv / Correlation3D modules outside the fused kernels' configuration (tests/cases.py GENERAL_CASES)."""
+    out = {}
+    for name, c in K.GENERAL_CASES.items():
+        x = K.block_inputs(name)
+        if c["kind"] == "corr":
+            m = ref_3d.Correlation3D(c["C"], c["Cout"], k=c["k"])
+            load_params(m, c["seed"] + 1000)
+            with torch.no_grad():
+                out[name] = m(T(x["xyz1"]), T(x["feat1"]), T(x["xyz2"]), T(x["feat2"])).numpy()
+            continue
+        cls = ref_pc.PointConvDownSampling if c["kind"] == "down" else ref_pc.PointConvNoSampling
+        m = cls(c["C"], c["Cout"], norm=c["norm"], activation=c["activation"], k=c["k"])
+        load_params(m, c["seed"] + 1000)
+        m.train(c["train"])
+        args = (T(x["xyz"]), T(x["feat"]), T(x["sampled"])) if c["kind"] == "down" else (T(x["xyz"]), T(x["feat"]))
+        if c["train"]:  # training-mode BatchNorm + the gradients of sum(out^2) w.r.t. the features and the linear weight
+            feat = args[1].clone().requires_grad_(True)
+            y = m(args[0], feat, *args[2:])
+            (y * y).sum().backward()
+            out[name] = y.detach().numpy()
+            out[name + "__grad_feat"] = feat.grad.numpy()
+            out[name + "__grad_linear"] = m.linear.weight.grad.numpy()
+            out[name + "__running_mean"] = m.norm_fn.running_mean.numpy().copy()
+        else:
+            with torch.no_grad():
+                out[name] = m(*args).numpy()
+    save("general_modules", **out)
+
+
 def reference_model():
     """The reference RPEFlow on CPU: things.yaml model section, MI noise drawn on the CPU (the reference
     hard-codes torch.cuda.FloatTensor in mutual_info.py:32,84,155,211; its output never reaches the flows)."""
@@ -416,6 +446,6 @@ def gen_eval():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval", "fblocks", "model_bench", "model_bench_dsec", "model_stress"]
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval", "fblocks", "model_bench", "model_bench_dsec", "model_stress", "blocks_general"]
     for w in which:
         globals()["gen_" + w]()

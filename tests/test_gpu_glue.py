@@ -131,6 +131,52 @@ def test_pointconv_channel_counts(C, M, Q):
     close_sum(out, O.pointconv(p, xyz, feat, sampled_xyz=sampled, k=16))
 
 
+@pytest.mark.parametrize("name", list(K.GENERAL_CASES))
+def test_pointconv_and_correlation3d_outside_the_fused_configuration(golden_dir, name):
+    """Everything the reference's constructors accept (pointconv.py:8-31, pwc3d_core.py:61-67) that the fused kernels are not
+    built for -- k = 5 / 9 / 20, instance_norm, relu / no activation, training-mode BatchNorm (with gradients), a 200-channel
+    Correlation3D -- runs the reference's op sequence on the GPU (HIP neighbour search and gathers): against the reference's
+    own outputs (tests/golden/general_modules.npz, made by importing it)."""
+    c, x = K.GENERAL_CASES[name], K.block_inputs(name)
+    g = G(golden_dir, "general_modules")
+    if c["kind"] == "corr":
+        m = P3.Correlation3D(c["C"], c["Cout"], k=c["k"])
+        assert not m.fusable
+        shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        m, _ = _load(m, shapes, c["seed"] + 1000)
+        with torch.no_grad():
+            out = m(dev(x["xyz1"]), dev(x["feat1"]), dev(x["xyz2"]), dev(x["feat2"]))
+        close_sum(out, g[name], what=name)
+        return
+    cls = PC.PointConvDownSampling if c["kind"] == "down" else PC.PointConvNoSampling
+    m = cls(c["C"], c["Cout"], norm=c["norm"], activation=c["activation"], k=c["k"])
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    m, _ = _load(m, shapes, c["seed"] + 1000)
+    m.train(c["train"])
+    args = [dev(x["xyz"]), dev(x["feat"])] + ([dev(x["sampled"])] if c["kind"] == "down" else [])
+    if not c["train"]:
+        assert not m.fusable
+        with torch.no_grad():
+            close_sum(m(*args), g[name], what=name)
+            rows = m(*args, out_rows=True)  # (the next layer's gather rows, as FlowEstimator3D asks for them)
+            close_sum(rows.rows[:, :, 3:3 + c["Cout"]].transpose(1, 2), g[name], what=name + " rows")
+        return
+    # training mode: batch statistics, running-stat update, gradients through the gathers (torch.gather there) and the GEMMs
+    args[1].requires_grad_(True)
+    y = m(*args)
+    (y * y).sum().backward()
+    close_sum(y.detach(), g[name], what=name)
+    for got, want, what in ((args[1].grad, g[name + "__grad_feat"], "d/d features"), (m.linear.weight.grad, g[name + "__grad_linear"], "d/d linear.weight")):
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-3, atol=2e-5 * float(np.abs(want).max()), err_msg=name + " " + what)
+    close_sum(m.norm_fn.running_mean, g[name + "__running_mean"], what=name + " running mean")
+    m.eval()  # ... and back under no_grad with the norm in eval mode the fused kernel runs again
+    with torch.no_grad():
+        fused = m(*args)
+        from rpeflow_amd.csrc import k_nearest_neighbor
+        general = m._general(args[0], args[1].detach(), args[0], k_nearest_neighbor(args[0], args[0], c["k"]), False)
+    close_sum(fused, general.cpu().numpy(), what=name + " fused vs general in eval mode")
+
+
 @torch.no_grad()
 def test_correlation3d_module(golden_dir):
     c, x = K.BLOCK_CASES["correlation3d"], K.block_inputs("correlation3d")
