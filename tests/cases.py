@@ -188,6 +188,10 @@ FBLOCK_CASES = {
     "cross_block2d": dict(B=2, C=24, heads=2, H=20, W=28, seed=701),
     "cross_block2d_3heads": dict(B=1, C=48, heads=3, H=18, W=30, seed=702),
     "cross_block3d": dict(B=2, C=32, heads=4, N=300, seed=703),
+    # the level-1 instantiations of the forward (144 x 240 maps, 4096 points): stored on a stride-8 grid / every 8th point
+    "cross_block2d_level1_c96": dict(B=1, C=96, heads=2, H=144, W=240, seed=708, stride=8),
+    "cross_block2d_level1_c81": dict(B=1, C=81, heads=1, H=144, W=240, seed=709, stride=8),
+    "cross_block3d_level1_c32": dict(B=2, C=32, heads=1, N=4096, seed=710, stride=8),
     "convex_upsample4": dict(B=2, H=9, W=15, scale=4, seed=704),
     "convex_upsample8": dict(B=1, H=6, W=10, scale=8, seed=705),
     "resize_flow2d": dict(B=2, H=64, W=128, th=60, tw=120, seed=706),
@@ -200,7 +204,7 @@ def fblock_inputs(name):
     r = I.rng(c["seed"])
     if name.startswith("cross_block2d"):
         return dict(x=I.feature_map(r, c["B"], c["C"], c["H"], c["W"]), y=I.feature_map(r, c["B"], c["C"], c["H"], c["W"]))
-    if name == "cross_block3d":
+    if name.startswith("cross_block3d"):
         return dict(x=r.standard_normal((c["B"], c["C"], c["N"]), dtype=np.float32), y=r.standard_normal((c["B"], c["C"], c["N"]), dtype=np.float32))
     if name.startswith("convex_upsample"):
         s = c["scale"]

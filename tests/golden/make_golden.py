@@ -300,7 +300,9 @@ def gen_fblocks():
             cls = ref_ra.CrossTransformerBlock2D if "2d" in name else ref_ra.CrossTransformerBlock3D
             m = cls(dim=c["C"], num_heads=c["heads"])
             load_params(m, c["seed"] + 1000)
-            save(name, out=m(T(x["x"]), T(x["y"])).numpy())
+            out = m(T(x["x"]), T(x["y"])).numpy()
+            st = c.get("stride", 1)
+            save(name, out=np.ascontiguousarray(out[:, :, ::st, ::st] if out.ndim == 4 else out[:, :, ::st]))
         elif name.startswith("convex_upsample"):
             save(name, out=ref_utils.convex_upsample(T(x["flow"]), T(x["mask"]), scale_factor=c["scale"]).numpy())
         else:
