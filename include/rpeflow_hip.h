@@ -339,6 +339,16 @@ int rpe_dwconv3(const float *in0, int C0, const float *in1, int C1, const float 
 int rpe_channel_layernorm(const float *x0, const float *weight0, const float *bias0, float *out0,
                           const float *x1, const float *weight1, const float *bias1, float *out1,
                           int B, int C, int64_t P, float eps, rpe_stream_t stream);
+/* rpe_gdfn_tail: the gated feed-forward behind project_in in ONE launch (restormer_arch.py:104-106, 244-246): depth-wise 3x3
+ *   (kh = 3; t [B, 2*hidden, H, W]) or 3-tap (kh = 1, H = 1; t [B, 2*hidden, W]) convolution with dw_weight [2*hidden, kh*3] and
+ *   dw_bias [2*hidden] or NULL, g = gelu(first half) * second half, then project_out: y[b][o][p] = sum_c Wout[o][c] g[b][c][p] +
+ *   shift[o] (+ residual[b][o][p]; y may BE residual).  packed_weight: Wout [Cout, hidden] in rpe_pointwise_conv's fragment order.
+ *   The arithmetic of rpe_dwconv3(gate = 1) followed by rpe_pointwise_conv, without the gated tensor's round trip through HBM.
+ *   Needs W % 4 == 0, Cout <= 128, 16-byte aligned t / y / residual: else RPE_EUNSUPPORTED (callers keep the two launches).
+ *   Faster than the two launches for the 3-tap form (the point-cloud blocks: 20-27 against 32 us); for 3x3 maps the gate is three
+ *   times the work and the two launches win (level 1, C = 96: 237 against 296 us): rpeflow_amd uses it for kh = 1 only.       */
+int rpe_gdfn_tail(const float *t, int B, int hidden, int H, int W, int kh, const float *dw_weight, const float *dw_bias,
+                  const float *packed_weight, int Cout, const float *shift, const float *residual, float *y, rpe_stream_t stream);
 /* rpe_channel_attention_matrix: the attention core of Mutual_Attention{2D,3D}.forward (restormer_arch.py:184-203,
  *   265-282) up to and including project_out, as a per-batch C x C matrix (C = heads * c):
  *     attn_h = softmax_j( normalize(q_h) normalize(k_h)^T * temperature[h] ),  F.normalize over the P positions (eps),

@@ -36,6 +36,7 @@ _PROTOTYPES = {
     "rpe_channel_attention_matrix": [_c_ptr, _c_ptr, _c_i64, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_i64, _c_float,
                                      _c_ptr, _c_ptr, _c_int, _c_ptr],
     "rpe_channel_attention_workspace_floats": [_c_int, _c_int, _c_int, _c_i64],
+    "rpe_gdfn_tail": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     "rpe_convex_upsample": [_c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_events_to_voxel": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int, _c_int, _c_i64,
                             _c_ptr, _c_ptr],

@@ -134,6 +134,100 @@ __global__ __launch_bounds__(256) void dwconv3_strip_kernel(Segments seg, const 
         if (y0 + o < H) *reinterpret_cast<float4 *>(op + (int64_t)o * W) = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
 }
 
+// ---- the tail of the gated feed-forward in ONE launch: depth-wise 3x3 (or 3-tap) + bias + gelu gate + project_out (1x1) + bias
+// + residual (restormer_arch.py:104-106 / 244-246; FeedForward.forward after project_in).  The gated tensor g [B, hidden, P] is
+// the B operand of project_out's matrix product; here it goes from the lanes that compute it to the lanes that multiply it
+// through LDS instead of HBM (2 x 119 MB of 850 MB per level-1 block, and a launch).  A workgroup owns 64 positions; a round is
+// 16 hidden channels: wave w computes the gate of channel group 4 r + w in the 1x1 kernel's operand layout (lane (k, j): channel
+// 4 kt + k, positions p0 .. p0 + 3 of one map row; dw_strip and gelu_erf exactly as dwconv3_strip_kernel<KH, true> runs them)
+// and leaves it in LDS for everybody; then every wave multiplies the round's four groups into ITS output tiles (w and w + 4: up
+// to 128 output channels) in the channel order of pointwise_conv_kernel.  The gate of round r + 1 is computed before the
+// products of round r are issued (double-buffered: one barrier a round).  (A first form -- one wave per 64 positions computing
+// every gate itself and holding all output tiles -- was 282 us against the two launches' 236: 204 VGPRs, two waves a SIMD, a
+// 64-round serial loop.)
+typedef float gd_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KH>
+__global__ __launch_bounds__(256) void gdfn_tail_kernel(const float *__restrict__ t, int hidden, int H, int W, const float *__restrict__ dw_w,
+                                                        const float *__restrict__ dw_b, const float *__restrict__ wpk, int ktiles,
+                                                        int n_otiles, int Cout, const float *__restrict__ shift, const float *res, float *y) {
+    __shared__ float4 gbuf[2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = lane >> 4, j = lane & 15;
+    const int b = blockIdx.y;
+    const int64_t P = (int64_t)H * W;
+    const int64_t p0 = (int64_t)blockIdx.x * 64 + 4 * j;
+    const bool p_in = p0 < P;  // (W % 4 == 0: the four positions share a row and are in range together)
+    const int py = p_in ? (int)(p0 / W) : 0, px = p_in ? (int)(p0 - (int64_t)py * W) : 0;
+    const float *tb = t + (int64_t)b * 2 * hidden * P;
+    gd_f32x4 acc[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[o][q] = gd_f32x4{0.f, 0.f, 0.f, 0.f};
+    auto gate = [&](int kt) {  // this wave's channel group of a round
+        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = 4 * kt + k;
+        if (kt < ktiles && c < hidden && p_in) {
+            float a[1][4], g[1][4];
+            dw_strip<KH, 1>(tb + (int64_t)c * P, dw_w + (int64_t)c * KH * 3, py, px, H, W, a);
+            dw_strip<KH, 1>(tb + (int64_t)(hidden + c) * P, dw_w + (int64_t)(hidden + c) * KH * 3, py, px, H, W, g);
+            const float b0 = dw_b ? dw_b[c] : 0.f, b1 = dw_b ? dw_b[hidden + c] : 0.f;
+            gv.x = gelu_erf(a[0][0] + b0) * (g[0][0] + b1), gv.y = gelu_erf(a[0][1] + b0) * (g[0][1] + b1);
+            gv.z = gelu_erf(a[0][2] + b0) * (g[0][2] + b1), gv.w = gelu_erf(a[0][3] + b0) * (g[0][3] + b1);
+        }
+        return gv;
+    };
+    const int rounds = (ktiles + 3) / 4;
+    const int o0 = wave, o1 = wave + 4;
+    gbuf[0][wave][lane] = gate(wave);
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        float av[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kt = 4 * r + u;
+            av[u][0] = (kt < ktiles && o0 < n_otiles) ? wpk[((int64_t)o0 * ktiles + kt) * 64 + lane] : 0.f;
+            av[u][1] = (kt < ktiles && o1 < n_otiles) ? wpk[((int64_t)o1 * ktiles + kt) * 64 + lane] : 0.f;
+        }
+        const float4 nxt = r + 1 < rounds ? gate(4 * (r + 1) + wave) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 g = gbuf[r & 1][u][lane];
+            const float gq[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], gq[q], acc[0][q], 0, 0, 0);
+                acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], gq[q], acc[1][q], 0, 0, 0);
+            }
+        }
+        gbuf[(r + 1) & 1][wave][lane] = nxt;
+        __syncthreads();
+    }
+    if (!p_in) return;
+    // D layout: lane (g = lane >> 4, j), register r: output 16 o + 4 g + r, position p0 + q of tile q
+#pragma unroll
+    for (int oo = 0; oo < 2; ++oo) {
+        const int o = oo == 0 ? o0 : o1;
+        if (o >= n_otiles) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oc = 16 * o + 4 * k + r;
+            if (oc >= Cout) continue;
+            const float sh = shift ? shift[oc] : 0.0f;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = acc[oo][q][r] + sh;
+            const int64_t off = ((int64_t)b * Cout + oc) * P + p0;
+            if (res) {
+                const float4 rr = *reinterpret_cast<const float4 *>(res + off);
+                v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
+            }
+            *reinterpret_cast<float4 *>(y + off) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // 64 positions x 4 channel groups per workgroup: thread (pl, cg) keeps channels cg, cg+4, ... of its position in
 // registers (x is read once), the two reductions over the four groups (mean, then sum of squared deviations:
 // the exact two-pass variance) go through LDS.
@@ -383,6 +477,22 @@ RPE_API int rpe_dwconv3(const float *in0, int C0, const float *in1, int C1, cons
         if (gate) hipLaunchKernelGGL((dwconv3_kernel<1, true>), grid, block, 0, st, seg, weight, bias, C, H, W, out);
         else hipLaunchKernelGGL((dwconv3_kernel<1, false>), grid, block, 0, st, seg, weight, bias, C, H, W, out);
     }
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_gdfn_tail(const float *t, int B, int hidden, int H, int W, int kh, const float *dw_weight, const float *dw_bias,
+                          const float *packed_weight, int Cout, const float *shift, const float *residual, float *y, rpe_stream_t stream) {
+    if (!t || !dw_weight || !packed_weight || !y || B < 0 || hidden < 1 || H < 1 || W < 1 || Cout < 1) return RPE_EINVAL;
+    if ((kh != 1 && kh != 3) || (kh == 1 && H != 1)) return RPE_EINVAL;
+    auto aligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (W % 4 != 0 || Cout > 128 || B > 65535 || !aligned(t) || !aligned(y) || !aligned(residual)) return RPE_EUNSUPPORTED;
+    if (B == 0) return 0;
+    const int64_t P = (int64_t)H * W;
+    const int ktiles = (hidden + 3) / 4, n_otiles = (Cout + 15) / 16;
+    dim3 grid((unsigned)((P + 63) / 64), (unsigned)B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (kh == 3) hipLaunchKernelGGL(gdfn_tail_kernel<3>, grid, block, 0, st, t, hidden, H, W, dw_weight, dw_bias, packed_weight, ktiles, n_otiles, Cout, shift, residual, y);
+    else hipLaunchKernelGGL(gdfn_tail_kernel<1>, grid, block, 0, st, t, hidden, H, W, dw_weight, dw_bias, packed_weight, ktiles, n_otiles, Cout, shift, residual, y);
     return rpe_launch_status();
 }
 

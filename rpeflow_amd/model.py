@@ -130,9 +130,15 @@ class _GatedFeedForward(nn.Module):
 
     def forward(self, x, residual=None, inplace=False):
         """project_out(gelu(a) * b) (+ residual, added by project_out's GEMM; ``inplace``: accumulated into ``residual``)."""
-        if x.is_cuda:  # depth-wise conv + gelu gate in one kernel
-            from .restormer_ops import dwconv3
-            hidden = dwconv3([conv_module(self.project_in, x)], self.dwconv.weight, self.dwconv.bias, gate=True)
+        if x.is_cuda:
+            from .restormer_ops import dwconv3, gdfn_tail
+            from .utils import _inference_only
+            t = conv_module(self.project_in, x)
+            if _inference_only(x, *self.parameters()):  # the point-cloud blocks: 3-tap conv + gelu gate + project_out (+ residual) in one launch
+                out = gdfn_tail(t, self.dwconv.weight, self.dwconv.bias, self.project_out.weight, self.project_out.bias, residual, inplace)
+                if out is not None:
+                    return out
+            hidden = dwconv3([t], self.dwconv.weight, self.dwconv.bias, gate=True)  # depth-wise conv + gelu gate in one kernel
             return conv_module(self.project_out, hidden, residual=residual, inplace=inplace)
         a, b = self.dwconv(self.project_in(x)).chunk(2, dim=1)
         out = self.project_out(F.gelu(a) * b)

@@ -38,6 +38,39 @@ def dwconv3(inputs, weight, bias=None, gate=False):
     return out
 
 
+def gdfn_tail(t, dw_weight, dw_bias, out_weight, out_bias=None, residual=None, inplace=False, always=False):
+    """The gated feed-forward behind project_in in one launch: project_out(gelu(a) * b) (+ bias) (+ residual) with
+    a, b = dwconv(t).chunk(2, 1); ``t`` [B, 2h, H, W] or [B, 2h, N].  Returns None where the caller should keep dwconv3(gate=True) +
+    the 1x1 convolution: where the kernel does not apply (width not a multiple of 4, more than 128 output channels) and -- unless
+    ``always`` -- for 2-D maps, where it is correct but slower than the two launches (3x3 taps: the gate is 3x the work of the
+    3-tap form; level 1, C = 96: 296 against 237 us; the point-cloud blocks: 20-27 against 32 us).
+    ``inplace``: accumulate into ``residual`` itself."""
+    from .utils import _pw_packed_weight
+    _lib.require_gpu(t, dw_weight, out_weight, op="gdfn_tail")
+    two_d = t.dim() == 4
+    B, C2 = t.shape[:2]
+    H, W = (t.shape[2], t.shape[3]) if two_d else (1, t.shape[2])
+    hidden, cout = C2 // 2, out_weight.shape[0]
+    if W % 4 != 0 or cout > 128 or C2 % 2 or out_weight.numel() != cout * hidden or (two_d and not always):
+        return None
+    t = t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+    res = None
+    if residual is not None:
+        res = residual if (residual.dtype == torch.float32 and residual.is_contiguous()) else residual.float().contiguous()
+    out = res if (inplace and res is not None and res.data_ptr() == residual.data_ptr()) else torch.empty(
+        (B, cout) + tuple(t.shape[2:]), dtype=torch.float32, device=t.device)
+    w = dw_weight.detach().contiguous().float()
+    b = dw_bias.detach().contiguous().float() if dw_bias is not None else None
+    ob = out_bias.detach().contiguous().float() if out_bias is not None else None
+    with torch.cuda.device(t.device):
+        rc = _lib.lib().rpe_gdfn_tail(_ptr(t), B, hidden, H, W, 3 if two_d else 1, _ptr(w), _ptr(b), _ptr(_pw_packed_weight(out_weight)), cout,
+                                      _ptr(ob), _ptr(res), _ptr(out), _lib.stream_of(t))
+    if rc == -2:  # RPE_EUNSUPPORTED (alignment)
+        return None
+    _lib.check(rc, "gdfn_tail")
+    return out
+
+
 def channel_layernorm(x, weight, bias=None, eps=1e-5):
     """LayerNorm over dim 1 of [B,C,...] (biased variance); bias None = BiasFree form (no mean subtraction)."""
     _lib.require_gpu(x, weight, op="channel_layernorm")

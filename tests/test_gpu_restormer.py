@@ -255,6 +255,41 @@ def test_conv_chain_passes_epilogues_on_to_the_next_unfold(norm, H, W):
     assert len(calls) <= 3, "the dilated layers 2, 4, 8 of the context network still run an epilogue pass (%d passes)" % len(calls)
 
 
+@pytest.mark.parametrize("dims,shape", [(2, (2, 96, 36, 60)), (2, (1, 81, 24, 40)), (2, (4, 32, 16, 68)), (1, (3, 64, 512)), (1, (2, 96, 1028)),
+                                        (2, (1, 17, 5, 8)), (2, (2, 128, 8, 12)), (2, (2, 96, 144, 240))])
+@pytest.mark.parametrize("bias", [False, True])
+def test_gated_feed_forward_tail_in_one_launch(dims, shape, bias):
+    """rpe_gdfn_tail (depth-wise conv + gelu gate + project_out + bias + residual in one launch) against the two launches it
+    replaces -- rpe_dwconv3(gate) then rpe_pointwise_conv: the same arithmetic, so equal to fp32 re-association of the channel
+    sum (bit-identical where the 1x1 kernel does not split its channel loop: the large maps) -- and against the plain module on
+    the CPU; out of place, with a residual, and accumulated into the residual tensor itself."""
+    from rpeflow_amd.model import _GatedFeedForward
+    from rpeflow_amd.restormer_ops import dwconv3, gdfn_tail
+    from rpeflow_amd.utils import conv_module
+    torch.manual_seed(shape[1] + shape[-1])
+    ffn = _GatedFeedForward(shape[1], 2.66, bias, dims).to(DEV).eval()
+    x, r = torch.randn(shape, device=DEV), torch.randn(shape, device=DEV)
+    with torch.no_grad():
+        t = conv_module(ffn.project_in, x)
+        g = dwconv3([t], ffn.dwconv.weight, ffn.dwconv.bias, gate=True)
+        for res in (None, r):
+            two = conv_module(ffn.project_out, g, residual=res)
+            one = gdfn_tail(t, ffn.dwconv.weight, ffn.dwconv.bias, ffn.project_out.weight, ffn.project_out.bias, res, always=True)
+            assert one is not None
+            assert (one - two).abs().max() < 2e-6 * max(1.0, float(two.abs().max())), (one - two).abs().max().item()
+            if shape[2:] == (144, 240):  # (enough workgroups for the 1x1 kernel's plain form: channel sums in the same order)
+                assert torch.equal(one, two)
+        acc = r.clone()
+        out = gdfn_tail(t, ffn.dwconv.weight, ffn.dwconv.bias, ffn.project_out.weight, ffn.project_out.bias, acc, inplace=True, always=True)
+        assert out.data_ptr() == acc.data_ptr() and torch.equal(out, one)
+        assert torch.equal(ffn(x, residual=r), one if dims == 1 else two)  # the module: one launch for the point-cloud blocks, two for the maps
+        assert gdfn_tail(torch.randn(1, 2 * 85, 9, 15, device=DEV), ffn.dwconv.weight, None, ffn.project_out.weight, always=True) is None  # W % 4 != 0
+        assert (gdfn_tail(t, ffn.dwconv.weight, ffn.dwconv.bias, ffn.project_out.weight) is None) == (dims == 2)
+        import copy
+        cpu = copy.deepcopy(ffn).cpu()(x.cpu(), residual=r.cpu())
+    assert (one.cpu() - cpu).abs().max() < 3e-5 * max(1.0, float(cpu.abs().max()))
+
+
 def test_feed_forward_adds_its_residual_in_the_gemm():
     """_GatedFeedForward(x, residual=r) == r + _GatedFeedForward(x): project_out's GEMM carries the add (beta = 1)."""
     from rpeflow_amd.model import _GatedFeedForward
