@@ -8,6 +8,7 @@
 // are a few MB at most).
 #include <math.h>
 
+
 #include "common.h"
 
 namespace {
@@ -140,12 +141,12 @@ static inline unsigned xcd_grid(int ncb, int npb) { return (unsigned)(((ncb + 7)
 // (grid_sample_wrapper, utils.py:288-294).
 __global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__ feat, int C, int H, int W,
                                                        const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sp,
-                                                       int P, int add_grid, int border, int c_per_block,
+                                                       int P, int add_grid, int border, int c_per_block, int xcd_map,
                                                        float *__restrict__ out) {
     // scattered positions (grid_sample_wrapper): the XCD-aware mapping above; a warp (adjacent pixels sample adjacent taps: a
     // plane's lines are met once anyway) keeps the plain 3-D grid, which measured faster there (65 against 97 us at level 1)
     int cb = blockIdx.y, pb = blockIdx.x;
-    if (!add_grid && !xcd_block((C + c_per_block - 1) / c_per_block, cb, pb)) return;
+    if (xcd_map && !xcd_block((C + c_per_block - 1) / c_per_block, cb, pb)) return;
     const int p = pb * blockDim.x + threadIdx.x;
     const int b = blockIdx.z;
     if (p >= P) return;
@@ -573,11 +574,19 @@ RPE_API int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W, c
     if (add_pixel_grid && P != H * W) return RPE_EINVAL;
     if (B == 0 || C == 0 || P == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
-    const int cpb = channel_split(C, P, B);
+    int cpb = channel_split(C, P, B);
     dim3 grid((P + 255) / 256, (C + cpb - 1) / cpb, B);
-    if (!add_pixel_grid) grid = dim3(xcd_grid((C + cpb - 1) / cpb, (P + 255) / 256), 1, B);
+    int xcd_map = 0;
+    if (C >= 8) {
+        xcd_map = 1;
+        // XCD-aware mapping: at least 8 channel blocks (every XCD busy), about as many as the split above wanted
+        const int want = (C + cpb - 1) / cpb;
+        const int ncb = want <= 8 ? 8 : (want + 7) / 8 * 8;
+        cpb = (C + ncb - 1) / ncb;
+        grid = dim3(xcd_grid((C + cpb - 1) / cpb, (P + 255) / 256), 1, B);
+    }
     hipLaunchKernelGGL(bilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, C, H, W, xy, xy_sb, xy_sd, xy_sp, P,
-                       add_pixel_grid, border, cpb, out);
+                       add_pixel_grid, border, cpb, xcd_map, out);
     return rpe_launch_status();
 }
 
