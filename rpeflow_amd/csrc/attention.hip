@@ -9,9 +9,9 @@
 //                        G_ij / (max(|q_i|,eps) max(|k_j|,eps)), equals the reference's normalise-then-multiply up to
 //                        fp32 rounding.  Positions are split over workgroups; partial sums are written per workgroup
 //                        and added in a fixed order by the next kernel (deterministic, no atomics).
-//   attn_softmax_project_kernel  sums the partials, scales by the norms and the temperature, softmax over j (one wave per
-//                        row), and folds the 1x1 project_out convolution in: M[b] = W_o blockdiag_h(attn_h)  (C x C), so
-//                        that the caller finishes the block with ONE batched GEMM  out = residual + M[b] v[b].
+//   attn_softmax_kernel  sums the partials, scales by the norms and the temperature, softmax over j (one wave per row).
+//   attn_project_kernel  folds the 1x1 project_out convolution in: M[b] = W_o blockdiag_h(attn_h)  (C x C), so that the
+//                        caller finishes the block with ONE batched GEMM  out = residual + M[b] v[b].
 #include <math.h>
 
 #include "common.h"
@@ -152,95 +152,63 @@ __global__ __launch_bounds__(256) void attn_gram_kernel(const float *__restrict_
         for (int i = threadIdx.x; i < c; i += 256) np[heads * c + i] = norms[16 + i];
 }
 
-// softmax + project_out fold in one launch.  grid (B, Y), 256 threads; dynamic LDS: attn[b] (C*c floats) + the 2C squared
-// norms.  Every workgroup of batch b
-//   1. adds the S partial grams and partial norms of b in chunk order (sixteen loads in flight per thread: a thread's
-//      sums are chains of L2 round trips otherwise),
-//   2. scales each row by the norms and the temperature and takes its softmax over j (one wave per row, in LDS),
-//   3. writes its slice (blockIdx.y) of M[b][o][h*c + j] = sum_i W_o[o][h*c + i] * attn[b][h][i][j].
-// Steps 1-2 are repeated by the Y workgroups of a batch (a few hundred KB of L2 reads each) instead of travelling
-// through a second launch.  PACKED: M[b] is written in rpe_pointwise_conv's weight-fragment order
+// One wave per attention row (b, h, i): sums the partials in a fixed order, scales by the norms and the temperature,
+// softmax over j.  grid (ceil(B*C / 4)), 256 threads; attn_out [B][C][c].
+__global__ __launch_bounds__(256) void attn_softmax_kernel(const float *__restrict__ gpart, const float *__restrict__ npart, int S,
+                                                           const float *__restrict__ temperature, int B, int heads, int c, float eps,
+                                                           float *__restrict__ attn_out) {
+    const int lane = threadIdx.x & 63, C = heads * c;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B * C) return;
+    const int b = r / C, hi = r - b * C, h = hi / c, i = hi - h * c;
+    const float *gp = gpart + ((int64_t)b * heads + h) * S * c * c + i * c;
+    const float *np = npart + (int64_t)b * S * 2 * C;
+    float nq = 0.f;
+    for (int t = 0; t < S; ++t) nq += np[(int64_t)t * 2 * C + hi];
+    nq = fmaxf(sqrtf(nq), eps);
+    const float temp = temperature[h];
+    float v[2];  // c <= 96 < 128: columns lane and lane + 64
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = lane + 64 * u;
+        v[u] = -INFINITY;
+        if (j < c) {
+            float g = 0.f, nk = 0.f;
+            for (int t = 0; t < S; ++t) {
+                g += gp[(int64_t)t * c * c + j];
+                nk += np[(int64_t)t * 2 * C + C + h * c + j];
+            }
+            v[u] = g / (nq * fmaxf(sqrtf(nk), eps)) * temp;
+        }
+        mx = fmaxf(mx, v[u]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        v[u] = lane + 64 * u < c ? expf(v[u] - mx) : 0.f;
+        sum += v[u];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (lane + 64 * u < c) attn_out[(int64_t)r * c + lane + 64 * u] = v[u] * inv;
+}
+
+// M[b][o][h*c + j] = sum_i W_o[o][h*c + i] * attn[b][h][i][j].  grid (B, slices of M's elements), 256 threads;
+// dynamic LDS: attn[b] (C*c floats).  PACKED: M[b] is written in rpe_pointwise_conv's weight-fragment order
 // ([ceil(C/16)][ceil(C/4)][64]: entry (ot, kt, 16 k + i) = M[16 ot + i][4 kt + k], zero outside), so that the block's
 // "x + M[b] v[b]" is ONE launch of the 1x1 kernel with the residual in its epilogue instead of a copy + a batched GEMM.
 template <bool PACKED>
-__global__ __launch_bounds__(256) void attn_softmax_project_kernel(const float *__restrict__ gpart, const float *__restrict__ npart, int S,
-                                                                   const float *__restrict__ temperature, const float *__restrict__ w_out,
-                                                                   int heads, int c, float eps, float *__restrict__ m_out) {
+__global__ __launch_bounds__(256) void attn_project_kernel(const float *__restrict__ attn_in, const float *__restrict__ w_out, int heads,
+                                                           int c, float *__restrict__ m_out) {
     extern __shared__ float attn[];
-    const int C = heads * c, b = blockIdx.x, cc = c * c;
-    float *nrm = attn + C * c;
-    constexpr int TU = 8;
-    {  // 1a. squared norms: nrm[0..C) of q's rows, nrm[C..2C) of k's
-        const float *np = npart + (int64_t)b * S * 2 * C;
-        for (int o = threadIdx.x; o < 2 * C; o += 256) {
-            float n = 0.f;
-            for (int t0 = 0; t0 < S; t0 += TU) {
-                float v[TU];
-#pragma unroll
-                for (int u = 0; u < TU; ++u) v[u] = np[(int64_t)min(t0 + u, S - 1) * 2 * C + o];
-#pragma unroll
-                for (int u = 0; u < TU; ++u) n += t0 + u < S ? v[u] : 0.f;
-            }
-            nrm[o] = n;
-        }
-    }
-    {  // 1b. grams, two entries a trip
-        const int total = C * c;
-        for (int o0 = threadIdx.x; o0 < total; o0 += 512) {
-            const int o1 = min(o0 + 256, total - 1);
-            const int h0 = o0 / cc, h1 = o1 / cc;
-            const float *g0 = gpart + ((int64_t)b * heads + h0) * S * cc + (o0 - h0 * cc);
-            const float *g1 = gpart + ((int64_t)b * heads + h1) * S * cc + (o1 - h1 * cc);
-            float a0 = 0.f, a1 = 0.f;
-            for (int t0 = 0; t0 < S; t0 += TU) {
-                float v0[TU], v1[TU];
-#pragma unroll
-                for (int u = 0; u < TU; ++u) {
-                    const int64_t t = min(t0 + u, S - 1);
-                    v0[u] = g0[t * cc];
-                    v1[u] = g1[t * cc];
-                }
-#pragma unroll
-                for (int u = 0; u < TU; ++u) {
-                    a0 += t0 + u < S ? v0[u] : 0.f;
-                    a1 += t0 + u < S ? v1[u] : 0.f;
-                }
-            }
-            attn[o0] = a0;
-            if (o0 + 256 < total) attn[o0 + 256] = a1;
-        }
-    }
-    __syncthreads();
-    {  // 2. one wave per row
-        const int lane = threadIdx.x & 63;
-        for (int hi = threadIdx.x >> 6; hi < C; hi += 4) {
-            const int h = hi / c;
-            const float nq = fmaxf(sqrtf(nrm[hi]), eps), temp = temperature[h];
-            float *row = attn + hi * c;
-            float v[2];  // c <= 96 < 128: columns lane and lane + 64
-            float mx = -INFINITY;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int j = lane + 64 * u;
-                v[u] = j < c ? row[j] / (nq * fmaxf(sqrtf(nrm[C + h * c + j]), eps)) * temp : -INFINITY;
-                mx = fmaxf(mx, v[u]);
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            float sum = 0.f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                v[u] = lane + 64 * u < c ? expf(v[u] - mx) : 0.f;
-                sum += v[u];
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const float inv = 1.0f / sum;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (lane + 64 * u < c) row[lane + 64 * u] = v[u] * inv;
-        }
-    }
+    const int C = heads * c, b = blockIdx.x;
+    for (int o = threadIdx.x; o < C * c; o += 256) attn[o] = attn_in[(int64_t)b * C * c + o];
     __syncthreads();
     const int kt_n = (C + 3) / 4, total = PACKED ? ((C + 15) / 16) * kt_n * 64 : C * C;
     float *mb = m_out + (int64_t)b * total;
@@ -285,7 +253,7 @@ int launch_gram(bool vec, dim3 grid, hipStream_t st, const float *q, const float
 
 RPE_API int64_t rpe_channel_attention_workspace_floats(int B, int heads, int c, int64_t P) {
     if (B < 0 || heads < 1 || c < 1 || P < 0) return -1;
-    return (int64_t)B * attn_chunks(P > 0 ? P : 1) * ((int64_t)heads * c * c + 2 * (int64_t)heads * c);
+    return (int64_t)B * attn_chunks(P > 0 ? P : 1) * ((int64_t)heads * c * c + 2 * (int64_t)heads * c) + (int64_t)B * heads * c * c;
 }
 
 namespace {
@@ -295,8 +263,7 @@ int attention_matrix(const float *q, const float *k, int64_t batch_stride, const
     if (B == 0) return 0;
     if (c > 96 || heads > 65535 || B > 65535) return RPE_EUNSUPPORTED;
     const int C = heads * c, S = attn_chunks(P);
-    const size_t lds = ((size_t)C * c + 2 * (size_t)C) * sizeof(float);  // attn[b] and the norms, staged by attn_softmax_project_kernel
-    if (lds > 64 * 1024) return RPE_EUNSUPPORTED;
+    if ((size_t)C * c * sizeof(float) > 64 * 1024) return RPE_EUNSUPPORTED;  // attn[b] staged in LDS by attn_project_kernel
     float *gpart = workspace, *npart = workspace + (int64_t)B * heads * S * c * c;
     const bool vec = P % 4 == 0 && batch_stride % 4 == 0 && ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k)) & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
@@ -312,9 +279,10 @@ int attention_matrix(const float *q, const float *k, int64_t batch_stride, const
         default: rc = launch_gram<6>(vec, grid, st, q, k, batch_stride, heads, c, P, gpart, npart); break;
     }
     if (rc) return rc;
-    const dim3 tail(B, C >= 64 ? 8 : 4);
-    if (packed) hipLaunchKernelGGL(attn_softmax_project_kernel<true>, tail, dim3(256), lds, st, gpart, npart, S, temperature, w_out, heads, c, eps, m_out);
-    else hipLaunchKernelGGL(attn_softmax_project_kernel<false>, tail, dim3(256), lds, st, gpart, npart, S, temperature, w_out, heads, c, eps, m_out);
+    float *attn = npart + (int64_t)B * S * 2 * C;
+    hipLaunchKernelGGL(attn_softmax_kernel, dim3((B * C + 3) / 4), dim3(256), 0, st, gpart, npart, S, temperature, B, heads, c, eps, attn);
+    if (packed) hipLaunchKernelGGL(attn_project_kernel<true>, dim3(B, C >= 64 ? 16 : 4), dim3(256), (size_t)C * c * sizeof(float), st, attn, w_out, heads, c, m_out);
+    else hipLaunchKernelGGL(attn_project_kernel<false>, dim3(B, C >= 64 ? 16 : 4), dim3(256), (size_t)C * c * sizeof(float), st, attn, w_out, heads, c, m_out);
     return rpe_launch_status();
 }
 }  // namespace
