@@ -234,8 +234,8 @@ int rpe_ids_flow_inverse(const float *xyz, int64_t x_sb, int64_t x_sc, int64_t x
  * For pixel p with nearest projected point i = nn_idx[b][p]:
  *   out[b][0:2][p] = xy[b][:,i] - (p%W, p/W);  out[b][2][p] = mean_c(sample(feat_2d, xy_i)[c]*feat_2d[b][c][p]);
  *   out[b][3+c][p] = feat_3d[b][c][i].   feat_2d [B,C2,H,W] contiguous, out [B,C3+3,H,W].
- * workspace: B*N*(C2+C3) floats of scratch (per-point rows: the samples are taken once per
- * point, as the reference does, then gathered per pixel).
+ * workspace: B*N*(round4(C2)+round4(C3)) floats of scratch, 16-byte aligned (per-point rows: the samples are taken once per
+ * point, as the reference does, then gathered per pixel; round4(n) = n rounded up to a multiple of 4).
  * sampled_2d [B,C2,N] through element strides (batch, channel, point), or NULL: what grid_sample_wrapper(feat_2d, xy) returned --
  *   the 3-D fuser of the same (map, points) pair computes it anyway (RPEFlow_core.py:334-337, 394-395), and the per-point
  *   bilinear taps are the expensive half of this operator.

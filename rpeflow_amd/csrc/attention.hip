@@ -163,8 +163,33 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(const float *__restri
     const int b = r / C, hi = r - b * C, h = hi / c, i = hi - h * c;
     const float *gp = gpart + ((int64_t)b * heads + h) * S * c * c + i * c;
     const float *np = npart + (int64_t)b * S * 2 * C;
+    // the S partials are added in chunk order, their loads issued eight chunks at a time: one at a time the sums are
+    // chains of S memory round trips (the partials were written on other XCDs: every load misses this one's L2)
+    constexpr int TU = 8;
     float nq = 0.f;
-    for (int t = 0; t < S; ++t) nq += np[(int64_t)t * 2 * C + hi];
+    float g[2] = {0.f, 0.f}, nk[2] = {0.f, 0.f};
+    const int j0 = min(lane, c - 1), j1 = min(lane + 64, c - 1);
+    for (int t0 = 0; t0 < S; t0 += TU) {
+        float a[TU], g0[TU], g1[TU], k0[TU], k1[TU];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int64_t t = min(t0 + u, S - 1);
+            a[u] = np[t * 2 * C + hi];
+            g0[u] = gp[t * c * c + j0];
+            k0[u] = np[t * 2 * C + C + h * c + j0];
+            g1[u] = gp[t * c * c + j1];
+            k1[u] = np[t * 2 * C + C + h * c + j1];
+        }
+#pragma unroll
+        for (int u = 0; u < TU; ++u)
+            if (t0 + u < S) {
+                nq += a[u];
+                g[0] += g0[u];
+                nk[0] += k0[u];
+                g[1] += g1[u];
+                nk[1] += k1[u];
+            }
+    }
     nq = fmaxf(sqrtf(nq), eps);
     const float temp = temperature[h];
     float v[2];  // c <= 96 < 128: columns lane and lane + 64
@@ -172,15 +197,7 @@ __global__ __launch_bounds__(256) void attn_softmax_kernel(const float *__restri
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int j = lane + 64 * u;
-        v[u] = -INFINITY;
-        if (j < c) {
-            float g = 0.f, nk = 0.f;
-            for (int t = 0; t < S; ++t) {
-                g += gp[(int64_t)t * c * c + j];
-                nk += np[(int64_t)t * 2 * C + C + h * c + j];
-            }
-            v[u] = g / (nq * fmaxf(sqrtf(nk), eps)) * temp;
-        }
+        v[u] = j < c ? g[u] / (nq * fmaxf(sqrtf(nk[u]), eps)) * temp : -INFINITY;
         mx = fmaxf(mx, v[u]);
     }
 #pragma unroll

@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict
     const int b = blockIdx.z;
     if (i >= N) return;
     const int c0 = cb * c_per_block, c1 = min(CT, c0 + c_per_block);
-    float *row = rows + ((int64_t)b * N + i) * CT;
+    const int C2p = (C2 + 3) & ~3, RS = C2p + ((C3 + 3) & ~3);  // both halves of a row start on 16 bytes (float4 reads per pixel)
+    float *row = rows + ((int64_t)b * N + i) * RS;
     if (c0 < C2 && sampled) {  // the caller has grid_sample_wrapper(feat_2d, xy) already (the 3-D fuser of the same pair needs it)
         const float *sp = sampled + (int64_t)b * sm_sb + (int64_t)i * sm_sn;
         const int ce = min(c1, C2);
@@ -287,15 +288,66 @@ __global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict
     }
     const float *f3 = feat3d + (int64_t)b * f3_sb + (int64_t)i * f3_sn;
     {
+        float *row3 = row + C2p - C2;  // logical channel c >= C2 lives at row[C2p + (c - C2)]
         int c = max(c0, C2);
         for (; c + 8 <= c1; c += 8) {
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = f3[(int64_t)(c + u - C2) * f3_sc];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) row[c + u] = v[u];
+            for (int u = 0; u < 8; ++u) row3[c + u] = v[u];
         }
-        for (; c < c1; ++c) row[c] = f3[(int64_t)(c - C2) * f3_sc];
+        for (; c < c1; ++c) row3[c] = f3[(int64_t)(c - C2) * f3_sc];
+    }
+}
+
+// point_rows_kernel's job when the caller brings the samples (the decoder levels do): a transpose of [C2 | C3] channel
+// planes into per-point rows.  One thread per (point, channel slice) writes 32-byte pieces of 64 different rows; here a
+// workgroup takes PB consecutive points, reads every plane's PB values as one coalesced segment, turns the tile in LDS
+// (odd pitch: no bank conflicts) and writes the PB rows -- contiguous in memory -- as float4.
+__global__ __launch_bounds__(256) void point_rows_copy_kernel(const float *__restrict__ sampled, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
+                                                              int C2, const float *__restrict__ feat3d, int64_t f3_sb, int64_t f3_sc,
+                                                              int64_t f3_sn, int C3, int N, int PB, float *__restrict__ rows) {
+    extern __shared__ float tile[];
+    const int C2p = (C2 + 3) & ~3, C3p = (C3 + 3) & ~3, RS = C2p + C3p, RP = RS | 1;
+    const int b = blockIdx.y, i0 = blockIdx.x * PB;
+    const int pl = threadIdx.x % PB, g = threadIdx.x / PB, G = 256 / PB;
+    const int i = min(i0 + pl, N - 1);
+    float *mine = tile + pl * RP;
+    constexpr int CU = 16;  // (level 1: 118 planes over 8 slices = 15 loads a thread, one round trip)
+    {
+        const float *sp = sampled + (int64_t)b * sm_sb + (int64_t)i * sm_sn;
+        for (int c = g; c < C2; c += G * CU) {
+            float v[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) v[u] = sp[(int64_t)min(c + u * G, C2 - 1) * sm_sc];
+#pragma unroll
+            for (int u = 0; u < CU; ++u)
+                if (c + u * G < C2) mine[c + u * G] = v[u];
+        }
+        if (g == 0)
+            for (int c = C2; c < C2p; ++c) mine[c] = 0.f;
+    }
+    if (C3 > 0) {
+        const float *f3 = feat3d + (int64_t)b * f3_sb + (int64_t)i * f3_sn;
+        for (int c = g; c < C3; c += G * CU) {
+            float v[CU];
+#pragma unroll
+            for (int u = 0; u < CU; ++u) v[u] = f3[(int64_t)min(c + u * G, C3 - 1) * f3_sc];
+#pragma unroll
+            for (int u = 0; u < CU; ++u)
+                if (c + u * G < C3) mine[C2p + c + u * G] = v[u];
+        }
+        if (g == 0)
+            for (int c = C3; c < C3p; ++c) mine[C2p + c] = 0.f;
+    }
+    __syncthreads();
+    const int npts = min(PB, N - i0), RS4 = RS >> 2;
+    float4 *dst = reinterpret_cast<float4 *>(rows + ((int64_t)b * N + i0) * RS);
+    for (int e = threadIdx.x; e < npts * RS4; e += 256) {
+        const int r = e / RS4, q = (e - r * RS4) * 4;
+        const float *t = tile + r * RP + q;
+        dst[e] = make_float4(t[0], t[1], t[2], t[3]);
     }
 }
 
@@ -316,51 +368,65 @@ __global__ __launch_bounds__(256) void project_rows_kernel(const float *__restri
     float *o = out + (int64_t)b * (C3 + 3 + n_tail) * HW + p;
     o[0] = px - (float)(p % W);
     o[HW] = py - (float)(p / W);
-    const float *row = rows + ((int64_t)b * N + i) * (C2 + C3);
+    // A pixel's row is a gather: 64 lanes, 64 rows.  Read as float4 (the two halves of a row start on 16 bytes) it is a quarter
+    // of the load instructions (level 1: 19.5 -> 19.1 us, 70 MB: the kernel is at the bandwidth a copy reaches).
+    const int C2p = (C2 + 3) & ~3, RS = C2p + ((C3 + 3) & ~3);
+    const float *row = rows + ((int64_t)b * N + i) * RS;
+    const float4 *row4 = reinterpret_cast<const float4 *>(row);
     const float *f2 = feat2d + (int64_t)b * C2 * HW + p;
     float s = 0.f;
     int c = 0;
-    // loads of sixteen (then four) channels in flight; the sum keeps the reference's channel order.  On the coarse maps a
-    // launch is a few waves and a thread's loop is a chain of memory round trips: four channels a trip were 25 us for 192
-    // channels over 540 pixels.
+    // sixteen (then four) channels in flight; the sum keeps the reference's channel order
     for (; c + 16 <= C2; c += 16) {
-        float r[16], f[16];
+        float4 r[4];
+        float f[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            r[u] = row[c + u];
-            f[u] = f2[(int64_t)(c + u) * HW];
-        }
+        for (int u = 0; u < 4; ++u) r[u] = row4[(c >> 2) + u];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) s += r[u] * f[u];
-    }
-    for (; c + 4 <= C2; c += 4) {
-        float r[4], f[4];
+        for (int u = 0; u < 16; ++u) f[u] = f2[(int64_t)(c + u) * HW];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            r[u] = row[c + u];
-            f[u] = f2[(int64_t)(c + u) * HW];
+            s += r[u].x * f[4 * u];
+            s += r[u].y * f[4 * u + 1];
+            s += r[u].z * f[4 * u + 2];
+            s += r[u].w * f[4 * u + 3];
         }
+    }
+    for (; c + 4 <= C2; c += 4) {
+        const float4 r = row4[c >> 2];
+        float f[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s += r[u] * f[u];
+        for (int u = 0; u < 4; ++u) f[u] = f2[(int64_t)(c + u) * HW];
+        s += r.x * f[0];
+        s += r.y * f[1];
+        s += r.z * f[2];
+        s += r.w * f[3];
     }
     for (; c < C2; ++c) s += row[c] * f2[(int64_t)c * HW];
     o[2 * (int64_t)HW] = s / (float)C2;
+    const float *row3 = row + C2p;
+    const float4 *row34 = reinterpret_cast<const float4 *>(row3);
     c = 0;
     for (; c + 16 <= C3; c += 16) {
-        float r[16];
+        float4 r[4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) r[u] = row[C2 + c + u];
+        for (int u = 0; u < 4; ++u) r[u] = row34[(c >> 2) + u];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) o[(int64_t)(3 + c + u) * HW] = r[u];
+        for (int u = 0; u < 4; ++u) {
+            o[(int64_t)(3 + c + 4 * u) * HW] = r[u].x;
+            o[(int64_t)(3 + c + 4 * u + 1) * HW] = r[u].y;
+            o[(int64_t)(3 + c + 4 * u + 2) * HW] = r[u].z;
+            o[(int64_t)(3 + c + 4 * u + 3) * HW] = r[u].w;
+        }
     }
     for (; c + 4 <= C3; c += 4) {
-        float r[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) r[u] = row[C2 + c + u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) o[(int64_t)(3 + c + u) * HW] = r[u];
+        const float4 r = row34[c >> 2];
+        o[(int64_t)(3 + c) * HW] = r.x;
+        o[(int64_t)(3 + c + 1) * HW] = r.y;
+        o[(int64_t)(3 + c + 2) * HW] = r.z;
+        o[(int64_t)(3 + c + 3) * HW] = r.w;
     }
-    for (; c < C3; ++c) o[(int64_t)(3 + c) * HW] = row[C2 + c];
+    for (; c < C3; ++c) o[(int64_t)(3 + c) * HW] = row3[c];
     for (int t = 0; t < n_sub; ++t) {  // (after the copy above: same thread, same addresses)
         float *q = o + (int64_t)(3 + C3 - n_sub + t) * HW;
         *q = *q - sub[((int64_t)b * n_sub + t) * HW + p];
@@ -395,7 +461,8 @@ __global__ __launch_bounds__(CG * 64) void project_rows_small_kernel(const float
     const bool valid = p < HW;
     const int pc = valid ? p : HW - 1;  // (lanes past the end read the last pixel and store nothing)
     const int64_t i = nn[(int64_t)b * HW + pc];
-    const float *row = rows + ((int64_t)b * N + i) * (C2 + C3);
+    const int C2p = (C2 + 3) & ~3, RS = C2p + ((C3 + 3) & ~3);
+    const float *row = rows + ((int64_t)b * N + i) * RS;
     const float *f2 = feat2d + (int64_t)b * C2 * HW + pc;
     float *o = out + (int64_t)b * (C3 + 3 + n_tail) * HW + pc;
     constexpr int CU = 8;
@@ -423,7 +490,7 @@ __global__ __launch_bounds__(CG * 64) void project_rows_small_kernel(const float
 #pragma unroll
             for (int u = 0; u < CU; ++u) {
                 const int cc = min(c + u, c1 - 1);
-                r[u] = row[C2 + cc];
+                r[u] = row[C2p + cc];
                 if (cc >= C3 - n_sub) r[u] = r[u] - sp[(int64_t)cc * HW];
             }
 #pragma unroll
@@ -638,12 +705,20 @@ RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_
     if (!xy || !feat_2d || !feat_3d || !nn_idx || !out || !workspace || B < 0 || C2 < 1 || C3 < 0 || H < 1 || W < 1 || N < 1)
         return RPE_EINVAL;
     if (n_subtract < 0 || n_subtract > C3 || n_append < 0 || (n_subtract > 0 && !subtract) || (n_append > 0 && !append)) return RPE_EINVAL;
+    if (reinterpret_cast<uintptr_t>(workspace) & 15) return RPE_EINVAL;
     if (B == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int cpb = 8;  // channels per thread: 32-byte row segments, (C2+C3)/8 times the threads
-    hipLaunchKernelGGL(point_rows_kernel, dim3(xcd_grid((C2 + C3 + cpb - 1) / cpb, (N + 255) / 256), 1, B), dim3(256), 0, st, xy, xy_sb, xy_sd,
-                       xy_sn, feat_2d, C2, H, W, feat_3d, f3_sb, f3_sc, f3_sn, C3, N, cpb, sampled_2d, sm_sb, sm_sc, sm_sn, workspace);
+    const int RP = (((C2 + 3) & ~3) + ((C3 + 3) & ~3)) | 1;  // LDS pitch of point_rows_copy_kernel
+    const int PB = 32;  // points per workgroup: 512 workgroups at level 1, 10.0 us (64 points: 10.9; one thread per point and slice: 14.5)
+    if (sampled_2d && PB * RP * 4 <= 64 * 1024) {
+        hipLaunchKernelGGL(point_rows_copy_kernel, dim3((N + PB - 1) / PB, B), dim3(256), (size_t)PB * RP * sizeof(float), st, sampled_2d, sm_sb,
+                           sm_sc, sm_sn, C2, feat_3d, f3_sb, f3_sc, f3_sn, C3, N, PB, workspace);
+    } else {
+        const int cpb = 8;  // channels per thread: 32-byte row segments, (C2+C3)/8 times the threads
+        hipLaunchKernelGGL(point_rows_kernel, dim3(xcd_grid((C2 + C3 + cpb - 1) / cpb, (N + 255) / 256), 1, B), dim3(256), 0, st, xy, xy_sb,
+                           xy_sd, xy_sn, feat_2d, C2, H, W, feat_3d, f3_sb, f3_sc, f3_sn, C3, N, cpb, sampled_2d, sm_sb, sm_sc, sm_sn, workspace);
+    }
     if ((int64_t)B * H * W <= 16384) {  // the coarse levels (up to 36 x 60 at batch 4): channels split over eight waves
         hipLaunchKernelGGL(project_rows_small_kernel<8>, dim3((H * W + 63) / 64, B), dim3(8 * 64), 0, st, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2,
                            H, W, C3, N, workspace, nn_idx, subtract, n_subtract, append, n_append, out);

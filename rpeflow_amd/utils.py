@@ -626,7 +626,7 @@ def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=
         n_app = append.shape[1]
         assert append.shape == (B, n_app, H, W)
     out = torch.empty((B, C3 + 3 + n_app, H, W), dtype=torch.float32, device=feat_2d.device)
-    rows = torch.empty((B, N, C2 + C3), dtype=torch.float32, device=feat_2d.device)  # kernel scratch
+    rows = torch.empty((B, N, (C2 + 3) // 4 * 4 + (C3 + 3) // 4 * 4), dtype=torch.float32, device=feat_2d.device)  # kernel scratch
     sm_strides = (0, 0, 0)
     if sampled_2d is not None:
         sampled_2d = _f32(sampled_2d)

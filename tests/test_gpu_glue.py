@@ -526,7 +526,10 @@ def test_project_feat_with_the_fusers_two_elementwise_steps_inside():
     against the plain call followed by the two PyTorch steps; odd map sizes, with and without caller-provided samples."""
     from rpeflow_amd import utils as U
     torch.manual_seed(11)
-    for B, C2, C3, H, W, N, E in [(2, 81, 34, 9, 15, 256, 32), (1, 32, 5, 7, 5, 40, 3), (3, 16, 66, 18, 30, 512, 64)]:
+    # (the last two: rows too wide for 64 points of them in LDS -> 32 points a workgroup; then too wide for that -> one thread
+    # per point and channel slice)
+    for B, C2, C3, H, W, N, E in [(2, 81, 34, 9, 15, 256, 32), (1, 32, 5, 7, 5, 40, 3), (3, 16, 66, 18, 30, 512, 64),
+                                  (2, 192, 195, 6, 10, 130, 4), (1, 300, 290, 4, 5, 70, 2)]:
         xy = torch.rand(B, 2, N, device="cuda:0") * torch.tensor([W - 1.0, H - 1.0], device="cuda:0").view(1, 2, 1)
         f2, f3 = torch.randn(B, C2, H, W, device="cuda:0"), torch.randn(B, C3, N, device="cuda:0")
         nn = torch.randint(0, N, (B, H * W), device="cuda:0")

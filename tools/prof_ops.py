@@ -1,5 +1,5 @@
 """Single hot-path operators at the forward's level-1 shapes, for rocprofv3 --pmc / --kernel-trace runs.
-Usage: python3 tools/prof_ops.py <pointconv|knn16|knn3|knn2d|corr3d> [iters]"""
+Usage: python3 tools/prof_ops.py <pointconv|knn16|knn3|knn2d|corr3d|project> [iters]"""
 import os
 import sys
 
@@ -44,6 +44,14 @@ with torch.no_grad():
         xyz2 = xyz1 + 0.05 * torch.randn_like(xyz1)
         f1, f2 = torch.randn(4, 32, 4096, device=dev), torch.randn(4, 32, 4096, device=dev)
         step = lambda: m(xyz1, f1, xyz2, f2)
+    elif which == "project":  # project_feat_with_nn_corr at level 1: B=4, 144x240, N=4096, C2=81, C3=37 (RPEFlow_core.py:78-83)
+        from rpeflow_amd import utils as U
+        B, H, W, N, C2, C3 = 4, 144, 240, 4096, 81, 37
+        feat2d, feat3d = torch.randn(B, C2, H, W, device=dev), torch.randn(B, C3, N, device=dev)
+        xy = torch.stack([torch.rand(B, N, device=dev) * W, torch.rand(B, N, device=dev) * H], 1)
+        nn = k_nearest_neighbor(xy, U.mesh_grid(B, H, W, dev).reshape(B, 2, -1), 1)[..., 0]
+        sampled = U.grid_sample_wrapper(feat2d, xy)  # what the 3-D fuser of the pair has already (the decoder levels pass it on)
+        step = lambda: (U.project_feat_with_nn_corr(xy, feat2d, feat3d, nn), U.project_feat_with_nn_corr(xy, feat2d, feat3d, nn, sampled_2d=sampled))
     else:
         raise SystemExit("unknown operator " + which)
     for _ in range(iters):
