@@ -80,6 +80,8 @@ def parse():
     p.add_argument("--eval-batches", type=int, default=64, help="batches per rank of the 'eval' leg that the forward workload reports as well (0: skip)")
     p.add_argument("--eval-workers", type=int, default=None, help="loader threads per rank (default: rpeflow_amd.evaluate.default_workers())")
     p.add_argument("--eval-pinned", action="store_true", help="hold the cached synthetic set in pinned memory (no staging pass)")
+    p.add_argument("--eval-raw-events", type=int, default=0, help="the evaluation's samples carry up to this many RAW events each ([n,4] float32, "
+                   "as the reference's dataset loads them without a pre-processed file) instead of voxel grids; the input pipeline voxelises them on the device")
     p.add_argument("--eval-distinct", type=int, default=None, help="distinct samples of the evaluation's synthetic set (default: 16 per rank)")
     p.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)  # tests: all ranks on the visible GPU(s), collective on gloo
     p.add_argument("--backend", choices=["nccl", "gloo", "none"], default="nccl",
@@ -302,7 +304,7 @@ def cpu_baseline(workload, config="things", timeout_s=420):
                 "sample": f"worker exceeded {timeout_s} s"}
 
 
-def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist, workers=None, pinned=False, backend="nccl", distinct=None):
+def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist, workers=None, pinned=False, backend="nccl", distinct=None, raw_events=0):
     """The sharded evaluation END TO END (rpeflow_amd.evaluate.evaluate, the counterpart of eval_withocc.py:43-135): every
     rank reads its shard of a cached synthetic set (frame pairs r, r + W, ...) through the input pipeline -- loader threads
     into pinned host batches, H2D on a copy stream, the forward replayed from the HIP graph with the next batch's sampling
@@ -315,10 +317,10 @@ def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist,
     n = world * n_batches * batch_size
     distinct = world * per_rank if distinct is None else distinct
     data = SyntheticPairs(n, cfg["H"], cfg["W"], NPTS, dsec=cfg["dsec"], distinct=distinct, cache=True, pin=pinned,
-                          first_seed=cfg["first_seed"])
+                          first_seed=cfg["first_seed"], events=raw_events)
     mine = E.shard_indices(n, rank, world)
     t_gen = data.prepare(indices=mine)
-    warm = SyntheticPairs(world * 3 * batch_size, cfg["H"], cfg["W"], NPTS, dsec=cfg["dsec"], distinct=distinct, first_seed=cfg["first_seed"])
+    warm = SyntheticPairs(world * 3 * batch_size, cfg["H"], cfg["W"], NPTS, dsec=cfg["dsec"], distinct=distinct, first_seed=cfg["first_seed"], events=raw_events)
     warm.cache, warm.pin = data.cache, pinned  # same samples: the loader threads, the rings and the graph get their first use untimed
     E.evaluate(model, warm, batch_size, dev, rank, world, forward=forward, workers=workers)
     torch.cuda.synchronize()
@@ -343,7 +345,8 @@ def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist,
         "h2d_GBps_per_rank": round(stats["bytes"] / mine_dt / 1e9, 2), "h2d_MB_per_batch": round(stats["bytes"] / max(1, stats["batches"]) / 1e6, 1),
         "loader": {"threads": stats["workers"], "staging": "none: samples lie in pinned memory" if stats["direct"] else "pinned ring of host batches",
                    "copy": "dedicated HIP stream, one batch ahead of the replay", "copy_stream_probe_ms": stats.get("copy_stream_probe_ms"), "generator_s_untimed": round(t_gen, 2),
-                   "distinct_samples": distinct},
+                   "distinct_samples": distinct,
+                   **({"events": "raw: up to %d float32 events a sample, voxelised on the device by the copy stage (10 bins x 2 polarities)" % raw_events} if raw_events else {})},
         "collective": "one SUM all-reduce of float64[12] (%s)" % (backend if dist is not None else "single rank: none"),
         "metrics": {k: (float("%.12g" % v) if isinstance(v, float) else v) for k, v in metrics.items() if k != "counts"},
         "samples": metrics["counts"]["3d"] / NPTS,
@@ -545,7 +548,7 @@ def main():
         n_eval = args.steps if args.workload == "eval" else args.eval_batches
         if forward is not None and n_eval > 0:
             dt_eval, eval_info = eval_leg(model, forward, dev, cfg, args.batch, n_eval, rank, world, dist, workers=args.eval_workers,
-                                          pinned=args.eval_pinned, backend=args.backend, distinct=args.eval_distinct)
+                                          pinned=args.eval_pinned, backend=args.backend, distinct=args.eval_distinct, raw_events=args.eval_raw_events)
             if args.workload == "eval":
                 dt = dt_eval
             else:

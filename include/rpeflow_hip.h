@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 6
+#define RPE_ABI_VERSION 7
 
 #define RPE_EINVAL (-1)       /* bad size / null pointer */
 #define RPE_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
@@ -367,14 +367,15 @@ int rpe_channel_attention_matrix(const float *q, const float *k, int64_t batch_s
  *   (zero outside).  flow [B,2,H,W], mask [B,9*s*s,H,W], out [B,2,H*s,W*s]; s in {2,4,8}.                        */
 int rpe_convex_upsample(const float *flow, const float *mask, int B, int H, int W, int scale, float *out, rpe_stream_t stream);
 /* rpe_events_to_voxel: event stream -> voxel grid with temporal bilinear weights (event_utils.py:109-128, 211-303).
- *   Events are given stably sorted by pixel (pixel = y * W + x): pixel_sorted, t_sorted (the raw float64 timestamps),
- *   polarity_sorted, and the first index of every run of equal pixels (run_start [runs]).  t_first / t_last: timestamps
- *   of the first and last event of the ORIGINAL order.  out [C][HW] fp32, zero-initialised by the caller; C = bins, or
- *   2 * bins with split_polarity (positive grids, then negative grids).  Sums are formed per pixel in the events'
- *   original order: bit-identical to the reference's CPU index_put_(accumulate=True).                              */
-int rpe_events_to_voxel(const int *pixel_sorted, const double *t_sorted, const int *polarity_sorted, const int *run_start,
-                        int runs, int n_events, double t_first, double t_last, int bins, int split_polarity, int64_t HW,
-                        float *out, rpe_stream_t stream);
+ *   Events are given stably sorted by pixel (pixel = y * W + x): pixel_sorted, t_sorted (the raw timestamps: float64, or
+ *   float32 with t_is_f32 -- what load_events_h5 returns, event_utils.py:11-20; the arithmetic is then float32 throughout,
+ *   as numpy and torch do it on such arrays), polarity_sorted, and the first index of every run of equal pixels
+ *   (run_start [runs]).  t_first / t_last: timestamps of the first and last event of the ORIGINAL order.  out [C][HW] fp32,
+ *   zero-initialised by the caller; C = bins, or 2 * bins with split_polarity (positive grids, then negative grids).  Sums
+ *   are formed per pixel in the events' original order: bit-identical to the reference's CPU index_put_(accumulate=True). */
+int rpe_events_to_voxel(const int *pixel_sorted, const void *t_sorted, int t_is_f32, const int *polarity_sorted,
+                        const int *run_start, int runs, int n_events, double t_first, double t_last, int bins,
+                        int split_polarity, int64_t HW, float *out, rpe_stream_t stream);
 /* rpe_channel_affine_act: y[b][c][p] = act(scale[c]*y[b][c][p] + shift[c]) IN PLACE over [B,C,P] -- the bias add,
  *   eval-mode BatchNorm and activation after a Conv{1,2}dNormRelu convolution (models/utils.py:7-62) in one pass.
  *   scale / shift may be NULL (1 / 0).  act: 0 none, 1 relu, 2 leaky_relu(slope).                              */

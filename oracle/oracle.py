@@ -285,19 +285,23 @@ def correlation3d(params, xyz1, feat1, xyz2, feat2, knn_indices_1in1=None, k=16)
 # event voxelisation (event_utils.py:109-128, 211-303; temporal_bilinear=True)
 # --------------------------------------------------------------------------
 def events_to_voxel(events, num_bins, height, width, event_polarity):
-    """events [N,4] float64 (x, y, t, polarity).  Restates eventsToXYTP(post_process=True) -> events_to_voxel_torch /
-    events_to_neg_pos_voxel_torch: float64 time normalisation, weights rounded to float32, accumulated per bin in event
-    order (np.add.at is sequential, like index_put_(accumulate=True) on the CPU)."""
-    ev = np.asarray(events, np.float64)
+    """events [N,4] (x, y, t, polarity), float64 or float32.  Restates eventsToXYTP(post_process=True) -> events_to_voxel_torch /
+    events_to_neg_pos_voxel_torch in the arithmetic numpy and torch use for the array's dtype: float64 arrays in float64; float32
+    arrays (what load_events_h5 returns, event_utils.py:11-20) in float32 throughout -- deltaT + 1e-6 stays a float32 under
+    numpy 2's scalar promotion, which is what the goldens were generated with.  Weights rounded to float32, accumulated per
+    bin in event order (np.add.at is sequential, like index_put_(accumulate=True) on the CPU)."""
+    ev = np.asarray(events)
+    T = np.float32 if ev.dtype == np.float32 else np.float64
+    ev = ev.astype(T, copy=False)
     xs, ys, ps = ev[:, 0].astype(np.int32), ev[:, 1].astype(np.int32), ev[:, 3].astype(np.int32)
-    ts = (ev[:, 2] - ev[0, 2]) / ((ev[-1, 2] - ev[0, 2]) + 1e-6)
-    t_norm = (ts - ts[0]) / (ts[-1] - ts[0]) * (num_bins - 1)
-    grids = [np.where(ps > 0, 1.0, 0.0), np.where(ps <= 0, 1.0, 0.0)] if event_polarity else [ps.astype(np.float64)]
+    ts = ((ev[:, 2] - ev[0, 2]) / T((ev[-1, 2] - ev[0, 2]) + T(1e-6))).astype(T)
+    t_norm = ((ts - ts[0]) / T(ts[-1] - ts[0]) * T(num_bins - 1)).astype(T)
+    grids = [np.where(ps > 0, T(1), T(0)), np.where(ps <= 0, T(1), T(0))] if event_polarity else [ps.astype(T)]
     out = []
     for wgt in grids:
         for b in range(num_bins):
             img = np.zeros((height, width), np.float32)
-            np.add.at(img, (ys, xs), (wgt * np.maximum(0.0, 1.0 - np.abs(t_norm - b))).astype(np.float32))
+            np.add.at(img, (ys, xs), (wgt * np.maximum(T(0), T(1) - np.abs(t_norm - T(b)))).astype(np.float32))
             out.append(img)
     return np.stack(out)
 

@@ -38,8 +38,8 @@ _PROTOTYPES = {
     "rpe_channel_attention_workspace_floats": [_c_int, _c_int, _c_int, _c_i64],
     "rpe_gdfn_tail": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_ptr, _c_ptr],
     "rpe_convex_upsample": [_c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
-    "rpe_events_to_voxel": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int, _c_int, _c_i64,
-                            _c_ptr, _c_ptr],
+    "rpe_events_to_voxel": [_c_ptr, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_int, ctypes.c_double, ctypes.c_double, _c_int, _c_int,
+                            _c_i64, _c_ptr, _c_ptr],
     "rpe_channel_affine_act": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_int, _c_float, _c_ptr],
     "rpe_channel_affine_add_act": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_i64, _c_int, _c_float, _c_ptr],
     "rpe_residual_tail": [_c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr],
@@ -78,7 +78,7 @@ _PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 6  # RPE_ABI_VERSION of include/rpeflow_hip.h
+ABI_VERSION = 7  # RPE_ABI_VERSION of include/rpeflow_hip.h
 KNN_TIES = {"torch": 3, "set": 1, "index": 0}  # RPE_KNN_TIES_* (how equal distances are resolved)
 KNN_ALGO = {"auto": 0, "sweep": 0x100, "binned": 0x200}  # RPE_KNN_ALGO_* (OR-ed into the mode)
 # entry points only a library built with -DRPE_EXPERIMENTAL has (python -m rpeflow_amd.build --experimental)

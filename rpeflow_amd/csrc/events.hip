@@ -11,48 +11,64 @@
 
 namespace {
 
-// out [C][HW] zero-initialised, C = bins (signed polarity weights) or 2 * bins (positive grids, then negative grids)
-__global__ __launch_bounds__(256) void events_to_voxel_kernel(const int *__restrict__ pixel, const double *__restrict__ t,
+// out [C][HW] zero-initialised, C = bins (signed polarity weights) or 2 * bins (positive grids, then negative grids).
+// T = double: float64 event arrays (the arithmetic numpy / torch do on them).  T = float: the float32 [N,4] arrays
+// load_events_h5 returns (event_utils.py:11-20) -- every step below is then a float32 operation, rounded where numpy and torch
+// round it (the 1e-6 joins deltaT as a float32; 1.0 - |t - bin| and the product with the polarity are float32).
+template <typename T>
+__global__ __launch_bounds__(256) void events_to_voxel_kernel(const int *__restrict__ pixel, const T *__restrict__ t,
                                                               const int *__restrict__ pol, const int *__restrict__ run_start, int runs,
-                                                              int n_events, double t_first, double t_last, int bins, int split, int64_t HW,
+                                                              int n_events, T t_first, T t_last, int bins, int split, int64_t HW,
                                                               float *__restrict__ out) {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= runs) return;
     const int begin = run_start[u], end = u + 1 < runs ? run_start[u + 1] : n_events;
     const int p = pixel[begin];
-    const double span = (t_last - t_first) + 1e-6;                // eventsToXYTP: (t - t0) / (deltaT + 1e-6)
-    const double te_last = (t_last - t_first) / span, te_first = (t_first - t_first) / span;
-    const double dt = te_last - te_first;                           // events_to_voxel_torch: dt = ts[-1] - ts[0]
+    const T span = (t_last - t_first) + (T)1e-6;               // eventsToXYTP: (t - t0) / (deltaT + 1e-6)
+    const T te_last = (t_last - t_first) / span, te_first = (t_first - t_first) / span;
+    const T dt = te_last - te_first;                           // events_to_voxel_torch: dt = ts[-1] - ts[0]
     for (int i = begin; i < end; ++i) {
-        const double te = (t[i] - t_first) / span;
-        const double tn = (te - te_first) / dt * (double)(bins - 1);  // t_norm, left to right as written at :244
+        const T te = (t[i] - t_first) / span;
+        const T tn = (te - te_first) / dt * (T)(bins - 1);     // t_norm, left to right as written at :244
         const int b0 = (int)floor(tn);
         const int sign = pol[i];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int b = b0 + k;
             if (b < 0 || b >= bins) continue;
-            const double w = fmax(0.0, 1.0 - fabs(tn - (double)b));
+            const T d = tn - (T)b;
+            const T w = (T)1 - (d < (T)0 ? -d : d);
+            const T wz = w > (T)0 ? w : (T)0;
             if (split) {  // :296-297: positive grid takes p > 0, negative grid p <= 0, each with weight 1
                 float *o = out + (int64_t)(sign > 0 ? b : bins + b) * HW + p;
-                *o = *o + (float)(1.0 * w);
+                *o = *o + (float)((T)1 * wz);
             } else {
                 float *o = out + (int64_t)b * HW + p;
-                *o = *o + (float)((double)sign * w);
+                *o = *o + (float)((T)sign * wz);
             }
         }
     }
 }
 
-}  // namespace
-
-RPE_API int rpe_events_to_voxel(const int *pixel_sorted, const double *t_sorted, const int *polarity_sorted, const int *run_start,
-                                int runs, int n_events, double t_first, double t_last, int bins, int split_polarity, int64_t HW,
-                                float *out, rpe_stream_t stream) {
+template <typename T>
+int launch_events(const int *pixel_sorted, const T *t_sorted, const int *polarity_sorted, const int *run_start, int runs, int n_events,
+                  T t_first, T t_last, int bins, int split_polarity, int64_t HW, float *out, rpe_stream_t stream) {
     if (!pixel_sorted || !t_sorted || !polarity_sorted || !run_start || !out || runs < 0 || n_events < 0 || bins < 1 || HW < 1)
         return RPE_EINVAL;
     if (runs == 0 || n_events == 0) return 0;
-    hipLaunchKernelGGL(events_to_voxel_kernel, dim3((runs + 255) / 256), dim3(256), 0, (hipStream_t)stream, pixel_sorted, t_sorted,
+    hipLaunchKernelGGL(events_to_voxel_kernel<T>, dim3((runs + 255) / 256), dim3(256), 0, (hipStream_t)stream, pixel_sorted, t_sorted,
                        polarity_sorted, run_start, runs, n_events, t_first, t_last, bins, split_polarity, HW, out);
     return rpe_launch_status();
+}
+
+}  // namespace
+
+RPE_API int rpe_events_to_voxel(const int *pixel_sorted, const void *t_sorted, int t_is_f32, const int *polarity_sorted,
+                                const int *run_start, int runs, int n_events, double t_first, double t_last, int bins,
+                                int split_polarity, int64_t HW, float *out, rpe_stream_t stream) {
+    if (t_is_f32)
+        return launch_events<float>(pixel_sorted, (const float *)t_sorted, polarity_sorted, run_start, runs, n_events, (float)t_first,
+                                    (float)t_last, bins, split_polarity, HW, out, stream);
+    return launch_events<double>(pixel_sorted, (const double *)t_sorted, polarity_sorted, run_start, runs, n_events, t_first, t_last, bins,
+                                 split_polarity, HW, out, stream);
 }

@@ -18,6 +18,13 @@ from pageable memory on the compute stream feeds 4 frame pairs a second.  Here t
 Samples that already lie in pinned memory (``SyntheticPairs(pin=True)``, a registered memory-mapped set) skip stage 1:
 they are copied to the device from where they are.
 
+Raw events.  The reference's dataset voxelises a sample's events on the CPU when no pre-processed file exists
+(flyingthings3d.py:206-208: load_events_h5 -> eventsToVoxel, ~50 ms a sample in numpy/torch against a 15 ms batch).  A
+dataset may return ``events`` [n,4] (x, y, t, polarity; float32 as load_events_h5 yields them, or float64) INSTEAD of
+``event_voxel`` and describe them in ``dataset.event_format`` = dict(bins, polarity, height, width, max_events): the events
+cross PCIe (16 B each instead of 42 MB of grid per sample) and stage 2 voxelises them on the device, on the copy stream,
+bit for bit what eventsToVoxel returns (event_ops.events_to_voxel).  The consumer sees ``event_voxel`` either way.
+
 On a CPU device (the gloo tests) the same code runs without the device ring: stage 1 prefetches, stage 2 passes on.
 Batch order and contents never depend on the number of workers (tests/test_loader.py).
 """
@@ -107,6 +114,7 @@ def _memcpy(dst, src):
 class InputPipeline:
     def __init__(self, dataset, indices, batch_size, device, workers=4, depth=3, processes=False, busy=None):
         self.dataset, self.device = dataset, torch.device(device)
+        self.event_format = getattr(dataset, "event_format", None)  # raw events instead of voxel grids (module docstring)
         self.batches = [list(indices[s:s + batch_size]) for s in range(0, len(indices), batch_size)]  # the last one may be short
         self.batch_size, self.workers, self.depth, self.processes = batch_size, max(1, int(workers)), max(3, int(depth)), processes
         self.cuda = self.device.type == "cuda"
@@ -138,6 +146,24 @@ class InputPipeline:
         first, self._first = self._first, None  # the sample _start() looked at is not loaded twice
         return first[1] if first is not None and first[0] == i else self.dataset[i]
 
+    def _check_events(self, ev):
+        """What eventsToVoxel's index_put_ would refuse, found on the host (the device stage then needs no round trip)."""
+        f = self.event_format
+        if ev.dim() != 2 or ev.shape[1] != 4 or ev.shape[0] > f["max_events"]:
+            raise ValueError("events: expected [n <= %d, 4], got %s" % (f["max_events"], tuple(ev.shape)))
+        if ev.shape[0]:
+            a = ev.numpy()
+            x, y = a[:, 0].astype(np.int32), a[:, 1].astype(np.int32)
+            if int(x.min()) < 0 or int(x.max()) >= f["width"] or int(y.min()) < 0 or int(y.max()) >= f["height"]:
+                raise IndexError("event coordinates outside the sensor")
+
+    def _voxelise(self, dev, s, count, t_range):
+        """Device batch slot s: dev["events"][s][:count] -> dev["event_voxel"][s], on the current (copy) stream."""
+        from .event_ops import events_to_voxel
+        f = self.event_format
+        events_to_voxel(dev["events"][s][:count], num_bins=f["bins"], height=f["height"], width=f["width"], event_polarity=f["polarity"],
+                        out=dev["event_voxel"][s], t_range=t_range, validate=False)
+
     def _worker(self):
         """One task = one SAMPLE of a batch (the first batch is resident after one sample's load time, not four).  Tasks and
         host slots are handed out in batch order under one lock: the copier's next batch can never starve for a slot."""
@@ -155,11 +181,17 @@ class InputPipeline:
                         self._open[j] = {"slot": slot, "left": len(self.batches[j]), "samples": [None] * len(self.batches[j])}
                     rec = self._open[j]
                 sample = self._sample(self.batches[j][n])
+                if "events" in sample:
+                    self._check_events(sample["events"])
                 if rec["slot"] is None:  # pinned samples: copied from where they lie
                     rec["samples"][n] = sample
                 else:
                     for k, v in sample.items():
-                        _memcpy(rec["slot"][k][n], v)
+                        if k == "events":  # ragged: the first count rows of the slot's [max_events, 4]
+                            _memcpy(rec["slot"][k][n][:v.shape[0]], v)
+                            rec["slot"]["event_count"][n] = v.shape[0]
+                        else:
+                            _memcpy(rec["slot"][k][n], v)
                 with self._filled_cv:
                     rec["left"] -= 1
                     if rec["left"] == 0:
@@ -230,11 +262,25 @@ class InputPipeline:
                             self.stats["bytes"] += m * v.element_size()
                     elif kind == "slot":
                         for k, v in src.items():
+                            if k == "events":
+                                continue
                             dev[k][:n].copy_(v[:n], non_blocking=True)
                             self.stats["bytes"] += v[:n].numel() * v.element_size()
+                        if "events" in src:
+                            for s in range(n):
+                                count = int(src["event_count"][s])
+                                ev = src["events"][s][:count]
+                                dev["events"][s][:count].copy_(ev, non_blocking=True)
+                                self.stats["bytes"] += ev.numel() * ev.element_size()
+                                self._voxelise(dev, s, count, (float(ev[0, 2]), float(ev[-1, 2])) if count else None)
                     else:
                         for s, sample in enumerate(src):
                             for k, v in sample.items():
+                                if k == "events":
+                                    dev[k][s][:v.shape[0]].copy_(v, non_blocking=True)
+                                    self.stats["bytes"] += v.numel() * v.element_size()
+                                    self._voxelise(dev, s, v.shape[0], (float(v[0, 2]), float(v[-1, 2])) if v.shape[0] else None)
+                                    continue
                                 if self.copy_fraction < 1:
                                     m = max(1, int(v.numel() * self.copy_fraction))
                                     dev[k][s].view(-1)[:m].copy_(v.view(-1)[:m], non_blocking=True)
@@ -249,7 +295,7 @@ class InputPipeline:
                         self.trace.append((j, begin, done, time.perf_counter()))
                 if kind == "slot":
                     self._free_host.put((src, done))
-                _put(self._ready, ({k: v[:n] for k, v in dev.items()}, done, dev), self._stop)  # dev: handed back with an event
+                _put(self._ready, ({k: v[:n] for k, v in dev.items() if k not in ("events", "event_count")}, done, dev), self._stop)  # dev: handed back with an event
         except _Stop:
             pass
         except BaseException as e:  # noqa: BLE001
@@ -270,8 +316,17 @@ class InputPipeline:
         self._first = (self.batches[0][0], first)
         self._direct = self.cuda and not self.processes and all(v.is_pinned() for v in first.values())
         no_host_ring = self._direct or (self.processes and not self.cuda)
-        self._free_host = queue.Queue() if no_host_ring else self._ring(first, self.depth + self.workers, pin_memory=self.cuda)
-        self._free_dev = self._ring(first, self.depth, device=self.device) if self.cuda else queue.Queue()
+        host_like = dev_like = first
+        if "events" in first:
+            f = self.event_format
+            if f is None or "event_voxel" in first:
+                raise ValueError("a dataset that returns raw `events` describes them in `event_format` and returns no `event_voxel`")
+            if not self.cuda or self.processes:
+                raise RuntimeError("raw events are voxelised on the GPU by the pipeline's copy stage: a CUDA device, loader threads")
+            host_like = dict(first, events=torch.empty((f["max_events"], 4), dtype=first["events"].dtype), event_count=torch.zeros((), dtype=torch.int64))
+            dev_like = dict(host_like, event_voxel=torch.empty(((2 if f["polarity"] else 1) * f["bins"], f["height"], f["width"]), dtype=torch.float32))
+        self._free_host = queue.Queue() if no_host_ring else self._ring(host_like, self.depth + self.workers, pin_memory=self.cuda)
+        self._free_dev = self._ring(dev_like, self.depth, device=self.device) if self.cuda else queue.Queue()
         self._ready = queue.Queue(maxsize=self.depth)
         self._copy_stream = pick_copy_stream(self.device, self.busy) if self.cuda else None
         targets = [self._process_source] if self.processes else [self._worker] * self.workers

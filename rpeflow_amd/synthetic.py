@@ -4,14 +4,25 @@ import numpy as np
 import torch
 
 
-def frame_pair(seed, H=544, W=960, N=8192, f=1050.0, dsec=False):
+def raw_events(seed, n, H, W):
+    """[n', 4] float32 (x, y, t, polarity) in time order, n' a little below n and different per seed -- the array
+    load_events_h5 builds from an event file (event_utils.py:11-20): microsecond timestamps, polarity 0 / 1."""
+    r = np.random.default_rng(seed + 0x5EED)
+    n = n - int(seed * 7919 % (n // 8 + 1))
+    t = np.sort(r.integers(1_000_000, 1_050_000, n))
+    return np.stack([r.integers(0, W, n), r.integers(0, H, n), t, r.integers(0, 2, n)], axis=1).astype(np.float32)
+
+
+def frame_pair(seed, H=544, W=960, N=8192, f=1050.0, dsec=False, events=0):
     """One sample with the keys the reference datasets return (flyingthings3d.py:228-234): uint8 RGB
     pair, 20-channel event voxel, two back-projected clouds (pc2 = pc1 + N(0,0.05^2)), targets.
-    ``dsec``: flow_3d carries a 4th mask channel and there is no occ_mask_3d (dsec.py:762,777-784)."""
+    ``dsec``: flow_3d carries a 4th mask channel and there is no occ_mask_3d (dsec.py:762,777-784).
+    ``events`` > 0: up to that many raw events (``events`` [n,4], see raw_events) instead of the finished voxel grid --
+    the dataset's path without a pre-processed file (flyingthings3d.py:206-208); the input pipeline voxelises them."""
     r = np.random.default_rng(seed)
     cx, cy = (W - 1) / 2.0, (H - 1) / 2.0
     images = r.integers(0, 256, (6, H, W), dtype=np.uint8)
-    event_voxel = r.standard_normal((20, H, W), dtype=np.float32)
+    event_voxel = r.standard_normal((20, H, W), dtype=np.float32) if not events else None
     z = r.uniform(2.0, 35.0, N)
     u = r.uniform(0.0, W - 1.0, N)
     v = r.uniform(0.0, H - 1.0, N)
@@ -26,6 +37,9 @@ def frame_pair(seed, H=544, W=960, N=8192, f=1050.0, dsec=False):
         sample["flow_3d"] = np.concatenate([flow_3d, (r.random((1, N)) < 0.9).astype(np.float32)])
     else:
         sample["occ_mask_3d"] = occ
+    if events:
+        del sample["event_voxel"]
+        sample["events"] = raw_events(seed, events, H, W)
     return sample
 
 
@@ -36,8 +50,10 @@ class SyntheticPairs(torch.utils.data.Dataset):
     dataset on disk), optionally in pinned memory (``pin=True``), from where the input pipeline copies it to the device
     without a staging pass.  ``prepare()`` fills the cache with a thread pool (numpy's generators release the GIL)."""
 
-    def __init__(self, n_samples, H=544, W=960, N=8192, dsec=False, distinct=None, cache=False, pin=False, first_seed=1000):
-        self.n, self.kw = n_samples, dict(H=H, W=W, N=N, dsec=dsec)
+    def __init__(self, n_samples, H=544, W=960, N=8192, dsec=False, distinct=None, cache=False, pin=False, first_seed=1000, events=0):
+        self.n, self.kw = n_samples, dict(H=H, W=W, N=N, dsec=dsec, events=events)
+        if events:  # raw events, voxelised by the input pipeline: 10 bins x 2 polarities = the model's 20 event channels
+            self.event_format = dict(bins=10, polarity=True, height=H, width=W, max_events=events)
         self.distinct = n_samples if distinct is None else max(1, min(distinct, n_samples))
         self.first_seed, self.pin = first_seed, pin
         self.cache = {} if (cache or pin) else None

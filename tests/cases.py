@@ -169,6 +169,9 @@ EVENT_CASES = {
     "events_5000_24x40_b5": (5000, 24, 40, 5, False, 601),
     "events_20000_36x60_b10_pol": (20000, 36, 60, 10, True, 602),
     "events_300_9x15_b1_pol": (300, 9, 15, 1, True, 603),
+    # float32 [N,4] arrays, as load_events_h5 hands them to the datasets (event_utils.py:11-20): float32 arithmetic throughout
+    "events_f32_20000_36x60_b10_pol": (20000, 36, 60, 10, True, 604),
+    "events_f32_5000_24x40_b5": (5000, 24, 40, 5, False, 605),
 }
 
 
@@ -179,6 +182,8 @@ def event_inputs(name):
     t = np.sort(r.integers(1_000_000, 1_050_000, n)).astype(np.float64)
     ev = np.stack([r.integers(0, W, n).astype(np.float64), r.integers(0, H, n).astype(np.float64), t,
                    r.integers(0, 2, n).astype(np.float64)], axis=1)
+    if name.startswith("events_f32"):
+        ev = ev.astype(np.float32)  # (timestamps of 1.0e6 .. 1.05e6 us: exact in float32)
     return ev, H, W, bins, pol
 
 

@@ -119,3 +119,50 @@ def test_device_ring_delivers_the_samples(pin):
         (batch["event_voxel"] * 2).sum()  # consumer work on the compute stream before the slot goes back
         n += 1
     assert n == 12 and pipe.stats["batches"] == 12 and (pipe.stats["direct"] == 12) == pin
+
+
+def test_raw_events_need_the_device_stage():
+    """A dataset that returns raw events (flyingthings3d.py:206-208 without a pre-processed file) is voxelised by the pipeline's
+    copy stage on the GPU; there is no CPU voxelisation in the product, so a CPU consumer is refused -- loudly."""
+    data = SyntheticPairs(4, H=32, W=48, N=64, events=2000)
+    assert "events" in data[0] and "event_voxel" not in data[0] and data[0]["events"].dtype == torch.float32
+    assert data[0]["events"].shape[0] != data[1]["events"].shape[0] <= 2000  # ragged
+    with pytest.raises(RuntimeError, match="voxelised on the GPU"):
+        list(InputPipeline(data, [0, 1, 2, 3], 2, "cpu", workers=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pin", [False, True])
+def test_raw_events_are_voxelised_on_the_device_bit_for_bit(pin):
+    """events [n,4] float32 per sample (ragged) -> pinned ring -> device -> event_ops.events_to_voxel on the copy stream: the
+    consumer's event_voxel equals eventsToVoxel(events, 10 bins, polarity split) -- the CPU restatement pinned to the reference's
+    float32 goldens -- for every sample, short last batch included, with and without the staging ring."""
+    from oracle import oracle as O
+    H, W = 40, 56
+    data = SyntheticPairs(11, H=H, W=W, N=256, cache=True, pin=pin, events=6000)
+    pipe = InputPipeline(data, list(range(11)), 3, "cuda:0", workers=2)
+    n = 0
+    for batch, upcoming in pipe.pairs():
+        ids = list(range(3 * n, min(3 * n + 3, 11)))
+        assert "events" not in batch and batch["event_voxel"].shape == (len(ids), 20, H, W) and batch["event_voxel"].device.type == "cuda"
+        got = batch["event_voxel"].cpu().numpy()
+        for s, i in enumerate(ids):
+            want = O.events_to_voxel(data[i]["events"].numpy(), 10, H, W, True)
+            assert np.array_equal(got[s].view(np.uint32), want.view(np.uint32)), (n, s)
+            assert torch.equal(batch["pcs"][s].cpu(), data[i]["pcs"])
+        n += 1
+    assert n == 4 and (pipe.stats["direct"] == 4) == pin
+
+
+@pytest.mark.gpu
+def test_raw_events_outside_the_sensor_surface_in_the_consumer():
+    class Bad(SyntheticPairs):
+        def __getitem__(self, i):
+            s = dict(super().__getitem__(i))
+            if i == 2:
+                s["events"] = s["events"].clone()
+                s["events"][5, 0] = 9999.0
+            return s
+    with pytest.raises(RuntimeError) as err:
+        list(InputPipeline(Bad(4, H=32, W=48, N=64, events=500), [0, 1, 2, 3], 2, "cuda:0", workers=1))
+    assert isinstance(err.value.__cause__, IndexError)
