@@ -301,6 +301,7 @@ def main():
     p.add_argument("--width", type=int, default=960)
     p.add_argument("--points", type=int, default=8192)
     p.add_argument("--dsec", action="store_true")
+    p.add_argument("--raw-events", type=int, default=0, help="samples carry up to this many raw events each instead of voxel grids (voxelised on the device)")
     p.add_argument("--weights", default=None, help="reference checkpoint ({'state_dict': ...}); default: seeded random init")
     p.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     args = p.parse_args()
@@ -320,7 +321,7 @@ def main():
     if args.weights:
         model.load_state_dict(torch.load(args.weights, map_location=device)["state_dict"], strict=True)
     from .synthetic import SyntheticPairs
-    data = SyntheticPairs(args.samples, args.height, args.width, args.points, dsec=args.dsec)
+    data = SyntheticPairs(args.samples, args.height, args.width, args.points, dsec=args.dsec, events=args.raw_events)
     t0 = time.perf_counter()
     metrics, _ = evaluate(model, data, args.batch, device, rank, world, graph=False if args.eager else None)
     torch.cuda.synchronize()
