@@ -167,6 +167,34 @@ def test_graph_replayed_evaluation_matches_eager():
 
 
 @pytest.mark.gpu
+def test_evaluation_from_raw_events_equals_evaluation_from_their_voxel_grids():
+    """A set that hands out raw events (flyingthings3d.py:206-208 without a pre-processed file; voxelised by the pipeline's copy
+    stage) against the same set with the grids made beforehand by event_ops.events_to_voxel: the same metrics, sum for sum."""
+    from rpeflow_amd.event_ops import events_to_voxel
+    from rpeflow_amd.model import RPEFlow
+
+    class Voxelised(torch.utils.data.Dataset):
+        def __init__(self, raw):
+            self.raw, self.f = raw, raw.event_format
+
+        def __len__(self):
+            return len(self.raw)
+
+        def __getitem__(self, i):
+            s = dict(self.raw[i])
+            ev = s.pop("events")
+            s["event_voxel"] = events_to_voxel(ev.to("cuda:0"), self.f["bins"], self.f["height"], self.f["width"], self.f["polarity"]).cpu()
+            return s
+
+    torch.manual_seed(0)
+    model = RPEFlow().to("cuda:0").eval()
+    raw = SyntheticPairs(5, H=128, W=192, N=8192, events=40000, cache=True)
+    from_events, acc_a = E.evaluate(model, raw, batch_size=2, device="cuda:0", graph=False)
+    from_grids, acc_b = E.evaluate(model, Voxelised(raw), batch_size=2, device="cuda:0", graph=False, workers=1)
+    assert from_events["counts"] == from_grids["counts"] and np.array_equal(acc_a.cpu().numpy(), acc_b.cpu().numpy())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dsec,B,H,W,N", [(False, 3, 24, 40, 517), (True, 2, 31, 33, 1000), (False, 4, 544, 960, 8192), (True, 3, 480, 640, 8192)])
 def test_device_accumulate_kernel_equals_the_tensor_form(dsec, B, H, W, N):
     """rpe_eval_accumulate (csrc/eval.hip) against the host-side tensor statement of eval_withocc.py:65-108 on the same
