@@ -637,6 +637,17 @@ class RPEFlow_core(nn.Module):
                 fused[level] = fuse_level(level)
         return fused, ready
 
+    def _up_mask(self, feat):
+        """up_mask_head_2d (RPEFlow_core.py:208-211, 424): 3x3 convolution -> ReLU -> 1x1.  On the GPU the 3x3's bias and the ReLU are
+        ONE in-place pass over the raw convolution output (the library adds the bias in a pass of its own and the ReLU is another:
+        86 -> 45 us over [4,256,136,240] at the very end of the chain).  (Applied by the 1x1 kernel as it reads its input instead,
+        the two passes disappear and that kernel goes from 147 to 201 us: its loop has no room for 64 more vector instructions.)"""
+        head = self.up_mask_head_2d
+        from .utils import _inference_only, conv_no_bias_or
+        if feat.is_cuda and _inference_only(feat, *head.parameters()) and isinstance(head[1], nn.ReLU):
+            return conv_module(head[2], conv_no_bias_or(head[0], feat, False, epilogue=(None, head[0].bias, "relu")))
+        return conv_module(head[2], head[1](conv_module(head[0], feat)))
+
     def decode(self, xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d, camera_info, side_stream=None, pre_stream=None,
                all_levels=False, hoisted_early=None):
         """RPEFlow_core.py:302-432 without the MI loss bookkeeping.
@@ -782,8 +793,7 @@ class RPEFlow_core(nn.Module):
             hoisted = nxt
 
         flows_2d = [f.float() for f in flows_2d][::-1]
-        mask = self.up_mask_head_2d[1](conv_module(self.up_mask_head_2d[0], flow_feats_2d[-1]))
-        flows_2d[0] = convex_upsample(flows_2d[0], conv_module(self.up_mask_head_2d[2], mask), scale_factor=4)
+        flows_2d[0] = convex_upsample(flows_2d[0], self._up_mask(flow_feats_2d[-1]), scale_factor=4)
         br.join(list(out_s1) + flows_3d + flow_feats_3d)
         flows_3d = [f.float() for f in flows_3d][::-1]
         flows_3d_up = [out_s1[0]]
