@@ -11,6 +11,7 @@ export TMPDIR=/tmp
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python3 bench.py --workload eval --steps 128 --no-cpu-baseline --no-corr-microbench > $OUT/bench_eval.json 2> $OUT/bench_eval.err
 python3 bench.py --config dsec > $OUT/bench_dsec.json 2> $OUT/bench_dsec.err
+python3 bench.py --workload eval --steps 128 --no-cpu-baseline --no-corr-microbench --eval-raw-events 300000 > $OUT/bench_eval_raw_events.json 2> $OUT/bench_eval_raw_events.err
 cd /tmp
 # 1. the default bench command, kernel stats
 rm -rf /tmp/p1; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --eval-batches 0 --backend none > $OUT/bench_under_rocprof.json 2> /tmp/p1.err

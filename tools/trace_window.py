@@ -19,7 +19,7 @@ for r in win:
 tot = sum(a[0] for a in agg.values())
 span = int(rows[hi]["Start_Timestamp"]) - int(rows[lo]["End_Timestamp"])
 print(f"window: {len(win)} kernels, kernel time {tot / 1e6 / steps:.3f} ms/step, wall {span / 1e6 / steps:.3f} ms/step, {len(win) / steps:.0f} launches/step")
-for name, (d, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:45]:
+for name, (d, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(__import__("os").environ.get("TRACE_TOP", 45))]:
     print(f"{d / 1e6 / steps:8.3f} ms/step {n / steps:7.1f}/step {d / n / 1e3:9.1f} us  {name[:120]}")
 
 if len(sys.argv) > 3:  # per-launch dump of the last step in the window: start offset, duration, queue, grid, name
