@@ -224,7 +224,11 @@ class HotPathWorkload(torch.nn.Module):
             with t.span("correlation3d"):
                 corr_3d = self.correlations_3d[level](xyz1, f1_3d, xyz2_warp, f2_3d, knn_1in1)
             with t.span("correlation2d"):
-                corr_2d = torch.nn.functional.leaky_relu(correlation2d(f1_2d, f2_2d_warp, 4), 0.1)
+                if shares:  # the native operators: the activation of RPEFlow_core.py:362 in the kernel's epilogue, as rpeflow_amd.model calls it
+                    from .csrc.wrapper import _correlation2d_algo
+                    corr_2d = _correlation2d_algo(f1_2d, f2_2d_warp, 4, 0, leaky_slope=0.1)
+                else:
+                    corr_2d = torch.nn.functional.leaky_relu(correlation2d(f1_2d, f2_2d_warp, 4), 0.1)
 
             with t.span("grid_sample"):  # corr fuser 3D (:376; utils via RPEFlow_core.py:107-108)
                 sampled = grid_sample_wrapper(torch.cat([corr_2d, self.flow_2d[level]], 1), xy1)
