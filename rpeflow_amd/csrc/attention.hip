@@ -40,66 +40,86 @@ __device__ __forceinline__ float4 load_row4(const float *__restrict__ base, int 
     return v;
 }
 
-// grid (chunks * T, heads, B), 256 threads; T = ceil(c / 16).  Workgroup (s, ti) owns rows 16 ti .. 16 ti + 15 of the
-// gram for positions [s * chunk, (s + 1) * chunk): one q tile row against all T k tiles (k is re-read T times, from L2).
-template <int T, bool VEC>
+// grid (chunks * ceil(T / R), heads, B), 256 threads; T = ceil(c / 16).  Workgroup (s, tg) owns R tile rows (16 R rows) of the
+// gram for positions [s * chunk, (s + 1) * chunk): R q tile rows against all T k tiles (k is re-read ceil(T / R) times, from L2).
+template <int T, int R, bool VEC>
 __global__ __launch_bounds__(256) void attn_gram_kernel(const float *__restrict__ q, const float *__restrict__ k, int64_t batch_stride,
                                                         int heads, int c, int64_t P, float *__restrict__ gpart,
                                                         float *__restrict__ npart) {
-    __shared__ float tiles[T * 256];  // [T][64][4] accumulator tiles
-    __shared__ float norms[(T + 1) * 16];
+    constexpr int TG = (T + R - 1) / R;  // workgroups per chunk: each owns R of the T tile rows (k is read TG times)
+    __shared__ float tiles[R * T * 256];  // [R][T][64][4] accumulator tiles
+    __shared__ float norms[(T + R) * 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int s = blockIdx.x / T, ti = blockIdx.x - s * T, h = blockIdx.y, b = blockIdx.z, S = gridDim.x / T;
+    const int s = blockIdx.x / TG, tg = blockIdx.x - s * TG, h = blockIdx.y, b = blockIdx.z, S = gridDim.x / TG;
+    const int ti0 = tg * R;
     const int row = lane & 15, grp = lane >> 4;
     const float *qh = q + (int64_t)b * batch_stride + (int64_t)h * c * P;
     const float *kh = k + (int64_t)b * batch_stride + (int64_t)h * c * P;
     const int chunk = attn_chunk(P);
     const int64_t p0 = (int64_t)s * chunk;
     const int64_t pend = p0 + chunk < P ? p0 + chunk : P;
-    const bool k_norms = ti == 0;  // the k norms are the same in every tile row: the first one writes them
+    const bool k_norms = tg == 0;  // the k norms are the same in every group of tile rows: the first one writes them
 
-    f32x4 acc[T];
-    float sq = 0.f, sk[T];
+    f32x4 acc[R][T];
+    float sq[R], sk[T];
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
-        sk[j] = 0.f;
-        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < T; ++j) sk[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        sq[r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[r][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    auto accumulate = [&](const float4 &a, const float4 (&bb)[T]) {
-        sq += (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w);
+    auto accumulate = [&](const float4 (&a)[R], const float4 (&bb)[T]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) sq[r] += (a[r].x * a[r].x + a[r].y * a[r].y) + (a[r].z * a[r].z + a[r].w * a[r].w);
         if (k_norms) {
 #pragma unroll
             for (int t = 0; t < T; ++t) sk[t] += (bb[t].x * bb[t].x + bb[t].y * bb[t].y) + (bb[t].z * bb[t].z + bb[t].w * bb[t].w);
         }
         // position phase outermost: consecutive MFMAs write different accumulators (40-cycle dependent latency)
 #pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb[j].x, acc[j], 0, 0, 0);
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb[j].y, acc[j], 0, 0, 0);
+            for (int j = 0; j < T; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].x, bb[j].x, acc[r][j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb[j].z, acc[j], 0, 0, 0);
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb[j].w, acc[j], 0, 0, 0);
+            for (int j = 0; j < T; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].y, bb[j].y, acc[r][j], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].z, bb[j].z, acc[r][j], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r].w, bb[j].w, acc[r][j], 0, 0, 0);
     };
     int64_t gs = p0 + wave * 16;  // wave-uniform trip counts below: every lane joins the MFMAs
     if (VEC) {
         // Full 16-position groups, no guards: a row beyond the head's channels reads the last valid row instead (its gram
         // rows / columns and norms are never stored); the next group's loads are issued before this group's MFMAs.
-        const float *qrow = qh + (int64_t)min(ti * 16 + row, c - 1) * P + grp * 4;
+        const float *qrow[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) qrow[r] = qh + (int64_t)min((ti0 + r) * 16 + row, c - 1) * P + grp * 4;
         const float *krow[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) krow[t] = kh + (int64_t)min(t * 16 + row, c - 1) * P + grp * 4;
         if (gs + 16 <= pend) {
-            float4 a = *reinterpret_cast<const float4 *>(qrow + gs), bb[T];
+            float4 a[R], bb[T];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] = *reinterpret_cast<const float4 *>(qrow[r] + gs);
 #pragma unroll
             for (int t = 0; t < T; ++t) bb[t] = *reinterpret_cast<const float4 *>(krow[t] + gs);
             for (; gs + 64 + 16 <= pend; gs += 64) {
-                const float4 na = *reinterpret_cast<const float4 *>(qrow + gs + 64);
-                float4 nb[T];
+                float4 na[R], nb[T];
+#pragma unroll
+                for (int r = 0; r < R; ++r) na[r] = *reinterpret_cast<const float4 *>(qrow[r] + gs + 64);
 #pragma unroll
                 for (int t = 0; t < T; ++t) nb[t] = *reinterpret_cast<const float4 *>(krow[t] + gs + 64);
                 accumulate(a, bb);
-                a = na;
+#pragma unroll
+                for (int r = 0; r < R; ++r) a[r] = na[r];
 #pragma unroll
                 for (int t = 0; t < T; ++t) bb[t] = nb[t];
             }
@@ -109,15 +129,19 @@ __global__ __launch_bounds__(256) void attn_gram_kernel(const float *__restrict_
     }
     for (; gs < pend; gs += 64) {  // the chunk's ragged end (and everything when rows are not 16-byte aligned)
         const int64_t p = gs + grp * 4;
-        const float4 a = load_row4<VEC>(qh, ti * 16 + row, c, P, p, pend);
-        float4 bb[T];
+        float4 a[R], bb[T];
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = load_row4<VEC>(qh, (ti0 + r) * 16 + row, c, P, p, pend);
 #pragma unroll
         for (int t = 0; t < T; ++t) bb[t] = load_row4<VEC>(kh, t * 16 + row, c, P, p, pend);
         accumulate(a, bb);
     }
     // norms: add the four position groups of the wave (lanes l, l^16, l^32, l^48 share a row)
-    sq += __shfl_xor(sq, 16);
-    sq += __shfl_xor(sq, 32);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        sq[r] += __shfl_xor(sq[r], 16);
+        sq[r] += __shfl_xor(sq[r], 32);
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         sk[t] += __shfl_xor(sk[t], 16);
@@ -126,30 +150,33 @@ __global__ __launch_bounds__(256) void attn_gram_kernel(const float *__restrict_
     for (int w = 0; w < 4; ++w) {  // waves add into LDS one after the other (fixed order)
         if (wave == w) {
 #pragma unroll
-            for (int j = 0; j < T; ++j) {
-                f32x4 *slot = reinterpret_cast<f32x4 *>(tiles + (j * 64 + lane) * 4);
-                *slot = w == 0 ? acc[j] : *slot + acc[j];
-            }
-            if (grp == 0) {
-                norms[row] = w == 0 ? sq : norms[row] + sq;
+            for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int t = 0; t < T; ++t) norms[(1 + t) * 16 + row] = w == 0 ? sk[t] : norms[(1 + t) * 16 + row] + sk[t];
+                for (int j = 0; j < T; ++j) {
+                    f32x4 *slot = reinterpret_cast<f32x4 *>(tiles + ((r * T + j) * 64 + lane) * 4);
+                    *slot = w == 0 ? acc[r][j] : *slot + acc[r][j];
+                }
+            if (grp == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) norms[r * 16 + row] = w == 0 ? sq[r] : norms[r * 16 + row] + sq[r];
+#pragma unroll
+                for (int t = 0; t < T; ++t) norms[(R + t) * 16 + row] = w == 0 ? sk[t] : norms[(R + t) * 16 + row] + sk[t];
             }
         }
         __syncthreads();
     }
     // partial gram [b][h][s][c][c]; tile element (j-tile, lane, reg): row 16 ti + 4 (lane >> 4) + reg, col 16 jt + (lane & 15)
     float *gp = gpart + (((int64_t)b * heads + h) * S + s) * c * c;
-    const int rows = min(16, c - ti * 16);
+    const int rows = max(0, min(16 * R, c - ti0 * 16));  // rows of this group inside the head
     for (int o = threadIdx.x; o < rows * c; o += 256) {
-        const int ir = o / c, j = o - ir * c, jt = j >> 4, jc = j & 15;
-        gp[(ti * 16 + ir) * c + j] = tiles[(jt * 64 + ((ir >> 2) << 4) + jc) * 4 + (ir & 3)];
+        const int ig = o / c, j = o - ig * c, jt = j >> 4, jc = j & 15, r = ig >> 4, ir = ig & 15;
+        gp[(ti0 * 16 + ig) * c + j] = tiles[((r * T + jt) * 64 + ((ir >> 2) << 4) + jc) * 4 + (ir & 3)];
     }
     // partial squared norms [b][s][2][heads*c]
     float *np = npart + ((int64_t)b * S + s) * 2 * heads * c + h * c;
-    if (threadIdx.x < rows) np[ti * 16 + threadIdx.x] = norms[threadIdx.x];
+    if ((int)threadIdx.x < rows) np[ti0 * 16 + threadIdx.x] = norms[threadIdx.x];
     if (k_norms)
-        for (int i = threadIdx.x; i < c; i += 256) np[heads * c + i] = norms[16 + i];
+        for (int i = threadIdx.x; i < c; i += 256) np[heads * c + i] = norms[R * 16 + i];
 }
 
 // One wave per attention row (b, h, i): sums the partials in a fixed order, scales by the norms and the temperature,
@@ -260,9 +287,19 @@ __global__ __launch_bounds__(256) void attn_project_kernel(const float *__restri
 template <int T>
 int launch_gram(bool vec, dim3 grid, hipStream_t st, const float *q, const float *k, int64_t batch_stride, int heads, int c, int64_t P,
                 float *gpart, float *npart) {
+    // big maps: a workgroup owns R tile rows of the gram, so that k is read ceil(T / R) times instead of T times (level 1,
+    // with the softmax / project launches: c = 48: 49.5 -> 41.9 us; c = 81: 69.3 -> 59.1; c = 32: 35.4 -> 29.1; three rows of
+    // six, or 1024-position chunks, were no better: 68 us)
+    constexpr int R = T <= 3 ? T : 2;
+    if (R > 1 && P > 16384) {
+        grid.x *= (T + R - 1) / R;
+        if (vec) hipLaunchKernelGGL((attn_gram_kernel<T, R, true>), grid, dim3(256), 0, st, q, k, batch_stride, heads, c, P, gpart, npart);
+        else hipLaunchKernelGGL((attn_gram_kernel<T, R, false>), grid, dim3(256), 0, st, q, k, batch_stride, heads, c, P, gpart, npart);
+        return rpe_launch_status();
+    }
     grid.x *= T;
-    if (vec) hipLaunchKernelGGL((attn_gram_kernel<T, true>), grid, dim3(256), 0, st, q, k, batch_stride, heads, c, P, gpart, npart);
-    else hipLaunchKernelGGL((attn_gram_kernel<T, false>), grid, dim3(256), 0, st, q, k, batch_stride, heads, c, P, gpart, npart);
+    if (vec) hipLaunchKernelGGL((attn_gram_kernel<T, 1, true>), grid, dim3(256), 0, st, q, k, batch_stride, heads, c, P, gpart, npart);
+    else hipLaunchKernelGGL((attn_gram_kernel<T, 1, false>), grid, dim3(256), 0, st, q, k, batch_stride, heads, c, P, gpart, npart);
     return rpe_launch_status();
 }
 
