@@ -92,48 +92,7 @@ def parse():
 
 
 NOMINAL_SCLK_MHZ = 2400.0   # MI355X_MICROARCH.md: peak engine clock
-HBM_COPY_GBS = 6290.0       # MI355X_MICROARCH.md: what a device-to-device copy reaches of the 8 TB/s
-
-
-class ClockSampler:
-    """Shader clock while a kernel loop runs: amdgpu's hwmon freq1_input, else one `rocm-smi --showclocks --json` call (0.3-1 s:
-    the loop it samples has to run that long).  None where neither can be read (a container without the sysfs node or the tool)."""
-
-    def __init__(self):
-        import glob
-        self.path = next((c for c in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")) if os.access(c, os.R_OK)), None)
-        self.samples, self.thread, self.stop = [], None, False
-
-    def _run(self):
-        import subprocess
-        while not self.stop:
-            mhz = None
-            try:
-                if self.path:
-                    mhz = float(open(self.path).read()) / 1e6
-                    time.sleep(0.01)
-                else:
-                    out = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
-                    for k, v in next(iter(json.loads(out).values())).items():
-                        if k.startswith("sclk clock speed"):
-                            mhz = float(str(v).strip("()").lower().replace("mhz", ""))
-            except Exception:  # noqa: BLE001 -- no clock reading on this machine
-                return
-            if mhz:
-                self.samples.append(mhz)
-
-    def __enter__(self):
-        import threading
-        self.thread = threading.Thread(target=self._run, daemon=True)
-        self.thread.start()
-        return self
-
-    def __exit__(self, *exc):
-        self.stop = True
-        self.thread.join(timeout=6)
-
-    def mean(self):
-        return round(sum(self.samples) / len(self.samples), 1) if self.samples else None
+HBM_COPY_GBS = 6290.0       # MI355X_MICROARCH.md: what a device-to-device copy reaches of the 8 TB/s (the guide's figure; the run measures its own beside it)
 
 
 def pmc_traffic(suffix):
@@ -145,12 +104,17 @@ def pmc_traffic(suffix):
     return None, None
 
 
-def clocked(frac, clock):
-    """Extra fields of a roofline object: the shader clock read while the loop ran (mean, range and count of the readings: under
-    the power cap the firmware moves between levels and a reading is one instant) and the fraction scaled to the nominal clock."""
-    sclk = clock.mean()
-    return {"sclk_MHz": sclk, "sclk_MHz_range": [min(clock.samples), max(clock.samples)] if clock.samples else None,
-            "sclk_readings": len(clock.samples), "frac_at_nominal_clock": round(frac * NOMINAL_SCLK_MHZ / sclk, 4) if sclk else None}
+def clocked(frac, clock, dev):
+    """Extra fields of a roofline object: the clock the shader engines ran at DURING the timed launches -- two clock stamps on the
+    stream around them (rpeflow_amd.runtime.ShaderClock: d s_memtime / d s_memrealtime), else the hwmon reading of this very
+    device, else null -- and the fraction scaled to the nominal clock, null unless the clock is plausible and the result <= 1."""
+    sclk, source = clock.mhz(), "clock stamps around the timed launches (d s_memtime / d s_memrealtime x the constant rate)"
+    if sclk is None:
+        sclk, source = runtime.hwmon_sclk_mhz(dev), "hwmon sclk of this device, one reading after the loop"
+    at_nominal = round(frac * NOMINAL_SCLK_MHZ / sclk, 4) if sclk else None
+    cycles, ticks, khz = clock.raw()
+    return {"sclk_MHz": sclk, "sclk_source": source if sclk else None, "sclk_stamp_raw": {"shader_cycles": cycles, "wall_ticks": ticks, "wall_kHz": khz},
+            "frac_at_nominal_clock": at_nominal if (at_nominal is not None and at_nominal <= 1.0) else None}
 
 
 def corr_microbench(dev, iters=40):
@@ -162,25 +126,28 @@ def corr_microbench(dev, iters=40):
         ops.correlation2d(a, b, 4)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    clock = runtime.ShaderClock(dev)
     s.record()
-    for _ in range(iters):
-        ops.correlation2d(a, b, 4)
+    with clock:  # the clock stamps sit inside the event pair, around the very launches that are timed
+        for _ in range(iters):
+            ops.correlation2d(a, b, 4)
     e.record()
     torch.cuda.synchronize()
-    us = s.elapsed_time(e) / iters * 1e3
-    with ClockSampler() as clock:  # the same loop again, long enough for a clock reading (untimed)
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < (0.25 if clock.path else 2.5):
-            for _ in range(20):
-                ops.correlation2d(a, b, 4)
-            torch.cuda.synchronize()
+    us = s.elapsed_time(e) / iters * 1e3  # (the two one-wave stamp kernels inside the pair: ~4 us over >= 5 ms of launches)
     alg = 2 * a.numel() * 4 + 81 * H * W * 4  # 1 238 753 280 B
     gbs = alg / us / 1e3
+    s.record()  # what a plain device-to-device copy of one operand reaches on THIS box right now (read + write bytes)
+    for _ in range(10):
+        b.copy_(a)
+    e.record()
+    torch.cuda.synchronize()
+    copy_gbs = 2 * a.numel() * 4 / (s.elapsed_time(e) / 10) / 1e6
     traffic, source = pmc_traffic("corr_microbench_pmc.json")
     frac = gbs / HBM_PEAK_GBS
     return {"kernel": "corr_mfma_dma_kernel<2,8,2,3,3,true>", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(frac, 4), "traffic": traffic, "traffic_source": source, "us_per_launch": round(us, 1),
-            **clocked(frac, clock), "frac_of_measured_copy_bw": round(gbs / HBM_COPY_GBS, 4),
+            **clocked(frac, clock, dev), "copy_GBs_measured": round(copy_gbs, 1), "frac_of_measured_copy_bw": round(gbs / copy_gbs, 4),
+            "frac_of_guide_copy_bw": round(gbs / HBM_COPY_GBS, 4),
             "algorithmic_bytes": alg, "workload": "correlation2d 1x256x544x960 md=4 fp32 NCHW (BASELINE config 2)"}
 
 
@@ -196,18 +163,14 @@ def knn_microbench(dev, iters=30):
         ops.k_nearest_neighbor(cloud, query, k)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    clock = runtime.ShaderClock(dev)
     s.record()
-    for _ in range(iters):
-        ops.k_nearest_neighbor(cloud, query, k)
+    with clock:
+        for _ in range(iters):
+            ops.k_nearest_neighbor(cloud, query, k)
     e.record()
     torch.cuda.synchronize()
-    us = s.elapsed_time(e) / iters * 1e3
-    with ClockSampler() as clock:
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < (0.25 if clock.path else 2.5):
-            for _ in range(20):
-                ops.k_nearest_neighbor(cloud, query, k)
-            torch.cuda.synchronize()
+    us = s.elapsed_time(e) / iters * 1e3  # (the two one-wave stamp kernels inside the pair: ~4 us over >= 5 ms of launches)
     from rpeflow_amd.csrc.wrapper import k_nearest_neighbor_ties
     for _ in range(5):
         k_nearest_neighbor_ties(cloud, query, k, ties="index")
@@ -226,7 +189,7 @@ def knn_microbench(dev, iters=30):
     frac = tflops / MFMA_F32_PEAK_TFLOPS
     return {"kernel": "knn_mfma_kernel<3, true> + knn_tie_replay_kernel<3> (the sweep, then its tied rows redone the libstdc++ way by a second launch)",
             "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(frac, 4),
-            "traffic": traffic, "traffic_source": source, **clocked(frac, clock),
+            "traffic": traffic, "traffic_source": source, **clocked(frac, clock, dev),
             "us_per_launch": round(us, 1), "launches": 2, "pairs_per_s": round(pairs / us * 1e6), "algorithmic_bytes": 4 * B * D * (M + Q) + 8 * B * Q * k,
             "us_per_launch_lowest_index_ties": round(us_index, 1),  # the same search without the libstdc++ restatement of equal distances
             "frac_lowest_index_ties": round(pairs * (2 * D + 3) / us_index / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
@@ -322,13 +285,14 @@ def eval_leg(model, forward, dev, cfg, batch_size, n_batches, rank, world, dist,
     t_gen = data.prepare(indices=mine)
     warm = SyntheticPairs(world * 3 * batch_size, cfg["H"], cfg["W"], NPTS, dsec=cfg["dsec"], distinct=distinct, first_seed=cfg["first_seed"], events=raw_events)
     warm.cache, warm.pin = data.cache, pinned  # same samples: the loader threads, the rings and the graph get their first use untimed
-    E.evaluate(model, warm, batch_size, dev, rank, world, forward=forward, workers=workers)
+    group = dist.group.WORLD if dist is not None else None  # explicit: evaluate() joins a collective only on its caller's say-so
+    E.evaluate(model, warm, batch_size, dev, rank, world, group=group, forward=forward, workers=workers)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     stats = {"timeline": bool(os.environ.get("RPE_EVAL_TIMELINE"))}  # diagnostic: per-batch device times (adds 3 event records a batch)
     t0 = time.perf_counter()
-    metrics, _ = E.evaluate(model, data, batch_size, dev, rank, world, forward=forward, workers=workers, stats=stats)  # ends on the host: finalize() reads the sums
+    metrics, _ = E.evaluate(model, data, batch_size, dev, rank, world, group=group, forward=forward, workers=workers, stats=stats)  # ends on the host: finalize() reads the sums
     mine_dt = time.perf_counter() - t0
     torch.cuda.synchronize()
     dts = [mine_dt]

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 7
+#define RPE_ABI_VERSION 8
 
 #define RPE_EINVAL (-1)       /* bad size / null pointer */
 #define RPE_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
@@ -410,10 +410,14 @@ int rpe_eval_accumulate(const float *flow2d, const float *target2d, int target2d
                         double *workspace, double *acc, rpe_stream_t stream);
 
 /* ---- diagnostics -------------------------------------------------------------
- * Writes the GPU's constant-rate clock (100 MHz wall_clock64) to *slot when the stream reaches this point: a
- * one-thread kernel, usable inside a captured HIP graph, for timelines of multi-stream replays that rocprofv3
- * serialises (rpeflow_amd.model.Stamps, tools/stamp_timeline.py).                                             */
-int rpe_debug_stamp(unsigned long long *slot, rpe_stream_t stream);
+ * When the stream reaches this point one wave stores slot2[0] = the shader-engine cycle counter (s_memtime) and slot2[1] =
+ * the constant-rate counter (s_memrealtime, wall_clock64).  A one-thread kernel, usable inside a captured HIP graph:
+ *   - timelines of multi-stream replays that rocprofv3 serialises read slot2[1] (rpeflow_amd.model.StampTrace,
+ *     tools/stamp_timeline.py);
+ *   - two stamps bracket a stretch of a stream: d[0] / d[1] x the constant rate = the clock the engines actually ran at
+ *     (rpeflow_amd.runtime.ShaderClock; bench.py's roofline objects carry it).
+ * wall_khz (host pointer, may be NULL): receives the constant rate of the current device (hipDeviceAttributeWallClockRate). */
+int rpe_clock_stamp(unsigned long long *slot2, int *wall_khz, rpe_stream_t stream);
 
 #ifdef RPE_EXPERIMENTAL /* only in a library built with -DRPE_EXPERIMENTAL (python -m rpeflow_amd.build --experimental) */
 /* Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation

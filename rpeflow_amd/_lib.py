@@ -48,7 +48,7 @@ _PROTOTYPES = {
     "rpe_corr3d_n2n": [_c_ptr] * 7 + [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_correlation2d_backward": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_knn_multi": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr],
-    "rpe_debug_stamp": [_c_ptr, _c_ptr],
+    "rpe_clock_stamp": [_c_ptr, _c_ptr, _c_ptr],
     "rpe_gather_channel_first": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_gather_channel_last": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_pointwise_conv": [_c_ptr, _c_i64, _c_int, _c_int, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_float,
@@ -78,7 +78,7 @@ _PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 7  # RPE_ABI_VERSION of include/rpeflow_hip.h
+ABI_VERSION = 8  # RPE_ABI_VERSION of include/rpeflow_hip.h
 KNN_TIES = {"torch": 3, "set": 1, "index": 0}  # RPE_KNN_TIES_* (how equal distances are resolved)
 KNN_ALGO = {"auto": 0, "sweep": 0x100, "binned": 0x200}  # RPE_KNN_ALGO_* (OR-ed into the mode)
 # entry points only a library built with -DRPE_EXPERIMENTAL has (python -m rpeflow_amd.build --experimental)

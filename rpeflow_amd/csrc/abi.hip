@@ -12,11 +12,23 @@ RPE_API const char *rpe_error_string(int code) {
 }
 
 namespace {
-__global__ void stamp_kernel(unsigned long long *slot) { *slot = wall_clock64(); }
+// s_memtime (the free-running counter of the shader engine clock) and s_memrealtime (the constant-rate reference clock) read
+// back to back by one wave: two such pairs bracket a stretch of a stream, d(shader) / d(wall) x the wall rate = the clock
+// the engines actually ran at over that stretch
+__global__ void clock_stamp_kernel(unsigned long long *slot) {
+    slot[0] = clock64();
+    slot[1] = wall_clock64();
+}
 }  // namespace
 
-RPE_API int rpe_debug_stamp(unsigned long long *slot, rpe_stream_t stream) {
-    if (!slot) return RPE_EINVAL;
-    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
+RPE_API int rpe_clock_stamp(unsigned long long *slot2, int *wall_khz, rpe_stream_t stream) {
+    if (!slot2) return RPE_EINVAL;
+    if (wall_khz) {
+        int device = 0;
+        hipError_t e = hipGetDevice(&device);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(wall_khz, hipDeviceAttributeWallClockRate, device);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot2);
     return rpe_launch_status();
 }

@@ -533,7 +533,7 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
         if (dma_ok && C % 2 == 0 && px >= 144 * 240) algo = 7;
         else if (dma_ok && C % 4 == 0 && px >= 72 * 120) algo = 4;
         else if (md == MD && px >= 72 * 120) algo = 2;
-        else if (md <= 4 && B <= 65535) algo = 3;
+        else if (md <= 4 && B <= 65535 && (int64_t)B * px <= 8 * 36 * 60) algo = 3;  // the maps it was written and measured on (<= 36x60, 2B = 8)
         else algo = 1;
     }
     if (algo == 2) {

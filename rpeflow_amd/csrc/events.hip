@@ -30,15 +30,20 @@ __global__ __launch_bounds__(256) void events_to_voxel_kernel(const int *__restr
     for (int i = begin; i < end; ++i) {
         const T te = (t[i] - t_first) / span;
         const T tn = (te - te_first) / dt * (T)(bins - 1);     // t_norm, left to right as written at :244
-        const int b0 = (int)floor(tn);
         const int sign = pol[i];
+        if (tn != tn) {  // all timestamps equal (dt = 0 -> 0/0) or a NaN timestamp: the reference's weight max(0, 1 - |t_norm - b|) is NaN
+            const T nan_w = tn;  // in EVERY bin, and polarity * NaN (0 * NaN in the other polarity's grid) is NaN too
+            for (int c = 0; c < (split ? 2 * bins : bins); ++c) out[(int64_t)c * HW + p] += (float)nan_w;
+            continue;
+        }
+        const int b0 = (int)floor(tn);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int b = b0 + k;
             if (b < 0 || b >= bins) continue;
             const T d = tn - (T)b;
             const T w = (T)1 - (d < (T)0 ? -d : d);
-            const T wz = w > (T)0 ? w : (T)0;
+            const T wz = w < (T)0 ? (T)0 : w;  // torch.max(zeros, w): a NaN weight (all timestamps equal: t_norm = 0/0) stays NaN
             if (split) {  // :296-297: positive grid takes p > 0, negative grid p <= 0, each with weight 1
                 float *o = out + (int64_t)(sign > 0 ? b : bins + b) * HW + p;
                 *o = *o + (float)((T)1 * wz);

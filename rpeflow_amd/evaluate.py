@@ -253,9 +253,11 @@ def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=Non
         accumulate(acc, out, batch)
         mark()
     import torch.distributed as dist
-    if world_size > 1 or group is not None or (dist.is_available() and dist.is_initialized()):
-        # also with ONE rank inside an initialised process group (bench.py --gpus 1 joins a world-size-1 nccl group): the sum is
-        # the identity there, and the collective has then run on the real backend in every configuration
+    if world_size > 1 or group is not None:
+        # decided by the caller's arguments alone: an unsharded call (world_size=1, group=None) made inside a multi-rank job --
+        # rank 0 validating on its own, or every rank evaluating the whole set -- must neither wait for the others nor multiply
+        # its sums.  A launcher's single rank passes its world-size-1 group explicitly (bench.py, main() below): the sum is the
+        # identity there, and the collective has then run on the real backend in every configuration
         if acc.is_cuda and dist.get_backend(group) == "gloo":  # (tests on a one-GPU box: the collective through host memory)
             acc_host = acc.cpu()
             dist.all_reduce(acc_host, op=dist.ReduceOp.SUM, group=group)
@@ -311,10 +313,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    if world > 1 or "MASTER_PORT" in os.environ:  # (a launcher's single rank joins its world-size-1 group as well)
+    # a launcher sets all three (torchrun does, also for one rank); a stale MASTER_PORT in a plain shell is not a launcher
+    launched = world > 1 or all(k in os.environ for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
+    group = None
+    if launched:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        group = dist.group.WORLD
     from .model import RPEFlow
     from .synthetic import load_seeded_parameters
     model = load_seeded_parameters(RPEFlow()).to(device).eval()
@@ -323,12 +330,12 @@ def main():
     from .synthetic import SyntheticPairs
     data = SyntheticPairs(args.samples, args.height, args.width, args.points, dsec=args.dsec, events=args.raw_events)
     t0 = time.perf_counter()
-    metrics, _ = evaluate(model, data, args.batch, device, rank, world, graph=False if args.eager else None)
+    metrics, _ = evaluate(model, data, args.batch, device, rank, world, group=group, graph=False if args.eager else None)
     torch.cuda.synchronize()
     metrics["seconds"] = round(time.perf_counter() - t0, 3)
     if rank == 0:
         print(json.dumps(metrics))
-    if world > 1 or "MASTER_PORT" in os.environ:
+    if launched:
         dist.destroy_process_group()
 
 

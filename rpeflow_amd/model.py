@@ -466,22 +466,22 @@ def _pair_scale(a, b, like):
 
 class StampTrace:
     """Timeline of a multi-stream forward: stamp(name) drops a one-thread kernel on the current stream that stores the
-    GPU wall clock (rpe_debug_stamp).  Works inside a captured HIP graph: every replay refreshes the values.  Set
+    GPU wall clock (rpe_clock_stamp).  Works inside a captured HIP graph: every replay refreshes the values.  Set
     rpeflow_amd.model.TRACE = StampTrace(device) before the (captured) forward, read() after a replay."""
 
     def __init__(self, device, slots=1024):
-        self.buf = torch.zeros(slots, dtype=torch.int64, device=device)
+        self.buf = torch.zeros((slots, 2), dtype=torch.int64, device=device)  # (shader cycles, constant-rate ticks) per stamp
         self.names = []
 
     def __call__(self, name):
         from . import _lib
         i = len(self.names)
         self.names.append(name)
-        _lib.check(_lib.lib().rpe_debug_stamp(self.buf.data_ptr() + 8 * i, _lib.stream_of(self.buf)), "stamp")
+        _lib.check(_lib.lib().rpe_clock_stamp(self.buf.data_ptr() + 16 * i, None, _lib.stream_of(self.buf)), "stamp")
 
     def read(self):
         """[(name, microseconds since the first stamp)] in issue order."""
-        v = self.buf[:len(self.names)].cpu().tolist()
+        v = self.buf[:len(self.names), 1].cpu().tolist()
         return [(n, (t - v[0]) / 100.0) for n, t in zip(self.names, v)]
 
 

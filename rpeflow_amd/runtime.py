@@ -52,3 +52,70 @@ def configure():
         out["hip"] = getattr(torch.version, "hip", None)
         out["torch"] = torch.__version__
     return out
+
+
+SCLK_PLAUSIBLE_MHZ = (500.0, 2500.0)  # an engine clock outside this range on an MI355X under load is a broken reading
+
+
+class ShaderClock:
+    """The clock the shader engines ran at over a stretch of the CURRENT stream of ``device``, measured on the device the
+    work runs on and inside the stream it runs in: ``with ShaderClock(dev) as c: <launches>`` puts one clock stamp
+    (rpe_clock_stamp: s_memtime and s_memrealtime read by one wave) in front of and one behind the launches;
+    ``c.mhz()`` (after the stream has been synchronised) = d(shader cycles) / d(constant-rate ticks) x the constant rate.
+    ``None`` -- never a number -- when the result is not a plausible engine clock (e.g. a part whose s_memtime does not
+    follow the engine clock): callers fall back to ``hwmon_sclk_mhz`` or print null."""
+
+    def __init__(self, device):
+        import ctypes
+        import torch
+        self.device = torch.device(device)
+        self.slots = torch.zeros(4, dtype=torch.int64, device=self.device)
+        self.khz = ctypes.c_int(0)
+
+    def _stamp(self, i):
+        import ctypes
+        import torch
+        from . import _lib
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().rpe_clock_stamp(self.slots.data_ptr() + 16 * i, ctypes.byref(self.khz), _lib.stream_of(self.slots)), "clock_stamp")
+
+    def __enter__(self):
+        self._stamp(0)
+        return self
+
+    def __exit__(self, *exc):
+        self._stamp(1)
+
+    def raw(self):
+        """(d shader cycles, d constant-rate ticks, constant rate in kHz)."""
+        s0, w0, s1, w1 = self.slots.tolist()
+        return s1 - s0, w1 - w0, self.khz.value
+
+    def mhz(self):
+        cycles, ticks, khz = self.raw()
+        if ticks <= 0 or khz <= 0:
+            return None
+        mhz = cycles / ticks * khz / 1e3
+        return round(mhz, 1) if SCLK_PLAUSIBLE_MHZ[0] <= mhz <= SCLK_PLAUSIBLE_MHZ[1] else None
+
+
+def hwmon_sclk_mhz(device):
+    """Fallback reading: amdgpu's hwmon node OF THE DEVICE PyTorch runs on (found through its PCI address), only if the node
+    is labelled "sclk" and the value is a plausible engine clock; else None.  One instant, not an average."""
+    import glob
+    import torch
+    try:
+        prop = torch.cuda.get_device_properties(device)
+        bdf = "%04x:%02x:%02x.0" % (prop.pci_domain_id, prop.pci_bus_id, prop.pci_device_id)  # (integers in torch's properties)
+    except (AttributeError, RuntimeError, TypeError):
+        return None
+    for label in glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*/freq*_label" % bdf):
+        try:
+            if open(label).read().strip() != "sclk":
+                continue
+            mhz = float(open(label.replace("_label", "_input")).read()) / 1e6
+        except (OSError, ValueError):
+            continue
+        if SCLK_PLAUSIBLE_MHZ[0] <= mhz <= SCLK_PLAUSIBLE_MHZ[1]:
+            return round(mhz, 1)
+    return None

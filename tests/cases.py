@@ -172,6 +172,9 @@ EVENT_CASES = {
     # float32 [N,4] arrays, as load_events_h5 hands them to the datasets (event_utils.py:11-20): float32 arithmetic throughout
     "events_f32_20000_36x60_b10_pol": (20000, 36, 60, 10, True, 604),
     "events_f32_5000_24x40_b5": (5000, 24, 40, 5, False, 605),
+    # every event at ONE timestamp: dt = 0, t_norm = 0/0 -- the reference's weights are NaN in every bin of every touched pixel
+    "events_same_t_40_6x8_b3_pol": (40, 6, 8, 3, True, 606),
+    "events_f32_same_t_40_6x8_b3": (40, 6, 8, 3, False, 607),
 }
 
 
@@ -180,6 +183,8 @@ def event_inputs(name):
     n, H, W, bins, pol, seed = EVENT_CASES[name]
     r = I.rng(seed)
     t = np.sort(r.integers(1_000_000, 1_050_000, n)).astype(np.float64)
+    if "same_t" in name:
+        t[:] = t[0]
     ev = np.stack([r.integers(0, W, n).astype(np.float64), r.integers(0, H, n).astype(np.float64), t,
                    r.integers(0, 2, n).astype(np.float64)], axis=1)
     if name.startswith("events_f32"):

@@ -9,7 +9,7 @@ def bits(a):
 def assert_bits_equal(a, b, what=""):
     a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
     assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
-    bad = bits(a) != bits(b)
+    bad = (bits(a) != bits(b)) & ~(np.isnan(a) & np.isnan(b))  # a NaN is a NaN: sign and payload are not part of the contract
     assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} fp32 bit patterns differ"
 
 

@@ -385,6 +385,43 @@ def gen_model_stress():
              epe2d=np.float64(epe2), epe3d=np.float64(epe3), **ids_clouds(), **levels)
 
 
+IDS_SWEEP = dict(first_seed=6000, pairs=32, H=544, W=960, N=8192, samples=4096)
+
+
+@torch.no_grad()
+def gen_ids_sweep():
+    """What the product's DEFAULT path replaces -- the host-side IDS transform (RPEFlow.py:56-69 -> utils.py:320-346) followed by
+    build_pc_pyramid's furthest-point sampling (pwc3d_core.py:11-13) -- recorded from the reference for 64 clouds (32 stress
+    frame pairs, seeds 6000...): per cloud the full sampling order (uint16) and, instead of the 6 MB of transformed clouds,
+    the positions and values where the reference's z' (torch.log on this container's CPU) is NOT the correctly rounded one
+    of oracle.perspect2parallel; x' and y' are asserted bit-identical here, so the reference cloud is oracle + patches."""
+    from oracle import oracle as O
+    c = IDS_SWEEP
+    H, W, N = c["H"], c["W"], c["N"]
+    Hp, Wp = (H + 63) // 64 * 64 // 32, (W + 63) // 64 * 64 // 32
+    orders, patch_cloud, patch_pos, patch_val = [], [], [], []
+    for i in range(c["pairs"]):
+        sample = I.frame_pair_stress(c["first_seed"] + i, H=H, W=W, N=N)
+        pcs, intr = T(sample["pcs"])[None], T(sample["intrinsics"])[None]
+        persp = {"projection_mode": "perspective", "sensor_h": H, "sensor_w": W, "f": intr[:, 0], "cx": intr[:, 1], "cy": intr[:, 2]}
+        paral = {"projection_mode": "parallel", "sensor_h": Hp, "sensor_w": Wp, "cx": (Wp - 1) / 2, "cy": (Hp - 1) / 2}
+        clouds = [ref_utils.perspect2parallel(pcs[:, sl], persp, paral) for sl in (slice(0, 3), slice(3, 6))]
+        both = torch.cat(clouds, dim=0)
+        order = ref_ops.furthest_point_sampling(both.transpose(1, 2), c["samples"]).numpy()
+        for j in range(2):
+            mine = O.perspect2parallel(sample["pcs"][None, 3 * j:3 * j + 3], sample["intrinsics"][None], H, W, Hp, Wp)[0]
+            ref = clouds[j][0].numpy()
+            assert np.array_equal(mine[:2].view(np.uint32), ref[:2].view(np.uint32))
+            off = np.nonzero(mine[2].view(np.uint32) != ref[2].view(np.uint32))[0]
+            patch_cloud += [2 * i + j] * len(off)
+            patch_pos += off.tolist()
+            patch_val += ref[2][off].tolist()
+            orders.append(order[j].astype(np.uint16))
+        print("pair", i, "z' values off the correctly rounded log so far:", len(patch_pos), flush=True)
+    save("ids_fps_sweep", order=np.stack(orders), patch_cloud=np.array(patch_cloud, np.int32), patch_pos=np.array(patch_pos, np.int32),
+         patch_val=np.array(patch_val, np.float32))
+
+
 def gen_eval():
     """The reference's evaluation loops themselves (eval_withocc.py:45-135, eval_noocc.py:45-116), unmodified, over the
     synthetic frame pairs and the stand-in predictions of tests/test_evaluate.py; stored: the accumulated metric sums.
@@ -448,6 +485,6 @@ def gen_eval():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval", "fblocks", "model_bench", "model_bench_dsec", "model_stress", "blocks_general"]
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval", "fblocks", "model_bench", "model_bench_dsec", "model_stress", "blocks_general", "ids_sweep"]
     for w in which:
         globals()["gen_" + w]()

@@ -98,6 +98,10 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 data = SyntheticPairs(5, H=24, W=40, N=512)            # 5 samples over 2 ranks: shards of 3 and 2
 metrics, acc = E.evaluate(fake_model, data, batch_size=2, device="cpu", rank=rank, world_size=world)
 print("RESULT", rank, json.dumps(acc.tolist()))
+if rank == 0:  # an unsharded call inside the job (rank 0 validating on its own): no collective, nothing multiplied, no waiting for rank 1
+    _, alone = E.evaluate(fake_model, data, batch_size=2, device="cpu")
+    print("ALONE", rank, json.dumps(alone.tolist()))
+dist.barrier()
 dist.destroy_process_group()
 '''
 
@@ -122,6 +126,8 @@ def test_two_process_gloo_all_reduce_equals_single_process(tmp_path):
     _, single = E.evaluate(fake_model, data, batch_size=2, device="cpu")
     np.testing.assert_allclose(np.array(accs[0]), single.numpy(), rtol=1e-12)
     assert accs[0][0] == single[0].item() and accs[0][4] == single[4].item()
+    alone = json.loads(next(l for l in outs[0][0].splitlines() if l.startswith("ALONE")).split(" ", 2)[2])
+    assert alone == single.tolist()  # world_size=1, group=None inside an initialised 2-rank group: the plain single-process sums
 
 
 @pytest.mark.parametrize("device", ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)])

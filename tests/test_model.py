@@ -395,6 +395,49 @@ def test_model_on_gpu_matches_reference_golden_under_stress(golden_dir, name, se
             assert a2 <= 1e-4 * max(1.0, np.abs(w2).mean()) and a3 <= 1e-4 * max(1.0, np.abs(w3).mean())
 
 
+# ---- the DEFAULT path (round-4 review, weak #1): RPEFlow() as bench.py, evaluate() and a user build it -- IDS transform on the
+# device (rpe_ids_forward, correctly rounded logarithm), no ``pcs_ids`` from the golden, no ``ids_on_host`` -- against the
+# reference's CPU forward on every model golden, the three large-motion ones with the second parameter fill included.
+DEFAULT_PATH = [("model_128x192", 1000, 128, 192, False, False), ("model_dsec_480x640", 2000, 480, 640, True, False),
+                ("model_544x960", 3000, 544, 960, False, False)] + [(n, s, h, w, d, True) for n, s, h, w, d in STRESS]
+
+
+@pytest.mark.gpu
+@torch.no_grad()
+@pytest.mark.parametrize("name,seed,H,W,dsec,stress", DEFAULT_PATH)
+def test_default_device_ids_path_matches_reference_golden(golden_dir, name, seed, H, W, dsec, stress):
+    """|EPE2D - reference|, |EPE3D - reference| < 1e-4 (north_star) for the path users run: the clouds FPS / KNN see are
+    computed on the device.  Also reported: how many of the 2 x 3 x 8192 transformed coordinates differ from the reference's
+    (its CPU log is off the correctly rounded value on a few in ten thousand) and whether the sampling order is the one the
+    reference's clouds give."""
+    from rpeflow_amd.csrc import furthest_point_sampling
+    from rpeflow_amd.model import RPEFlow
+    model = RPEFlow().eval()
+    assert not model.ids_on_host
+    model.load_state_dict((stress_state if stress else seeded_state)(model), strict=True)
+    model = model.to("cuda:0")
+    s = (I.frame_pair_stress if stress else I.frame_pair)(seed, H=H, W=W, N=8192, dsec=dsec)
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    batch = {k: torch.from_numpy(v)[None].to("cuda:0") for k, v in s.items()}
+    assert "pcs_ids" not in batch
+    out = model(batch)
+    f2, f3 = out["flow_2d"].cpu().numpy(), out["flow_3d"].cpu().numpy()
+    assert np.isfinite(f2).all() and np.isfinite(f3).all() and f2.shape == (1, 2, H, W)
+    e2, e3 = I.masked_epes(f2[0], f3[0], s)
+    if "epe2d" in g:
+        r2, r3 = float(g["epe2d"]), float(g["epe3d"])
+    else:  # (the 128x192 golden stores the flows; its EPEs are means over every pixel / point, which masked_epes gives for unmasked targets)
+        r2, r3 = I.masked_epes(g["flow_2d"][0], g["flow_3d"][0], s)
+    ref_clouds = torch.from_numpy(np.concatenate([g["pc1_ids"], g["pc2_ids"]])).to("cuda:0")
+    mine = torch.cat(model._clouds(batch, *model._cameras(batch)))
+    off = int((mine != ref_clouds).sum())
+    same_order = torch.equal(model.sample_order(batch), furthest_point_sampling(ref_clouds.transpose(1, 2), 4096))
+    print(name, "default path: EPE2D diff", abs(e2 - r2), "EPE3D diff", abs(e3 - r3), "| transformed coordinates off the reference's:", off,
+          "| sampling order equals the reference's:", same_order)
+    assert abs(e2 - r2) < GOLDEN_EPE_TOL and abs(e3 - r3) < GOLDEN_EPE_TOL
+    assert off <= 4 and same_order
+
+
 @pytest.mark.gpu
 @torch.no_grad()
 def test_evaluation_metrics_under_stress_match_the_reference(golden_dir):

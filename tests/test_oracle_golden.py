@@ -143,6 +143,25 @@ def test_events_to_voxel(golden_dir, name):
     assert_bits_equal(O.events_to_voxel(ev, bins, H, W, pol), G(golden_dir, name)["voxel"], name)
 
 
+def test_ids_and_sampling_sweep_against_the_reference(golden_dir):
+    """tests/golden/ids_fps_sweep.npz (64 clouds of 32 large-motion pairs through the reference's perspect2parallel +
+    furthest_point_sampling): the restatements reproduce the sampling order from the correctly rounded transform as well as
+    from the reference's own z' -- checked here on the first eight clouds (all 64 in the build container: 0 orders differ)."""
+    g = np.load(os.path.join(golden_dir, "ids_fps_sweep.npz"))
+    assert g["order"].shape == (64, 4096) and len(g["patch_pos"]) == 32
+    for c in range(8):
+        s = I.frame_pair_stress(6000 + c // 2, H=544, W=960, N=8192)
+        mine = O.perspect2parallel(s["pcs"][None, 3 * (c % 2):3 * (c % 2) + 3], s["intrinsics"][None], 544, 960, 18, 30)[0]
+        ref = mine.copy()
+        m = g["patch_cloud"] == c
+        ref[2][g["patch_pos"][m]] = g["patch_val"][m]
+        ulps = np.abs(mine.view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
+        assert ulps.max() <= 1
+        for cloud in (ref, mine):
+            order = O.furthest_point_sampling(np.ascontiguousarray(cloud.T)[None], 4096)[0]
+            assert np.array_equal(order.astype(np.uint16), g["order"][c]), c
+
+
 @pytest.mark.parametrize("name,H,W,seeds", [("model_128x192", 128, 192, [1000]), ("model_544x960", 544, 960, [3000]),
                                             ("model_bench_b4_544x960", 544, 960, [1000, 1001, 1002, 1003]),
                                             ("model_dsec_480x640", 480, 640, [2000])])

@@ -19,8 +19,8 @@ for _ in range(3):
     model(batch)
 torch.cuda.synchronize()
 from rpeflow_amd import _lib
-probe = torch.zeros(1, dtype=torch.int64, device=dev)
-mark = lambda: _lib.lib().rpe_debug_stamp(probe.data_ptr(), torch.cuda.current_stream().cuda_stream)  # marker kernel
+probe = torch.zeros(2, dtype=torch.int64, device=dev)
+mark = lambda: _lib.lib().rpe_clock_stamp(probe.data_ptr(), None, torch.cuda.current_stream().cuda_stream)  # marker kernel
 step = lambda: model(batch)
 if "graph" in sys.argv:  # replay the forward as one HIP graph, as bench.py does
     graph = torch.cuda.CUDAGraph()

@@ -1,4 +1,4 @@
-"""Sum kernel durations of a rocprofv3 kernel trace between the two marker kernels (the stamp kernel of rpe_debug_stamp) of tools/prof_forward.py.
+"""Sum kernel durations of a rocprofv3 kernel trace between the two marker kernels (the stamp kernel of rpe_clock_stamp) of tools/prof_forward.py.
 Usage: python tools/trace_window.py <kernel_trace.csv> <steps>"""
 import collections
 import csv
