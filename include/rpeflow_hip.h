@@ -68,12 +68,17 @@ const char *rpe_error_string(int code);
  *   - the tied rows of a large k >= 2 search are redone by a second launch spread over the whole chip instead of by the waves
  *     that found them at the end of the first (csrc/knn.hip, knn_tie_replay_kernel).
  * RPE_KNN_ALGO_SWEEP: every query against every point whatever the sizes; RPE_KNN_ALGO_BINNED: the binned search or an error
- * (RPE_EUNSUPPORTED unless k = 1, D = 2, M >= 64; RPE_EINVAL without enough workspace) -- for cross-checks.              */
+ * (RPE_EUNSUPPORTED unless k = 1, D = 2, M >= 64; RPE_EINVAL without enough workspace); RPE_KNN_ALGO_MATRIX: the matrix-core
+ * kernel wherever its structure allows (k <= 63, 64 k <= M, M >= 256) instead of only above the measured break-even sizes;
+ * RPE_KNN_ALGO_INSERT: never the matrix-core kernel -- all four for cross-checks and for the break-even table
+ * (tools/knn_gate_table.py); results are identical whichever kernel runs.                                                  */
 #define RPE_KNN_TIES_INDEX 0
 #define RPE_KNN_TIES_SET 1
 #define RPE_KNN_TIES_TORCH 3
 #define RPE_KNN_ALGO_SWEEP 0x100
 #define RPE_KNN_ALGO_BINNED 0x200
+#define RPE_KNN_ALGO_MATRIX 0x400
+#define RPE_KNN_ALGO_INSERT 0x800
 int64_t rpe_knn_workspace_bytes(int B, int M, int Q, int D, int k, int mode);
 int rpe_knn(const float *input, int64_t in_sb, int64_t in_sn, int64_t in_sd,
             const float *query, int64_t q_sb, int64_t q_sn, int64_t q_sd,
@@ -155,7 +160,8 @@ int rpe_gather_channel_last(const float *data, int64_t sb, int64_t sn, int64_t s
 /* rpe_pointwise_conv: a stride-1 1x1 convolution with its epilogue in one launch (csrc/pointwise.hip; models/utils.py:7-62,
  * models/restormer_arch.py:88-110):  y[b][o][p] = act(scale[o] * sum_c W[o][c] x[b][c][p] + shift[o]) (+ residual[b][o][p]).
  * x [B,Cin,P] with batch stride x_batch_stride floats (Cin * P for a dense tensor; larger for a channel slice of a wider one),
- * y / residual [B,Cout,P] contiguous fp32; packed_weight [ceil(Cout/16)][ceil(Cin/4)][64]: entry (ot, kt, 16 k + i)
+ * y [B,Cout,P] contiguous fp32, residual [B,Cout,P] with batch stride residual_batch_stride (>= Cout * P: a channel slice of a wider
+ * tensor is added where it lies); packed_weight [ceil(Cout/16)][ceil(Cin/4)][64]: entry (ot, kt, 16 k + i)
  * = W[16 ot + i][4 kt + k], zero outside (the MFMA A-fragment order); weight_batch_stride 0: one weight for the batch, > 0: ONE
  * PACKED WEIGHT PER SAMPLE, W[b] at packed_weight + b * weight_batch_stride -- the channel attention's per-sample matrix M[b]
  * (rpe_channel_attention_matrix, packed = 1) applied to v[b] with the block's residual in the epilogue; scale / shift /
@@ -163,7 +169,7 @@ int rpe_gather_channel_last(const float *data, int64_t sb, int64_t sn, int64_t s
  * deterministic.                                                                                                       */
 int rpe_pointwise_conv(const float *x, int64_t x_batch_stride, int B, int Cin, int64_t P, const float *packed_weight,
                        int64_t weight_batch_stride, int Cout, const float *scale, const float *shift, int act, float slope,
-                       const float *residual, float *y, rpe_stream_t stream);
+                       const float *residual, int64_t residual_batch_stride, float *y, rpe_stream_t stream);
 /* rpe_im2col: cols [B, C*kh*kw, Ho*Wo] = torch.nn.functional.unfold(x [B,C,H,W], (kh,kw), dilation, padding, stride) for the whole
  * batch in one launch: the input side of the small convolutions that run as one deterministic GEMM instead of MIOpen's
  * atomically accumulating split-K kernels (rpeflow_amd/utils.py, wants_im2col) -- with the per-channel epilogue of the layer
@@ -175,26 +181,56 @@ int rpe_im2col(const float *x, int B, int C, int H, int W, int kh, int kw, int s
 
 /* ---- knn_interpolation after its KNN (models/utils.py:148-154) ------------------
  * w_j = 1/max(||in_xyz[:,knn_j] - q_xyz||_2, 1e-8), normalised over the k neighbours;
- * out[b][c][q] = sum_j (scale*feat[b][c][knn_j]) * w_j.  scale = -1 gives backwarp_3d's
+ * out[b][c][q] = sum_j (scale*F[b][c][knn_j]) * w_j.  scale = -1 gives backwarp_3d's
  * "-flow12" features (utils.py:166-167) without a negation pass.
+ * F: channels [0, C) from `feat`, [C, C + C_b) from `feat_b` (NULL with C_b = 0) -- the decoder interpolates the coarser
+ * level's [flow | flow features] (RPEFlow_core.py:352), two tensors that are never concatenated here.
+ * `residual` [B, C + C_b, Q] through strides, or NULL: out = fl(residual + sum) (backwarp_3d's "xyz2 + flow21", utils.py:169).
  * Point/feature tensors channel-first through strides (sb, channel stride, point stride);
- * knn [B,Q,*] int64 with row stride knn_row_stride >= k; out [B,C,Q] contiguous. k <= 8. */
+ * knn [B,Q,*] int64 with row stride knn_row_stride >= k; out [B, C + C_b, Q] contiguous. k <= 8. */
 int rpe_knn_interpolate(const float *in_xyz, int64_t x_sb, int64_t x_sd, int64_t x_sn,
-                        const float *feat, int64_t f_sb, int64_t f_sc, int64_t f_sn,
+                        const float *feat, int64_t f_sb, int64_t f_sc, int64_t f_sn, int C,
+                        const float *feat_b, int64_t g_sb, int64_t g_sc, int64_t g_sn, int C_b,
                         const float *q_xyz, int64_t q_sb, int64_t q_sd, int64_t q_sn,
                         const int64_t *knn, int64_t knn_row_stride,
-                        int B, int M, int Q, int C, int k, float scale, float *out, rpe_stream_t stream);
+                        int B, int M, int Q, int k, float scale,
+                        const float *residual, int64_t r_sb, int64_t r_sc, int64_t r_sn, float *out, rpe_stream_t stream);
 
 /* ---- bilinear sampling: backwarp_2d and grid_sample_wrapper ---------------------
  * (models/utils.py:186-198 and 288-294, i.e. F.grid_sample(bilinear, align_corners=True)
  * after the callers' 2*g/(S-1)-1 normalisation, restated as in ATen's CPU kernel.)
- * feat [B,C,H,W] contiguous; coordinates xy[b][d][p] = xy[b*xy_sb + d*xy_sd + p*xy_sp], d=0:x, 1:y.
- * add_pixel_grid=1, border=1, P=H*W: backwarp_2d(feat, flow=xy, 'border').
- * add_pixel_grid=0, border=0:         grid_sample_wrapper(feat, xy) (padding 'zeros').
- * out [B,C,P] contiguous.                                                           */
-int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W,
+ * The sampled map is the channel-wise concatenation of 1..RPE_SAMPLE_MAX_SOURCES tensors of one H x W, which is never built
+ * (`sources` is a HOST array): source i = channels planes data[b*sb + c*sc + pixel].  What the 3-D correlation fuser does
+ * around its two grid_sample_wrapper calls (RPEFlow_core.py:105-111) rides in the launch:
+ *   scale_even / scale_odd  every tap of an even / odd channel of the source is multiplied as it is read, fl(tap * s): sampling
+ *                           "flow_2d * (sx, sy)" (:103-104) without that tensor; 1, 1 for a plain source;
+ *   subtract                NULL, or [B, channels, P] through strides: taken off the source's samples (":110  -= flow_3d[:, :2]").
+ * Coordinates xy[b][d][p] = xy[b*xy_sb + d*xy_sd + p*xy_sp], d=0:x, 1:y.
+ * add_pixel_grid=1, border=1, P=H*W: backwarp_2d(map, flow=xy, 'border').
+ * add_pixel_grid=0, border=0:         grid_sample_wrapper(map, xy) (padding 'zeros').
+ * out [B, sum channels, P] contiguous.                                              */
+#define RPE_SAMPLE_MAX_SOURCES 4
+typedef struct {
+    const float *data;
+    int64_t sb, sc;
+    int channels;
+    float scale_even, scale_odd;
+    const float *subtract;
+    int64_t sub_sb, sub_sc, sub_sp;
+} rpe_sample_source;
+int rpe_bilinear_sample(const rpe_sample_source *sources, int n_sources, int B, int H, int W,
                         const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sp, int P,
                         int add_pixel_grid, int border, float *out, rpe_stream_t stream);
+/* rpe_project_points: project_pc2image (models/utils.py:260-285) followed by the sensor -> feature-map rescale of
+ *   RPEFlow_core.py:316-324, for the clouds of BOTH frames in one launch (the reference: per frame two adds -- or a div, two muls
+ *   and two adds --, a cat and two in-place muls).  xyz_a, xyz_b [B,3,N] through strides (batch, channel, point); xyz_b NULL:
+ *   one tensor.  intrinsics NULL: 'parallel' projection, u = fl(fl(x + cx) * scale_x); else 'perspective' with per-sample
+ *   (f, cx, cy) at intrinsics[b*intr_sb + 0..2]: u = fl(fl(cx_b + fl(fl(f_b / z) * x)) * scale_x); v likewise.
+ *   out [2B (or B), 2, N] contiguous: the first tensor's samples, then the second's.                             */
+int rpe_project_points(const float *xyz_a, int64_t a_sb, int64_t a_sd, int64_t a_sn,
+                       const float *xyz_b, int64_t b_sb, int64_t b_sd, int64_t b_sn, int B, int N,
+                       const float *intrinsics, int64_t intr_sb, float cx, float cy, float scale_x, float scale_y,
+                       float *out, rpe_stream_t stream);
 /* rpe_resize_frames: RPEFlow.forward's input preparation (models/RPEFlow.py:40-47, utils.py:227-241): src [B,C,H,W]
  *   (uint8 when src_is_u8, else float) resized to [Ho,Wo] with F.interpolate(bilinear, align_corners=True); each tap is
  *   divided by ``divisor`` first when divisor != 0 (the images' / 255).  pair_split: C = 2*c channels are the two frames of
@@ -242,10 +278,15 @@ int rpe_ids_flow_inverse(const float *xyz, int64_t x_sb, int64_t x_sc, int64_t x
  * The two element-wise steps the 2-D correlation fuser puts behind the operator (RPEFlow_core.py:82-83) ride in the launch:
  *   `subtract` [B, n_subtract, H*W] is subtracted from the LAST n_subtract projected channels ("projected 3-D flow minus the
  *   2-D flow") and `append` [B, n_append, H*W] is copied behind the C3 + 3 channels (the cat with the event features):
- *   out [B, C3 + 3 + n_append, H, W].  Either may be NULL with a count of 0.                                              */
+ *   out [B, C3 + 3 + n_append, H, W].  Either may be NULL with a count of 0.
+ * feat_3d as two tensors, C3 = C3a + C3b: channels [0, C3a) from feat_3d, [C3a, C3) from feat_3d_b (NULL with C3b = 0), whose
+ *   even / odd channels are multiplied by scale_even / scale_odd as they are read -- the 2-D correlation fuser projects
+ *   [3-D cost volume | xy of the 3-D flow in feature-map units] (RPEFlow_core.py:371-373: two in-place muls and a cat there).  */
 int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
                              int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
-                             const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
+                             const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3a,
+                             const float *feat_3d_b, int64_t g3_sb, int64_t g3_sc, int64_t g3_sn, int C3b,
+                             float scale_even, float scale_odd,
                              const int64_t *nn_idx, const float *subtract, int n_subtract, const float *append, int n_append,
                              int B, int N, float *workspace, float *out, rpe_stream_t stream);
 

@@ -295,7 +295,8 @@ def events_to_voxel(events, num_bins, height, width, event_polarity):
     ev = ev.astype(T, copy=False)
     xs, ys, ps = ev[:, 0].astype(np.int32), ev[:, 1].astype(np.int32), ev[:, 3].astype(np.int32)
     ts = ((ev[:, 2] - ev[0, 2]) / T((ev[-1, 2] - ev[0, 2]) + T(1e-6))).astype(T)
-    t_norm = ((ts - ts[0]) / T(ts[-1] - ts[0]) * T(num_bins - 1)).astype(T)
+    with np.errstate(invalid="ignore", divide="ignore"):  # one timestamp for every event: 0 / 0, NaN weights, as in the reference
+        t_norm = ((ts - ts[0]) / T(ts[-1] - ts[0]) * T(num_bins - 1)).astype(T)
     grids = [np.where(ps > 0, T(1), T(0)), np.where(ps <= 0, T(1), T(0))] if event_polarity else [ps.astype(T)]
     out = []
     for wgt in grids:

@@ -52,17 +52,21 @@ _PROTOTYPES = {
     "rpe_gather_channel_first": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_gather_channel_last": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_pointwise_conv": [_c_ptr, _c_i64, _c_int, _c_int, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_float,
-                           _c_ptr, _c_ptr, _c_ptr],
+                           _c_ptr, _c_i64, _c_ptr, _c_ptr],
     "rpe_im2col": [_c_ptr] + [_c_int] * 12 + [_c_ptr, _c_ptr, _c_int, _c_float, _c_ptr, _c_ptr],
-    "rpe_knn_interpolate": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64,
-                            _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_ptr, _c_ptr],
+    "rpe_knn_interpolate": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
+                            _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_float,
+                            _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr],
     "rpe_resize_frames": [_c_ptr, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_resize_flow2d": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_ptr, _c_ptr],
     "rpe_upsample2x_pair": [_c_ptr, _c_int, _c_float, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_bilinear_sample": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int,
                             _c_int, _c_int, _c_ptr, _c_ptr],
+    "rpe_project_points": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_ptr, _c_i64,
+                           _c_float, _c_float, _c_float, _c_float, _c_ptr, _c_ptr],
     "rpe_project_feat_nn_corr": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64,
-                                 _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
+                                 _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_float, _c_float,
+                                 _c_ptr, _c_ptr, _c_int, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_pointconv_pack_rows": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_pointconv_fused": [_c_ptr, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                             _c_float, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -80,9 +84,16 @@ _PROTOTYPES = {
 _lib = None
 ABI_VERSION = 8  # RPE_ABI_VERSION of include/rpeflow_hip.h
 KNN_TIES = {"torch": 3, "set": 1, "index": 0}  # RPE_KNN_TIES_* (how equal distances are resolved)
-KNN_ALGO = {"auto": 0, "sweep": 0x100, "binned": 0x200}  # RPE_KNN_ALGO_* (OR-ed into the mode)
+KNN_ALGO = {"auto": 0, "sweep": 0x100, "binned": 0x200, "matrix": 0x400, "insert": 0x800}  # RPE_KNN_ALGO_* (OR-ed into the mode)
 # entry points only a library built with -DRPE_EXPERIMENTAL has (python -m rpeflow_amd.build --experimental)
 _EXPERIMENTAL = {"rpe_probe_mfma4x4": [_c_ptr, _c_ptr]}
+
+
+class SampleSource(ctypes.Structure):
+    """rpe_sample_source of include/rpeflow_hip.h."""
+    _fields_ = [("data", ctypes.c_void_p), ("sb", ctypes.c_int64), ("sc", ctypes.c_int64), ("channels", ctypes.c_int),
+                ("scale_even", ctypes.c_float), ("scale_odd", ctypes.c_float), ("subtract", ctypes.c_void_p),
+                ("sub_sb", ctypes.c_int64), ("sub_sc", ctypes.c_int64), ("sub_sp", ctypes.c_int64)]
 
 
 class KnnJob(ctypes.Structure):

@@ -32,6 +32,10 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef RPE_CORR_PROBE
+#define RPE_CORR_PROBE 0  // 1, 2: diagnostic builds that drop part of corr_mfma_dma_kernel's work (tools/corr_energy_probes.sh), never shipped
+#endif
+
 __global__ __launch_bounds__(256) void corr_direct_kernel(const float *__restrict__ in1, const float *__restrict__ in2,
                                                           int C, int H, int W, int md, float slope,
                                                           float *__restrict__ out) {
@@ -416,6 +420,12 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
                     }
 #pragma unroll
                     for (int s = 0; s < 3; ++s) {
+#if RPE_CORR_PROBE == 2  // energy probe (WRONG results): one B-operand read per step instead of three, the matrix work unchanged
+                        if (s > 0) {
+                            br[t % (PD + 1)][s] = br[t % (PD + 1)][0];
+                            continue;
+                        }
+#endif
                         br[t % (PD + 1)][s] = l2[(c * G::TY2 + r) * PX2 + 4 * s];
                     }
                 };
@@ -433,6 +443,12 @@ __global__ __launch_bounds__(NW * RPE_WAVE) void corr_mfma_dma_kernel(const floa
 #pragma unroll
                         for (int ry = 0; ry < RY; ++ry) {
                             const int dy = r - ry;
+#if RPE_CORR_PROBE == 1  // energy probe (tools/corr_energy_probes.sh; WRONG results): a third of the matrix work, every operand read kept
+                            if (s != 1) {
+                                asm volatile("" ::"v"(br[t % (PD + 1)][s]));
+                                continue;
+                            }
+#endif
                             if (dy >= 0 && dy < ND)
                                 acc[ry][dy][s] = __builtin_amdgcn_mfma_f32_4x4x1f32(ar[c & 1][ry], br[t % (PD + 1)][s], acc[ry][dy][s], 0, 0, 0);
                         }
@@ -543,7 +559,11 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
     } else if (algo == 4 || algo == 7) {
         if (md != MD || B > 65535 || W % 4 != 0 || !aligned) return RPE_EUNSUPPORTED;
         int rc = algo == 4 ? launch_mfma_dma<2, 4, 4, 3, 4, true>(in1, in2, B, C, H, W, leaky_slope, out, st)
+#if RPE_CORR_PROBE >= 3 && RPE_CORR_PROBE <= 5  // ring depth probes: 4 / 5 / 6 slots instead of 3 (tools/corr_energy_probes.sh)
+                           : launch_mfma_dma<2, 8, 2, RPE_CORR_PROBE + 1, 3, true>(in1, in2, B, C, H, W, leaky_slope, out, st);
+#else
                            : launch_mfma_dma<2, 8, 2, 3, 3, true>(in1, in2, B, C, H, W, leaky_slope, out, st);
+#endif
         if (rc) return rc;
     } else if (algo == 3) {  // small maps: 64 flattened pixels x one displacement row a workgroup, the channels split over its waves
         if (md > 4 || B > 65535) return RPE_EUNSUPPORTED;

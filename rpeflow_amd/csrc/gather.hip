@@ -41,12 +41,17 @@ __global__ __launch_bounds__(256) void gather_cl_kernel(const float *__restrict_
 
 // knn_interpolation (utils.py:140-156) after the KNN: inverse-distance weights of the
 // k neighbours, w_j = 1/max(||p_j - q||_2, 1e-8), normalised, weighted feature sum.
+// Features: channels [0, Ca) from `feat`, [Ca, C) from `feat_b` (the decoder interpolates [flow | flow features] of the coarser
+// level, RPEFlow_core.py:352: two tensors, never concatenated); `residual` (or NULL): added to the result, fl(residual + sum)
+// (backwarp_3d's "xyz2 + flow21", utils.py:169).
 template <int KMAX>
 __global__ __launch_bounds__(256) void knn_interp_kernel(const float *__restrict__ in_xyz, int64_t x_sb, int64_t x_sd, int64_t x_sn,
-                                                         const float *__restrict__ feat, int64_t f_sb, int64_t f_sc, int64_t f_sn,
+                                                         const float *__restrict__ feat, int64_t f_sb, int64_t f_sc, int64_t f_sn, int Ca,
+                                                         const float *__restrict__ feat_b, int64_t g_sb, int64_t g_sc, int64_t g_sn,
                                                          const float *__restrict__ q_xyz, int64_t q_sb, int64_t q_sd, int64_t q_sn,
                                                          const int64_t *__restrict__ knn, int64_t k_sq, int k, int C, int Q,
-                                                         float negate, int cpb, float *__restrict__ out) {
+                                                         float negate, int cpb, const float *__restrict__ residual, int64_t r_sb, int64_t r_sc,
+                                                         int64_t r_sn, float *__restrict__ out) {
     // a thread: one query, cpb channels (blockIdx.y): with one thread per query and all channels in its loop the small
     // levels ran 256-1024 threads on the whole chip, 15-25 us of dependent gathers for a few MB
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -71,14 +76,18 @@ __global__ __launch_bounds__(256) void knn_interp_kernel(const float *__restrict
 #pragma unroll
     for (int j = 0; j < KMAX; ++j)
         if (j < k) w[j] = w[j] / wsum;
-    const float *fb = feat + (int64_t)b * f_sb;
+    const float *fa = feat + (int64_t)b * f_sb, *fg = feat_b ? feat_b + (int64_t)b * g_sb : nullptr;
     const int c0 = blockIdx.y * cpb, c1 = min(C, c0 + cpb);
 #pragma unroll 4
     for (int c = c0; c < c1; ++c) {
+        const bool first = c < Ca;
+        const float *plane = first ? fa + (int64_t)c * f_sc : fg + (int64_t)(c - Ca) * g_sc;
+        const int64_t sn = first ? f_sn : g_sn;
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < KMAX; ++j)
-            if (j < k) s += (negate * fb[(int64_t)c * f_sc + id[j] * f_sn]) * w[j];
+            if (j < k) s += (negate * plane[id[j] * sn]) * w[j];
+        if (residual) s = residual[(int64_t)b * r_sb + (int64_t)c * r_sc + (int64_t)q * r_sn] + s;
         out[((int64_t)b * C + c) * Q + q] = s;
     }
 }
@@ -120,6 +129,15 @@ struct Bilinear {
         acc = acc + v_se * w_se;
         return acc;
     }
+    // the same on the map (plane * scale): every tap rounded once more, as reading the caller's scaled tensor would
+    __device__ __forceinline__ float sample_scaled(const float *plane, float scale) const {
+        const float v_nw = o_nw >= 0 ? plane[o_nw] * scale : 0.f, v_ne = o_ne >= 0 ? plane[o_ne] * scale : 0.f;
+        const float v_sw = o_sw >= 0 ? plane[o_sw] * scale : 0.f, v_se = o_se >= 0 ? plane[o_se] * scale : 0.f;
+        float acc = v_nw * w_nw + v_ne * w_ne;
+        acc = acc + v_sw * w_sw;
+        acc = acc + v_se * w_se;
+        return acc;
+    }
 };
 
 // Workgroup -> (channel block, position block) for the kernels that GATHER from channel planes at scattered positions.
@@ -136,10 +154,20 @@ __device__ __forceinline__ bool xcd_block(int ncb, int &cb, int &pb) {
 }
 static inline unsigned xcd_grid(int ncb, int npb) { return (unsigned)(((ncb + 7) >> 3) * 8 * npb); }
 
-// out[b][c][p] = bilinear(feat[b][c], (gx,gy)[b][p]);  add_grid: coordinates are
+// out[b][c][p] = bilinear(map[b][c], (gx,gy)[b][p]);  add_grid: coordinates are
 // pixel (p % W, p / W) + flow  (backwarp_2d, utils.py:186-198); otherwise xy as given
 // (grid_sample_wrapper, utils.py:288-294).
-__global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__ feat, int C, int H, int W,
+// The map is the channel-wise concatenation of up to RPE_SAMPLE_MAX_SOURCES tensors of one H x W (rpe_sample_source), which is
+// never built: the 3-D correlation fuser samples [cost volume | flow in sensor units] and the event features at the same points
+// and concatenates the results (RPEFlow_core.py:105-111).  A source's taps are multiplied by its per-channel-parity scale as
+// they are read -- fl(tap * s), what sampling the caller's "flow * scale" tensor reads -- and `subtract` comes off its result.
+struct SampleSources {
+    rpe_sample_source src[RPE_SAMPLE_MAX_SOURCES];
+    int first[RPE_SAMPLE_MAX_SOURCES + 1];  // first output channel of every source; first[n] = C
+    int n;
+};
+
+__global__ __launch_bounds__(256) void bilinear_kernel(SampleSources S, int C, int H, int W,
                                                        const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sp,
                                                        int P, int add_grid, int border, int c_per_block, int xcd_map,
                                                        float *__restrict__ out) {
@@ -158,18 +186,34 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const float *__restrict__
     }
     Bilinear bl;
     bl.setup(gx, gy, H, W, border != 0);
-    const int64_t HW = (int64_t)H * W;
     const int c0 = cb * c_per_block, c1 = min(C, c0 + c_per_block);
-    // four channels per trip: 16 independent gathered loads in flight instead of 4
     int c = c0;
-    for (; c + 4 <= c1; c += 4) {
-        float v[4];
+    while (c < c1) {
+        int si = 0;
+        while (si + 1 < S.n && c >= S.first[si + 1]) ++si;  // (wave-uniform: c is)
+        const rpe_sample_source &src = S.src[si];
+        const int ce = min(c1, S.first[si + 1]);
+        const float *base = src.data + (int64_t)b * src.sb + (int64_t)(c - S.first[si]) * src.sc;
+        const bool plain = src.scale_even == 1.0f && src.scale_odd == 1.0f && !src.subtract;
+        if (plain) {
+            // four channels per trip: 16 independent gathered loads in flight instead of 4
+            for (; c + 4 <= ce; c += 4, base += 4 * src.sc) {
+                float v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = bl.sample(feat + ((int64_t)b * C + c + u) * HW);
+                for (int u = 0; u < 4; ++u) v[u] = bl.sample(base + (int64_t)u * src.sc);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) out[((int64_t)b * C + c + u) * P + p] = v[u];
+                for (int u = 0; u < 4; ++u) out[((int64_t)b * C + c + u) * P + p] = v[u];
+            }
+            for (; c < ce; ++c, base += src.sc) out[((int64_t)b * C + c) * P + p] = bl.sample(base);
+        } else {
+            for (; c < ce; ++c, base += src.sc) {
+                const int lc = c - S.first[si];
+                float v = bl.sample_scaled(base, (lc & 1) ? src.scale_odd : src.scale_even);
+                if (src.subtract) v = v - src.subtract[(int64_t)b * src.sub_sb + (int64_t)lc * src.sub_sc + (int64_t)p * src.sub_sp];
+                out[((int64_t)b * C + c) * P + p] = v;
+            }
+        }
     }
-    for (; c < c1; ++c) out[((int64_t)b * C + c) * P + p] = bl.sample(feat + ((int64_t)b * C + c) * HW);
 }
 
 // Coarse-to-fine hand-over of the 2-D decoder (RPEFlow_core.py:364-369 / pwc2d_core usage): the coarser level's flow (times
@@ -243,9 +287,25 @@ __global__ __launch_bounds__(256) void resize_frames_kernel(const T *__restrict_
 // The reference samples per point too (grid_sample_wrapper over all N points, utils.py:308) and then
 // gathers per pixel; sampling per pixel instead would repeat the 4-corner fetch ~HW/N = 8 times.
 // A pixel's gather is one contiguous row here instead of C2+C3 strided reads.
+// feat_3d of project_feat_with_nn_corr as up to two tensors: channels [0, Ca) from `a`, [Ca, C3) from `b` times a per-channel-parity
+// scale -- the 2-D correlation fuser projects [3-D cost volume | 3-D flow's xy in feature-map units] (RPEFlow_core.py:371-373: two
+// in-place muls and a cat there), which is never concatenated here.
+struct Feat3 {
+    const float *a;
+    int64_t a_sb, a_sc, a_sn;
+    int Ca;
+    const float *b;
+    int64_t b_sb, b_sc, b_sn;
+    float s_even, s_odd;
+    __device__ __forceinline__ float at(int batch, int c, int i) const {
+        if (c < Ca) return a[(int64_t)batch * a_sb + (int64_t)c * a_sc + (int64_t)i * a_sn];
+        const int lc = c - Ca;
+        return b[(int64_t)batch * b_sb + (int64_t)lc * b_sc + (int64_t)i * b_sn] * ((lc & 1) ? s_odd : s_even);
+    }
+};
+
 __global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict__ xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn,
-                                                         const float *__restrict__ feat2d, int C2, int H, int W,
-                                                         const float *__restrict__ feat3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn,
+                                                         const float *__restrict__ feat2d, int C2, int H, int W, Feat3 F3,
                                                          int C3, int N, int c_per_block, const float *__restrict__ sampled,
                                                          int64_t sm_sb, int64_t sm_sc, int64_t sm_sn, float *__restrict__ rows) {
     const int CT = C2 + C3;
@@ -286,18 +346,17 @@ __global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict
         }
         for (; c < ce; ++c) row[c] = bl.sample(f2 + (int64_t)c * HW);
     }
-    const float *f3 = feat3d + (int64_t)b * f3_sb + (int64_t)i * f3_sn;
     {
         float *row3 = row + C2p - C2;  // logical channel c >= C2 lives at row[C2p + (c - C2)]
         int c = max(c0, C2);
         for (; c + 8 <= c1; c += 8) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = f3[(int64_t)(c + u - C2) * f3_sc];
+            for (int u = 0; u < 8; ++u) v[u] = F3.at(b, c + u - C2, i);
 #pragma unroll
             for (int u = 0; u < 8; ++u) row3[c + u] = v[u];
         }
-        for (; c < c1; ++c) row3[c] = f3[(int64_t)(c - C2) * f3_sc];
+        for (; c < c1; ++c) row3[c] = F3.at(b, c - C2, i);
     }
 }
 
@@ -306,8 +365,7 @@ __global__ __launch_bounds__(256) void point_rows_kernel(const float *__restrict
 // workgroup takes PB consecutive points, reads every plane's PB values as one coalesced segment, turns the tile in LDS
 // (odd pitch: no bank conflicts) and writes the PB rows -- contiguous in memory -- as float4.
 __global__ __launch_bounds__(256) void point_rows_copy_kernel(const float *__restrict__ sampled, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
-                                                              int C2, const float *__restrict__ feat3d, int64_t f3_sb, int64_t f3_sc,
-                                                              int64_t f3_sn, int C3, int N, int PB, float *__restrict__ rows) {
+                                                              int C2, Feat3 F3, int C3, int N, int PB, float *__restrict__ rows) {
     extern __shared__ float tile[];
     const int C2p = (C2 + 3) & ~3, C3p = (C3 + 3) & ~3, RS = C2p + C3p, RP = RS | 1;
     const int b = blockIdx.y, i0 = blockIdx.x * PB;
@@ -329,11 +387,10 @@ __global__ __launch_bounds__(256) void point_rows_copy_kernel(const float *__res
             for (int c = C2; c < C2p; ++c) mine[c] = 0.f;
     }
     if (C3 > 0) {
-        const float *f3 = feat3d + (int64_t)b * f3_sb + (int64_t)i * f3_sn;
         for (int c = g; c < C3; c += G * CU) {
             float v[CU];
 #pragma unroll
-            for (int u = 0; u < CU; ++u) v[u] = f3[(int64_t)min(c + u * G, C3 - 1) * f3_sc];
+            for (int u = 0; u < CU; ++u) v[u] = F3.at(b, min(c + u * G, C3 - 1), i);
 #pragma unroll
             for (int u = 0; u < CU; ++u)
                 if (c + u * G < C3) mine[C2p + c + u * G] = v[u];
@@ -616,29 +673,41 @@ RPE_API int rpe_gather_channel_last(const float *data, int64_t sb, int64_t sn, i
 }
 
 RPE_API int rpe_knn_interpolate(const float *in_xyz, int64_t x_sb, int64_t x_sd, int64_t x_sn, const float *feat, int64_t f_sb,
-                                int64_t f_sc, int64_t f_sn, const float *q_xyz, int64_t q_sb, int64_t q_sd, int64_t q_sn,
-                                const int64_t *knn, int64_t knn_row_stride, int B, int M, int Q, int C, int k, float scale,
+                                int64_t f_sc, int64_t f_sn, int C, const float *feat_b, int64_t g_sb, int64_t g_sc, int64_t g_sn, int C_b,
+                                const float *q_xyz, int64_t q_sb, int64_t q_sd, int64_t q_sn, const int64_t *knn, int64_t knn_row_stride,
+                                int B, int M, int Q, int k, float scale, const float *residual, int64_t r_sb, int64_t r_sc, int64_t r_sn,
                                 float *out, rpe_stream_t stream) {
-    if (!in_xyz || !feat || !q_xyz || !knn || !out || B < 0 || M <= 0 || Q < 0 || C < 0 || k < 1) return RPE_EINVAL;
+    if (!in_xyz || !feat || !q_xyz || !knn || !out || B < 0 || M <= 0 || Q < 0 || C < 0 || C_b < 0 || k < 1 || (C_b > 0 && !feat_b)) return RPE_EINVAL;
     if (k > 8) return RPE_EUNSUPPORTED;
-    if (B == 0 || Q == 0 || C == 0) return 0;
+    const int CT = C + C_b;
+    if (B == 0 || Q == 0 || CT == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
-    const int cpb = channel_split(C, Q, B);
-    dim3 grid((Q + 255) / 256, (C + cpb - 1) / cpb, B);
+    const int cpb = channel_split(CT, Q, B);
+    dim3 grid((Q + 255) / 256, (CT + cpb - 1) / cpb, B);
     hipStream_t st = (hipStream_t)stream;
     if (k <= 3)
-        hipLaunchKernelGGL(knn_interp_kernel<3>, grid, dim3(256), 0, st, in_xyz, x_sb, x_sd, x_sn, feat, f_sb, f_sc, f_sn, q_xyz,
-                           q_sb, q_sd, q_sn, knn, knn_row_stride, k, C, Q, scale, cpb, out);
+        hipLaunchKernelGGL(knn_interp_kernel<3>, grid, dim3(256), 0, st, in_xyz, x_sb, x_sd, x_sn, feat, f_sb, f_sc, f_sn, C, C_b > 0 ? feat_b : nullptr,
+                           g_sb, g_sc, g_sn, q_xyz, q_sb, q_sd, q_sn, knn, knn_row_stride, k, CT, Q, scale, cpb, residual, r_sb, r_sc, r_sn, out);
     else
-        hipLaunchKernelGGL(knn_interp_kernel<8>, grid, dim3(256), 0, st, in_xyz, x_sb, x_sd, x_sn, feat, f_sb, f_sc, f_sn, q_xyz,
-                           q_sb, q_sd, q_sn, knn, knn_row_stride, k, C, Q, scale, cpb, out);
+        hipLaunchKernelGGL(knn_interp_kernel<8>, grid, dim3(256), 0, st, in_xyz, x_sb, x_sd, x_sn, feat, f_sb, f_sc, f_sn, C, C_b > 0 ? feat_b : nullptr,
+                           g_sb, g_sc, g_sn, q_xyz, q_sb, q_sd, q_sn, knn, knn_row_stride, k, CT, Q, scale, cpb, residual, r_sb, r_sc, r_sn, out);
     return rpe_launch_status();
 }
 
-RPE_API int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W, const float *xy, int64_t xy_sb, int64_t xy_sd,
-                                int64_t xy_sp, int P, int add_pixel_grid, int border, float *out, rpe_stream_t stream) {
-    if (!feat || !xy || !out || B < 0 || C < 0 || H < 1 || W < 1 || P < 0) return RPE_EINVAL;
+RPE_API int rpe_bilinear_sample(const rpe_sample_source *sources, int n_sources, int B, int H, int W, const float *xy, int64_t xy_sb,
+                                int64_t xy_sd, int64_t xy_sp, int P, int add_pixel_grid, int border, float *out, rpe_stream_t stream) {
+    if (!sources || n_sources < 1 || n_sources > RPE_SAMPLE_MAX_SOURCES || !xy || !out || B < 0 || H < 1 || W < 1 || P < 0) return RPE_EINVAL;
     if (add_pixel_grid && P != H * W) return RPE_EINVAL;
+    SampleSources S{};
+    S.n = n_sources;
+    int C = 0;
+    for (int i = 0; i < n_sources; ++i) {
+        if (sources[i].channels < 0 || (sources[i].channels > 0 && !sources[i].data)) return RPE_EINVAL;
+        S.src[i] = sources[i];
+        S.first[i] = C;
+        C += sources[i].channels;
+    }
+    for (int i = n_sources; i <= RPE_SAMPLE_MAX_SOURCES; ++i) S.first[i] = C;
     if (B == 0 || C == 0 || P == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
     int cpb = channel_split(C, P, B);
@@ -652,8 +721,48 @@ RPE_API int rpe_bilinear_sample(const float *feat, int B, int C, int H, int W, c
         cpb = (C + ncb - 1) / ncb;
         grid = dim3(xcd_grid((C + cpb - 1) / cpb, (P + 255) / 256), 1, B);
     }
-    hipLaunchKernelGGL(bilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, feat, C, H, W, xy, xy_sb, xy_sd, xy_sp, P,
+    hipLaunchKernelGGL(bilinear_kernel, grid, dim3(256), 0, (hipStream_t)stream, S, C, H, W, xy, xy_sb, xy_sd, xy_sp, P,
                        add_pixel_grid, border, cpb, xcd_map, out);
+    return rpe_launch_status();
+}
+
+// project_pc2image (utils.py:260-285) + the sensor -> feature-map rescale of RPEFlow_core.py:316-324 for both frames' clouds in one
+// launch: out[(f * B + b)][0][i] = fl(fl(x + cx) * sx)  ('parallel': cx, cy scalars) or fl(fl(cx_b + fl(fl(f_b / z) * x)) * sx)
+// ('perspective': per-sample f, cx, cy), y likewise.  The reference: 2 x (two adds or div / mul / add pairs, a cat, two in-place muls).
+__global__ __launch_bounds__(256) void project_points_kernel(const float *__restrict__ xyz_a, int64_t a_sb, int64_t a_sd, int64_t a_sn,
+                                                             const float *__restrict__ xyz_b, int64_t b_sb, int64_t b_sd, int64_t b_sn, int B,
+                                                             int N, const float *__restrict__ intr, int64_t intr_sb, float cx, float cy, float sx,
+                                                             float sy, float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int cloud = blockIdx.y;  // frame-major: [0, B) the first tensor's samples, [B, 2B) the second's
+    if (i >= N) return;
+    const bool second = cloud >= B;
+    const int b = second ? cloud - B : cloud;
+    const float *p = second ? xyz_b + (int64_t)b * b_sb + (int64_t)i * b_sn : xyz_a + (int64_t)b * a_sb + (int64_t)i * a_sn;
+    const int64_t sd = second ? b_sd : a_sd;
+    const float x = p[0], y = p[sd];
+    float u, v;
+    if (intr) {
+        const float f = intr[(int64_t)b * intr_sb], icx = intr[(int64_t)b * intr_sb + 1], icy = intr[(int64_t)b * intr_sb + 2];
+        const float fz = f / p[2 * sd];
+        u = icx + fz * x;
+        v = icy + fz * y;
+    } else {
+        u = x + cx;
+        v = y + cy;
+    }
+    out[((int64_t)cloud * 2) * N + i] = u * sx;
+    out[((int64_t)cloud * 2 + 1) * N + i] = v * sy;
+}
+
+RPE_API int rpe_project_points(const float *xyz_a, int64_t a_sb, int64_t a_sd, int64_t a_sn, const float *xyz_b, int64_t b_sb, int64_t b_sd,
+                               int64_t b_sn, int B, int N, const float *intrinsics, int64_t intr_sb, float cx, float cy, float scale_x,
+                               float scale_y, float *out, rpe_stream_t stream) {
+    if (!xyz_a || !out || B < 0 || N < 0) return RPE_EINVAL;
+    if (B == 0 || N == 0) return 0;
+    if (2 * B > 65535) return RPE_EUNSUPPORTED;
+    hipLaunchKernelGGL(project_points_kernel, dim3((N + 255) / 256, xyz_b ? 2 * B : B), dim3(256), 0, (hipStream_t)stream, xyz_a, a_sb, a_sd, a_sn,
+                       xyz_b, b_sb, b_sd, b_sn, B, N, intrinsics, intr_sb, cx, cy, scale_x, scale_y, out);
     return rpe_launch_status();
 }
 
@@ -699,11 +808,15 @@ RPE_API int rpe_upsample2x_pair(const float *a, int Ca, float scale_a, const flo
 
 RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
                                            int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
-                                           const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3,
-                                           const int64_t *nn_idx, const float *subtract, int n_subtract, const float *append, int n_append,
-                                           int B, int N, float *workspace, float *out, rpe_stream_t stream) {
-    if (!xy || !feat_2d || !feat_3d || !nn_idx || !out || !workspace || B < 0 || C2 < 1 || C3 < 0 || H < 1 || W < 1 || N < 1)
+                                           const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3a,
+                                           const float *feat_3d_b, int64_t g3_sb, int64_t g3_sc, int64_t g3_sn, int C3b, float scale_even,
+                                           float scale_odd, const int64_t *nn_idx, const float *subtract, int n_subtract, const float *append,
+                                           int n_append, int B, int N, float *workspace, float *out, rpe_stream_t stream) {
+    const int C3 = C3a + C3b;
+    if (!xy || !feat_2d || !nn_idx || !out || !workspace || B < 0 || C2 < 1 || C3a < 0 || C3b < 0 || H < 1 || W < 1 || N < 1 ||
+        (C3a > 0 && !feat_3d) || (C3b > 0 && !feat_3d_b))
         return RPE_EINVAL;
+    const Feat3 F3{feat_3d, f3_sb, f3_sc, f3_sn, C3a, feat_3d_b, g3_sb, g3_sc, g3_sn, scale_even, scale_odd};
     if (n_subtract < 0 || n_subtract > C3 || n_append < 0 || (n_subtract > 0 && !subtract) || (n_append > 0 && !append)) return RPE_EINVAL;
     if (reinterpret_cast<uintptr_t>(workspace) & 15) return RPE_EINVAL;
     if (B == 0) return 0;
@@ -713,11 +826,11 @@ RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_
     const int PB = 32;  // points per workgroup: 512 workgroups at level 1, 10.0 us (64 points: 10.9; one thread per point and slice: 14.5)
     if (sampled_2d && PB * RP * 4 <= 64 * 1024) {
         hipLaunchKernelGGL(point_rows_copy_kernel, dim3((N + PB - 1) / PB, B), dim3(256), (size_t)PB * RP * sizeof(float), st, sampled_2d, sm_sb,
-                           sm_sc, sm_sn, C2, feat_3d, f3_sb, f3_sc, f3_sn, C3, N, PB, workspace);
+                           sm_sc, sm_sn, C2, F3, C3, N, PB, workspace);
     } else {
         const int cpb = 8;  // channels per thread: 32-byte row segments, (C2+C3)/8 times the threads
         hipLaunchKernelGGL(point_rows_kernel, dim3(xcd_grid((C2 + C3 + cpb - 1) / cpb, (N + 255) / 256), 1, B), dim3(256), 0, st, xy, xy_sb,
-                           xy_sd, xy_sn, feat_2d, C2, H, W, feat_3d, f3_sb, f3_sc, f3_sn, C3, N, cpb, sampled_2d, sm_sb, sm_sc, sm_sn, workspace);
+                           xy_sd, xy_sn, feat_2d, C2, H, W, F3, C3, N, cpb, sampled_2d, sm_sb, sm_sc, sm_sn, workspace);
     }
     if ((int64_t)B * H * W <= 16384) {  // the coarse levels (up to 36 x 60 at batch 4): channels split over eight waves
         hipLaunchKernelGGL(project_rows_small_kernel<8>, dim3((H * W + 63) / 64, B), dim3(8 * 64), 0, st, xy, xy_sb, xy_sd, xy_sn, feat_2d, C2,

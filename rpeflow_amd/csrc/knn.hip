@@ -1523,8 +1523,11 @@ __global__ __launch_bounds__(256) void sqdist_kernel(const float *__restrict__ a
     out[((int64_t)b * N1 + i) * N2 + j] = rpe_pair_dist<D>(qm2, qq, p, pp);
 }
 
+#ifndef RPE_KNN_WAVE_TARGET
+#define RPE_KNN_WAVE_TARGET 2048
+#endif
 int pick_qw(int B, int Q) {
-    const long target = 2048;  // waves wanted in flight: 256 CUs x 4 SIMDs x 2 (1024 ... 4096 measure the same; 8192 and more are slower)
+    const long target = RPE_KNN_WAVE_TARGET;  // waves wanted in flight: 256 CUs x 4 SIMDs x 2 (1024 ... 4096 measure the same; 8192 and more are slower)
     for (int qw = 8; qw > 1; qw >>= 1)
         if ((long)B * ((Q + qw - 1) / qw) >= target) return qw;
     return 1;
@@ -1626,8 +1629,11 @@ int launch_group(const rpe_knn_job *const *jobs, char *const *ws, int njobs, boo
 }
 
 // which kernels take a search (the same rules size the workspace)
-bool takes_matrix(int B, int M, int Q, int k) {
-    return k < RPE_WAVE && M >= kMatrixMinM && (long)M >= 64L * k && (long)B * Q >= kMatrixMinQueries;
+bool takes_matrix(int B, int M, int Q, int k, int mode = 0) {
+    if (mode & RPE_KNN_ALGO_INSERT) return false;
+    const bool can = k < RPE_WAVE && (long)M >= 64L * k && M >= 4 * RPE_WAVE;  // topk's partial_sort regime; one ring chunk of points
+    if (mode & RPE_KNN_ALGO_MATRIX) return can;
+    return can && M >= kMatrixMinM && (long)B * Q >= kMatrixMinQueries;
 }
 // the binned nearest-point search (knn_binned.hip: k = 1, D = 2) against the sweeps -- two launches (8 us to bin the clouds),
 // then waves that meet ~50 points instead of the whole cloud.  Kernel time, both frames of a batch of 4: 4096 points /
@@ -1638,7 +1644,7 @@ int64_t job_workspace_bytes(int B, int M, int Q, int D, int k, int mode) {
     if (B <= 0 || M <= 0 || Q <= 0) return 0;
     if (D == 2 && k == 1 && M >= 64 && ((mode & RPE_KNN_ALGO_BINNED) || (takes_binned(B, M, Q, D, k) && !(mode & RPE_KNN_ALGO_SWEEP))))
         return rpe_nearest2d_workspace_bytes(B, M);
-    if (k >= 2 && takes_matrix(B, M, Q, k) && (mode & 3) != RPE_KNN_TIES_INDEX && M <= kReplayMaxM) {
+    if (k >= 2 && takes_matrix(B, M, Q, k, mode) && (mode & 3) != RPE_KNN_TIES_INDEX && M <= kReplayMaxM) {
         const int64_t nblk = (int64_t)B * ((Q + kWavesPerBlock * kMq - 1) / (kWavesPerBlock * kMq));
         if (nblk <= kReplayMaxBlocks) return ((((nblk + 3) & ~3ll) + nblk * (kWavesPerBlock * kMq)) * 4 + 15) & ~15ll;
     }
@@ -1653,7 +1659,8 @@ RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int 
                           rpe_stream_t stream) {
     if (!jobs || njobs < 1 || njobs > RPE_KNN_MAX_JOBS || B < 0 || D < 1 || D > 3 || k < 1) return RPE_EINVAL;
     const int tie_mode = mode & 3;
-    if ((mode & ~(3 | RPE_KNN_ALGO_SWEEP | RPE_KNN_ALGO_BINNED)) || tie_mode == 2 || ((mode & RPE_KNN_ALGO_SWEEP) && (mode & RPE_KNN_ALGO_BINNED)))
+    if ((mode & ~(3 | RPE_KNN_ALGO_SWEEP | RPE_KNN_ALGO_BINNED | RPE_KNN_ALGO_MATRIX | RPE_KNN_ALGO_INSERT)) || tie_mode == 2 ||
+        ((mode & RPE_KNN_ALGO_SWEEP) && (mode & RPE_KNN_ALGO_BINNED)) || ((mode & RPE_KNN_ALGO_MATRIX) && (mode & RPE_KNN_ALGO_INSERT)))
         return RPE_EINVAL;
     if (k > RPE_WAVE) return RPE_EUNSUPPORTED;
     if (B > 65535) return RPE_EUNSUPPORTED;
@@ -1677,7 +1684,7 @@ RPE_API int rpe_knn_multi(const rpe_knn_job *jobs, int njobs, int B, int D, int 
         if ((mode & RPE_KNN_ALGO_BINNED) && B > 0 && j.Q > 0 && !(want_binned && mine)) return (D == 2 && k == 1 && j.M >= 64) ? RPE_EINVAL : RPE_EUNSUPPORTED;
         if (want_binned && mine) {
             binned[nbinned] = &j, binned_ws[nbinned++] = mine;
-        } else if (takes_matrix(B, j.M, j.Q, k)) {
+        } else if (takes_matrix(B, j.M, j.Q, k, mode)) {
             big[nbig] = &j, big_ws[nbig++] = mine;
             all_big_ws = all_big_ws && mine;
         } else {

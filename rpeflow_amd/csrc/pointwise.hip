@@ -30,6 +30,7 @@ struct PwArgs {
     int Cin, Cout, ktiles, n_otiles, act;
     int64_t P, x_bstride, w_bstride;  // floats between samples of x; between per-sample weights (0: one weight for all)
     float slope;
+    int64_t res_bstride;  // floats between samples of res (Cout * P for a dense tensor; larger for a channel slice of a wider one)
 };
 
 template <int OT, bool VEC>
@@ -95,16 +96,17 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(PwArgs a) {
                 v[t] = a.act == 1 ? fmaxf(u, 0.f) : (a.act == 2 ? (u >= 0.f ? u : u * a.slope) : u);
             }
             const int64_t off = ((int64_t)b * a.Cout + oc) * P + p0;
+            const int64_t roff = (int64_t)b * a.res_bstride + (int64_t)oc * P + p0;
             if (VEC) {
                 if (a.res) {
-                    const float4 rr = *reinterpret_cast<const float4 *>(a.res + off);
+                    const float4 rr = *reinterpret_cast<const float4 *>(a.res + roff);
                     v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
                 }
                 *reinterpret_cast<float4 *>(a.y + off) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    if (p0 + t < P) a.y[off + t] = a.res ? v[t] + a.res[off + t] : v[t];
+                    if (p0 + t < P) a.y[off + t] = a.res ? v[t] + a.res[roff + t] : v[t];
             }
         }
     }
@@ -181,16 +183,17 @@ __global__ __launch_bounds__(256) void pointwise_conv_ksplit_kernel(PwArgs a) {
             v[t] = a.act == 1 ? fmaxf(u, 0.f) : (a.act == 2 ? (u >= 0.f ? u : u * a.slope) : u);
         }
         const int64_t off = ((int64_t)b * a.Cout + oc) * P + p0;
+        const int64_t roff = (int64_t)b * a.res_bstride + (int64_t)oc * P + p0;
         if (VEC) {
             if (a.res) {
-                const float4 rr = *reinterpret_cast<const float4 *>(a.res + off);
+                const float4 rr = *reinterpret_cast<const float4 *>(a.res + roff);
                 v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
             }
             *reinterpret_cast<float4 *>(a.y + off) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                if (p0 + t < P) a.y[off + t] = a.res ? v[t] + a.res[off + t] : v[t];
+                if (p0 + t < P) a.y[off + t] = a.res ? v[t] + a.res[roff + t] : v[t];
         }
     }
 }
@@ -207,13 +210,13 @@ int launch_pw(const PwArgs &a, int B, bool vec, hipStream_t st) {
 
 RPE_API int rpe_pointwise_conv(const float *x, int64_t x_batch_stride, int B, int Cin, int64_t P, const float *packed_weight,
                                int64_t weight_batch_stride, int Cout, const float *scale, const float *shift, int act, float slope,
-                               const float *residual, float *y, rpe_stream_t stream) {
+                               const float *residual, int64_t residual_batch_stride, float *y, rpe_stream_t stream) {
     if (!x || !packed_weight || !y || B < 0 || Cin < 1 || Cout < 1 || P < 0 || act < 0 || act > 2) return RPE_EINVAL;
-    if (x_batch_stride < (int64_t)Cin * P || weight_batch_stride < 0) return RPE_EINVAL;
+    if (x_batch_stride < (int64_t)Cin * P || weight_batch_stride < 0 || (residual && residual_batch_stride < (int64_t)Cout * P)) return RPE_EINVAL;
     if (B == 0 || P == 0) return 0;
     if (B > 65535) return RPE_EUNSUPPORTED;
-    PwArgs a{x, packed_weight, scale, shift, residual, y, Cin, Cout, (Cin + 3) / 4, (Cout + 15) / 16, act, P, x_batch_stride, weight_batch_stride, slope};
-    const bool vec = P % 4 == 0 && x_batch_stride % 4 == 0 &&
+    PwArgs a{x, packed_weight, scale, shift, residual, y, Cin, Cout, (Cin + 3) / 4, (Cout + 15) / 16, act, P, x_batch_stride, weight_batch_stride, slope, residual_batch_stride};
+    const bool vec = P % 4 == 0 && x_batch_stride % 4 == 0 && residual_batch_stride % 4 == 0 &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
     // output tiles per wave: enough workgroups to cover the chip on the small maps, fewer re-reads of x on the wider layers

@@ -126,8 +126,9 @@ class HotPathWorkload(torch.nn.Module):
         xy = torch.rand(batch, 2, n_points, generator=g) * torch.tensor([sw - 1.0, sh - 1.0])[None, :, None]
         xy = xy - torch.tensor([(sw - 1) / 2, (sh - 1) / 2])[None, :, None]
         z = 22.0 + 91.0 * torch.rand(batch, 1, n_points, generator=g)
-        self.pc1 = torch.cat([xy, z], 1).to(device).contiguous()
-        self.pc2 = (self.pc1 + rnd(batch, 3, n_points, scale=0.05)).contiguous()
+        pc1 = torch.cat([xy, z], 1).to(device)
+        self.pc_both = torch.cat([pc1, pc1 + rnd(batch, 3, n_points, scale=0.05)], 0).contiguous()  # [2B,3,N] as the IDS transform returns the clouds
+        self.pc1, self.pc2 = self.pc_both[:batch], self.pc_both[batch:]
 
         self.feats_2d_both = [rnd(2 * batch, c, h, w) for c, (h, w) in zip(PYRAMID_2D, self.sizes)]  # frame 1 then frame 2
         self.feats1_2d = [f[:batch] for f in self.feats_2d_both]
@@ -145,6 +146,10 @@ class HotPathWorkload(torch.nn.Module):
             grid = torch.stack([gx[None, :].expand(h, w), gy[:, None].expand(h, w)]).reshape(1, 2, -1)
             self.grid.append(grid.to(device).expand(batch, 2, h * w))
         self.grid_both = [g[:1].expand(2 * batch, 2, g.shape[2]) for g in self.grid]
+        self.camera = {"projection_mode": "parallel", "cx": (sw - 1) / 2, "cy": (sh - 1) / 2, "sensor_h": sh, "sensor_w": sw}
+        self.scale_xy = [((w - 1) / (sw - 1), (h - 1) / (sh - 1)) for (h, w) in self.sizes]
+        self.zero_flow_3d = torch.zeros(batch, 3, N_SAMPLES[-1], device=device)
+        self.zero_flow_feat_3d = torch.zeros(batch, 64, N_SAMPLES[-1], device=device)
 
         torch.manual_seed(seed)
         self.feature_pyramid_3d = ops.FeaturePyramid3D(PYRAMID_3D, norm="batch_norm", k=16)
@@ -165,14 +170,23 @@ class HotPathWorkload(torch.nn.Module):
         knn_interpolation, project_feat_with_nn_corr = o.knn_interpolation, o.project_feat_with_nn_corr
         import inspect
         shares = "sampled_2d" in inspect.signature(project_feat_with_nn_corr).parameters
+        if shares:
+            from .utils import conv_module, grid_sample_sources, project_points
         sh, sw = self.sensor
-        with t.span("fps+pyramid"):
-            xyzs1, xyzs2, _, _ = build_pc_pyramid(self.pc1, self.pc2, N_SAMPLES)
         # Frames 1 and 2 go through the shared-weight 3-D pyramid and the pyramid fusers' hot-path calls as ONE batch of 2B
         # clouds / maps, as rpeflow_amd.model does (the reference calls them once per frame, RPEFlow.py:78-79,
-        # RPEFlow_core.py:329-337; per-sample operators make the two forms equal sample by sample).
+        # RPEFlow_core.py:329-337; per-sample operators make the two forms equal sample by sample).  With the native operators
+        # (``shares``) the calls are the ones rpeflow_amd.model makes: the glue the reference puts between its operators
+        # (concatenations, scalings, the flow heads' adds) rides inside the launches; a CPU port passed as ``ops`` keeps the
+        # reference's calls.
+        with t.span("fps+pyramid"):
+            if shares:
+                xyzs1, xyzs2, _, _, xyzs_both = build_pc_pyramid(self.pc1, self.pc2, N_SAMPLES, return_both=True)
+            else:
+                xyzs1, xyzs2, _, _ = build_pc_pyramid(self.pc1, self.pc2, N_SAMPLES)
+                xyzs_both = [torch.cat([a, b], 0) for a, b in zip(xyzs1, xyzs2)]
         with t.span("feature_pyramid_3d"):
-            feats_both = self.feature_pyramid_3d([torch.cat([a, b], 0) for a, b in zip(xyzs1, xyzs2)])
+            feats_both = self.feature_pyramid_3d(xyzs_both)
             feats1_3d, feats2_3d = [f[:B] for f in feats_both], [f[B:] for f in feats_both]
 
         flows_3d, flow_feats_3d = [], []
@@ -185,8 +199,11 @@ class HotPathWorkload(torch.nn.Module):
             n = xyz1.shape[-1]
             scale, centre, grid = self.scale[level], self.centre[level], self.grid[level]
             f_2d_both, f_3d_both = self.feats_2d_both[level], feats_both[level]
-            with t.span("torch_glue"):
-                xy_both = (torch.cat([xyz1[:, :2], xyz2[:, :2]], 0) + centre) * scale  # project_pc2image 'parallel' + rescale (RPEFlow_core.py:316-324)
+            with t.span("torch_glue"):  # project_pc2image 'parallel' + rescale (RPEFlow_core.py:316-324)
+                if shares:
+                    xy_both = project_points(xyz1, xyz2, self.camera, self.scale_xy[level][0], self.scale_xy[level][1])
+                else:
+                    xy_both = (torch.cat([xyz1[:, :2], xyz2[:, :2]], 0) + centre) * scale
                 xy1 = xy_both[:B]
 
             with t.span("knn2d_k1"):
@@ -205,16 +222,18 @@ class HotPathWorkload(torch.nn.Module):
 
             if level == 5:
                 with t.span("torch_glue"):
-                    last_flow_3d = torch.zeros(B, 3, n, device=xyz1.device)
-                    last_flow_feat_3d = torch.zeros(B, 64, n, device=xyz1.device)
+                    if shares:  # constants, as rpeflow_amd.model keeps them
+                        last_flow_3d, last_flow_feat_3d = self.zero_flow_3d, self.zero_flow_feat_3d
+                    else:
+                        last_flow_3d = torch.zeros(B, 3, n, device=xyz1.device)
+                        last_flow_feat_3d = torch.zeros(B, 64, n, device=xyz1.device)
                 xyz2_warp, f2_2d_warp = xyz2, f2_2d
             else:
                 with t.span("backwarp_2d"):
                     f2_2d_warp = backwarp_2d(f2_2d, self.flow_2d[level], padding_mode="border")
                 with t.span("knn_interpolation"):
                     if shares:  # the same two clouds are interpolated again in the final up-sampling below: one search
-                        up, interp_knn[level] = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], 1), xyz1,
-                                                                  return_indices=True)
+                        up, interp_knn[level] = knn_interpolation(xyzs1[level + 1], (flows_3d[-1], flow_feats_3d[-1]), xyz1, return_indices=True)
                     else:
                         up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], 1), xyz1)
                     last_flow_3d, last_flow_feat_3d = up[:, :3], up[:, 3:]
@@ -230,13 +249,20 @@ class HotPathWorkload(torch.nn.Module):
                 else:
                     corr_2d = torch.nn.functional.leaky_relu(correlation2d(f1_2d, f2_2d_warp, 4), 0.1)
 
-            with t.span("grid_sample"):  # corr fuser 3D (:376; utils via RPEFlow_core.py:107-108)
-                sampled = grid_sample_wrapper(torch.cat([corr_2d, self.flow_2d[level]], 1), xy1)
-                grid_sample_wrapper(ef_2d, xy1)
-            with t.span("project_feat"):  # corr fuser 2D (:373)
-                flow_3d_to_2d = last_flow_3d[:, :2] * scale
-                project_feat_with_nn_corr(xy1, corr_2d, torch.cat([corr_3d, flow_3d_to_2d], 1), nn_proj1[..., 0],
-                                          **({"sampled_2d": sampled[:, :corr_2d.shape[1]]} if shares else {}))
+            if shares:
+                with t.span("grid_sample"):  # corr fuser 3D (:376; RPEFlow_core.py:103-111 in one launch)
+                    inv = (1.0 / self.scale_xy[level][0], 1.0 / self.scale_xy[level][1])
+                    sampled = grid_sample_sources([(corr_2d, None, None), (self.flow_2d[level], inv, last_flow_3d[:, :2]), (ef_2d, None, None)], xy1)
+                with t.span("project_feat"):  # corr fuser 2D (:371-373, :82-83)
+                    project_feat_with_nn_corr(xy1, corr_2d, corr_3d, nn_proj1[..., 0], sampled_2d=sampled[:, :corr_2d.shape[1]],
+                                              feat_3d_tail=last_flow_3d[:, :2], tail_scale=self.scale_xy[level])
+            else:
+                with t.span("grid_sample"):  # corr fuser 3D (:376; utils via RPEFlow_core.py:107-108)
+                    sampled = grid_sample_wrapper(torch.cat([corr_2d, self.flow_2d[level]], 1), xy1)
+                    grid_sample_wrapper(ef_2d, xy1)
+                with t.span("project_feat"):  # corr fuser 2D (:373)
+                    flow_3d_to_2d = last_flow_3d[:, :2] * scale
+                    project_feat_with_nn_corr(xy1, corr_2d, torch.cat([corr_3d, flow_3d_to_2d], 1), nn_proj1[..., 0])
 
             with t.span("flow_estimator_3d"):
                 x_3d = [self.aligners[level](corr_3d), self.aligners[level](f1_3d), last_flow_3d, last_flow_feat_3d]
@@ -248,8 +274,11 @@ class HotPathWorkload(torch.nn.Module):
             with t.span("project_feat"):
                 project_feat_with_nn_corr(xy1, self.flow_feat_2d[level], flow_feat_3d, nn_proj1[..., 0], **({"sampled_2d": sampled} if shares else {}))
 
-            with t.span("torch_glue"):
-                flows_3d.append(last_flow_3d + self.flow_head_3d(flow_feat_3d))
+            with t.span("torch_glue"):  # conv_last_3d + the residual flow (RPEFlow_core.py:409-410)
+                if shares:
+                    flows_3d.append(conv_module(self.flow_head_3d, flow_feat_3d, residual=last_flow_3d))
+                else:
+                    flows_3d.append(last_flow_3d + self.flow_head_3d(flow_feat_3d))
             flow_feats_3d.append(flow_feat_3d)
 
         flows_3d = flows_3d[::-1]

@@ -21,8 +21,12 @@ from .csrc import correlation2d as native_correlation2d
 from .csrc.wrapper import _correlation2d_algo as correlation2d_fused_leaky
 from .hotpath import native_ops
 from .pwc3d_core import FlowEstimator3D as NativeFlowEstimator3D
+from .pwc3d_core import build_pc_pyramid as native_build_pc_pyramid
 from .utils import Conv1dNormRelu, Conv2dNormRelu, conv_chain, conv_module, mesh_grid, resize_frames, run_chain, upsample2x_pair
 from .utils import backwarp_2d as native_backwarp_2d
+from .utils import grid_sample_sources, project_points
+from .utils import grid_sample_wrapper as native_grid_sample_wrapper
+from .utils import knn_interpolation as native_knn_interpolation
 from .utils import project_feat_with_nn_corr as native_project_feat_with_nn_corr
 
 
@@ -327,16 +331,18 @@ class CorrFeatureFuser2D(nn.Module):
         self.mi = Mutual_info_reg_2D_Event(in_channels_2d, in_channels_2d // 2)
         self.fuse = CrossTransformerBlock2D(dim=in_channels_2d, num_heads=num_heads)
 
-    def forward(self, xy, feat_2d, feat_3d, efeat_2d, last_flow_2d, last_flow_3d_to_2d, nn_proj):
-        """``last_flow_3d_to_2d`` None: ``feat_3d`` carries it already as its last two channels (RPEFlow_core.py:371-373's cat,
-        done by the caller on the stream that produced both)."""
-        if last_flow_3d_to_2d is not None:
-            feat_3d = torch.cat([feat_3d, last_flow_3d_to_2d], dim=1)
+    def forward(self, xy, feat_2d, feat_3d, efeat_2d, last_flow_2d, last_flow_3d_to_2d, nn_proj, flow_3d_scale=None):
+        """``flow_3d_scale`` (sx, sy): ``last_flow_3d_to_2d`` is the 3-D flow's xy still in sensor units and the product with
+        (sx, sy) (RPEFlow_core.py:371-372) as well as the cat with ``feat_3d`` (:373) happen as the projection kernel reads them."""
         project = self._ops.project_feat_with_nn_corr
         if feat_2d.is_cuda and project is native_project_feat_with_nn_corr:
-            # "-= last_flow_2d" on the projected flow (RPEFlow_core.py:82) and the cat with the event features (:83) inside the launch
-            both = project(xy, feat_2d, feat_3d, nn_proj[..., 0], subtract_last=last_flow_2d, append=efeat_2d)
+            # also "-= last_flow_2d" on the projected flow (RPEFlow_core.py:82) and the cat with the event features (:83) inside the launch
+            tail = {"feat_3d_tail": last_flow_3d_to_2d, "tail_scale": flow_3d_scale or (1.0, 1.0)}
+            both = project(xy, feat_2d, feat_3d, nn_proj[..., 0], subtract_last=last_flow_2d, append=efeat_2d, **tail)
         else:
+            if flow_3d_scale is not None:
+                last_flow_3d_to_2d = last_flow_3d_to_2d * _pair_scale(flow_3d_scale[0], flow_3d_scale[1], last_flow_3d_to_2d)
+            feat_3d = torch.cat([feat_3d, last_flow_3d_to_2d], dim=1)
             feat_3d_to_2d = project(xy, feat_2d, feat_3d, nn_proj[..., 0])
             feat_3d_to_2d[:, -2:] -= last_flow_2d  # RPEFlow_core.py:82
             both = torch.cat([feat_3d_to_2d, efeat_2d], dim=1)
@@ -354,7 +360,15 @@ class CorrFeatureFuser3D(nn.Module):
         self.mi = Mutual_info_reg_3D_Event(in_channels_3d, in_channels_3d // 2)
         self.fuse = CrossTransformerBlock3D(dim=in_channels_3d, num_heads=num_heads)
 
-    def forward(self, xy, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d, last_flow_2d_to_3d):
+    def forward(self, xy, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d, last_flow_2d_to_3d, flow_2d_scale=None):
+        """``flow_2d_scale`` (sx, sy): ``last_flow_2d_to_3d`` is the 2-D flow still in feature-map units; its product with (sx, sy)
+        (RPEFlow_core.py:103-104), both samplings, the subtraction (:110) and both concatenations (:105, :111) are ONE launch."""
+        if feat_corr_2d.is_cuda and self._ops.grid_sample_wrapper is native_grid_sample_wrapper:
+            both = grid_sample_sources([(feat_corr_2d, None, None), (last_flow_2d_to_3d, flow_2d_scale, last_flow_3d[:, :2]),
+                                        (efeat_2d, None, None)], xy)
+            return self.fuse(feat_corr_3d, run_chain(self.mlps, both))
+        if flow_2d_scale is not None:
+            last_flow_2d_to_3d = last_flow_2d_to_3d * _pair_scale(flow_2d_scale[0], flow_2d_scale[1], last_flow_2d_to_3d)
         feat_2d_to_3d = self._ops.grid_sample_wrapper(torch.cat([feat_corr_2d, last_flow_2d_to_3d], dim=1), xy)
         efeat_2d_to_3d = self._ops.grid_sample_wrapper(efeat_2d, xy)
         feat_2d_to_3d[:, -2:] -= last_flow_3d[:, :2]  # RPEFlow_core.py:110
@@ -537,6 +551,7 @@ class RPEFlow_core(nn.Module):
         super().__init__()
         self.cfgs2d, self.cfgs3d = cfgs2d, cfgs3d
         self.ops = ops = ops or native_ops()
+        self._zeros = {}  # constant zero tensors of decode(), by shape
         FeaturePyramid3D, Correlation3D, FlowEstimator3D = ops.FeaturePyramid3D, ops.Correlation3D, ops.FlowEstimator3D
         corr_ch = (2 * cfgs2d.max_displacement + 1) ** 2
         event_bins = cfgs2d.event_bins * 2 if cfgs2d.event_polarity else cfgs2d.event_bins
@@ -601,8 +616,12 @@ class RPEFlow_core(nn.Module):
 
         def fuse_level(level):
             image_h, image_w = feats_2d_both[level].shape[2:]
-            xy_both = project_pc2image(torch.cat([xyzs1[level], xyzs2[level]], dim=0), camera_both)
-            xy_both *= _pair_scale((image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1), xy_both)
+            sx, sy = (image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1)
+            if xyzs1[level].is_cuda and self.ops.project_feat_with_nn_corr is native_project_feat_with_nn_corr:
+                xy_both = project_points(xyzs1[level], xyzs2[level], camera_info, sx, sy)  # both frames, projection and rescale: one launch
+            else:
+                xy_both = project_pc2image(torch.cat([xyzs1[level], xyzs2[level]], dim=0), camera_both)
+                xy_both *= _pair_scale(sx, sy, xy_both)
             grid = mesh_grid(2 * batch_size, image_h, image_w, xy_both.device).reshape(2 * batch_size, 2, -1)
             nn_proj_both = k_nearest_neighbor(xy_both, grid, k=1)
             knn_1in1 = k_nearest_neighbor(xyzs1[level], xyzs1[level], k=k)
@@ -674,7 +693,17 @@ class RPEFlow_core(nn.Module):
         fused, ready = hoisted_early if hoisted_early is not None else self.hoist(xyzs1, xyzs2, feats_2d_both, feats_3d_both, efeats_2d, camera_info,
                                                                       pre_stream)
 
-        zeros = lambda *s: torch.zeros(s, dtype=feats_2d_both[1].dtype, device=feats_2d_both[1].device)
+        def zeros(*shape):
+            """The coarsest level's "previous" flows (RPEFlow_core.py:341-344): constant tensors, made once per shape -- every
+            consumer reads them (residual / subtrahend / gather source), none writes."""
+            like = feats_2d_both[1]
+            key = (shape, like.dtype, like.device)
+            if key not in self._zeros:
+                z = torch.zeros(shape, dtype=like.dtype, device=like.device)
+                if like.is_cuda and torch.cuda.is_current_stream_capturing():
+                    return z  # (memory of the capturing graph's pool: not kept beyond this call)
+                self._zeros[key] = z
+            return self._zeros[key]
         main_stream = torch.cuda.current_stream(pre_stream.device) if pre_stream is not None else None
 
         def take(level):
@@ -698,7 +727,10 @@ class RPEFlow_core(nn.Module):
                 last_flow_3d, last_flow_feat_3d, xyz2_warp = zeros(batch_size, 3, n_points), zeros(batch_size, 64, n_points), xyz2
             else:
                 _stamp("side L%d stage1 begin" % level)
-                up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], dim=1), xyz1)
+                if xyz1.is_cuda and knn_interpolation is native_knn_interpolation:  # the pair is read where it lies: no cat
+                    up = knn_interpolation(xyzs1[level + 1], (flows_3d[-1], flow_feats_3d[-1]), xyz1)
+                else:
+                    up = knn_interpolation(xyzs1[level + 1], torch.cat([flows_3d[-1], flow_feats_3d[-1]], dim=1), xyz1)
                 _stamp("side L%d stage1 knn_interp done" % level)
                 last_flow_3d, last_flow_feat_3d = up[:, :3, :], up[:, 3:, :]
                 xyz2_warp = backwarp_3d(xyz1, xyz2, last_flow_3d)
@@ -708,11 +740,10 @@ class RPEFlow_core(nn.Module):
                                                            projected=corr_proj)
             else:
                 feat_corr_3d = self.correlations_3d[level](xyz1, fused_3d[:batch_size], xyz2_warp, fused_3d[batch_size:], knn_1in1)
-            last_flow_3d_to_2d = last_flow_3d[:, :2] * _pair_scale(sx, sy, last_flow_3d)  # (:371-372) one launch, not mul, mul, cat
-            # the 2-D correlation fuser reads [cost volume | projected flow] (:373): joined here, on the stream that made both
-            feat_corr_3d_and_flow = torch.cat([feat_corr_3d, last_flow_3d_to_2d], dim=1)
+            # the 2-D correlation fuser reads [cost volume | xy of the 3-D flow x (sx, sy)] (:371-373): product and cat happen
+            # inside its projection kernel
             _stamp("side L%d stage1 done" % level)
-            return last_flow_3d, last_flow_feat_3d, feat_corr_3d, feat_corr_3d_and_flow
+            return last_flow_3d, last_flow_feat_3d, feat_corr_3d
 
         hoisted = take(top)
         out_s1 = br.fork(lambda: stage1_3d(top, hoisted), _tensors(hoisted) + [xyzs1[top], xyzs2[top]])
@@ -744,14 +775,14 @@ class RPEFlow_core(nn.Module):
                 feat_corr_2d = F.leaky_relu(correlation2d(feat1_2d, feat2_2d_warp, md), 0.1)
             _stamp("main L%d stage1 done" % level)
             br.join(out_s1)
-            last_flow_3d, last_flow_feat_3d, feat_corr_3d, feat_corr_3d_and_flow = out_s1
+            last_flow_3d, last_flow_feat_3d, feat_corr_3d = out_s1
+            sx, sy = (image_w - 1) / (sensor_w - 1), (image_h - 1) / (sensor_h - 1)
 
             # ---- stage 2: correlation fusers and flow estimators
             def chain_3d():
-                # (the 3-D chain is the only reader of the 2-D flow in sensor units: computed on its stream, off the main chain)
-                last_flow_2d_to_3d = last_flow_2d * _pair_scale((sensor_w - 1) / (image_w - 1), (sensor_h - 1) / (image_h - 1), last_flow_2d)
-                corr_3d_fused = self.corr_feat_fusers_3d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d,
-                                                                last_flow_2d_to_3d)
+                # (the 2-D flow in sensor units, :103-104, exists only as the sampling kernel reads it)
+                corr_3d_fused = self.corr_feat_fusers_3d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d, last_flow_2d,
+                                                                flow_2d_scale=((sensor_w - 1) / (image_w - 1), (sensor_h - 1) / (image_h - 1)))
                 x_3d = [self.correlation_aligners_3d[level](corr_3d_fused), aligned_3d, last_flow_3d, last_flow_feat_3d]
                 if not isinstance(self.flow_estimator_3d, NativeFlowEstimator3D):  # (the native one concatenates while packing)
                     x_3d = torch.cat(x_3d, dim=1)
@@ -760,7 +791,8 @@ class RPEFlow_core(nn.Module):
                 return (est,)
 
             out_3d = br.fork(chain_3d, [feat_corr_2d, efeat_2d, last_flow_2d])
-            corr_2d_fused = self.corr_feat_fusers_2d[level](xy1, feat_corr_2d, feat_corr_3d_and_flow, efeat_2d, last_flow_2d, None, nn_proj1)
+            corr_2d_fused = self.corr_feat_fusers_2d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_2d, last_flow_3d[:, :2], nn_proj1,
+                                                            flow_3d_scale=(sx, sy))
             x_2d = torch.cat([corr_2d_fused, aligned_2d, aligned_e2d, last_flow_2d, last_flow_feat_2d], dim=1)
             flow_feat_2d_raw = self.flow_estimator_2d(x_2d)
             _stamp("main L%d stage2 done" % level)
@@ -827,8 +859,16 @@ class RPEFlow(nn.Module):
         self.pwc_fusion_core = RPEFlow_core(self.cfgs.pwc2d, self.cfgs.pwc3d, self.cfgs.get("attention"), ops=ops)
 
     def _pyramid(self, pc1, pc2, n_samples, fps_order):
+        """(xyzs1, xyzs2, both): the two pyramids and, level by level, the two clouds stacked on the batch axis ([2B,3,n], frame 1
+        first) as the shared-weight 3-D encoder takes them.  The native pyramid samples the stacked clouds with ONE gather, so
+        every level of all three lists is a view of one tensor; a CPU port passed as ``ops`` gets the reference's calls."""
         build = self.pwc_fusion_core.ops.build_pc_pyramid
-        return build(pc1, pc2, n_samples) if fps_order is None else build(pc1, pc2, n_samples, sample_index_both=fps_order)
+        extra = {} if fps_order is None else {"sample_index_both": fps_order}
+        if build is native_build_pc_pyramid:
+            xyzs1, xyzs2, _, _, both = build(pc1, pc2, n_samples, return_both=True, **extra)
+            return xyzs1, xyzs2, both
+        xyzs1, xyzs2, _, _ = build(pc1, pc2, n_samples, **extra)
+        return xyzs1, xyzs2, [torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)]
 
     def _side_stream(self, device, name="side"):
         key = (torch.device(device).index, name)
@@ -931,8 +971,7 @@ class RPEFlow(nn.Module):
             pre = self._side_stream(pc1.device, "pre")
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                xyzs1, xyzs2, _, _ = self._pyramid(pc1, pc2, n_samples, fps_order)
-                both = [torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)]
+                xyzs1, xyzs2, both = self._pyramid(pc1, pc2, n_samples, fps_order)
                 _stamp("side fps done")
                 if self.early_hoist:
                     feats_3d_both = core.feature_pyramid_3d(both)
@@ -958,8 +997,8 @@ class RPEFlow(nn.Module):
                 for t in list(xyzs1) + list(xyzs2) + list(feats_3d_both):
                     t.record_stream(main)  # allocated on the side stream, consumed on the main one
         else:
-            xyzs1, xyzs2, _, _ = self._pyramid(pc1, pc2, n_samples, fps_order)
-            feats_3d_both = core.feature_pyramid_3d([torch.cat([a, b], dim=0) for a, b in zip(xyzs1, xyzs2)])
+            xyzs1, xyzs2, both = self._pyramid(pc1, pc2, n_samples, fps_order)
+            feats_3d_both = core.feature_pyramid_3d(both)
             _stamp("side encode3d done")
             feats_2d_both = core.feature_pyramid_2d(image_both)
             _stamp("main image pyramid done")

@@ -13,27 +13,52 @@ from .pointconv import PointConvDownSampling, PointConvNoSampling
 from .utils import MLP1d, MLP2d, batch_indexing_channel_first
 
 
-def build_pc_pyramid(pc1, pc2, n_samples_list, sample_index_both=None):
+_LEVEL0_INDEX = {}
+
+
+def build_pc_pyramid(pc1, pc2, n_samples_list, sample_index_both=None, return_both=False):
     """pwc3d_core.py:8-28: one FPS over both clouds, every level a prefix of its order.
-    ``sample_index_both`` ([2B, >=max(n_samples_list)] int64): that order, when the caller computed it already."""
+    ``sample_index_both`` ([2B, >=max(n_samples_list)] int64): that order, when the caller computed it already.
+    ``pc1`` / ``pc2`` that are the two halves of ONE [2B,3,N] tensor (what the IDS transform returns) are sampled where they
+    lie -- no torch.cat -- and the levels of both clouds come out of ONE gather; ``return_both``: also the list of the
+    stacked levels ([2B,3,n], frame 1 first: views of that gather's output)."""
     batch_size, _, n_points = pc1.shape
-    if sample_index_both is None:
+    pc_both = _stacked(pc1, pc2)
+    if pc_both is None:
         pc_both = torch.cat([pc1, pc2], dim=0)
+    if sample_index_both is None:
         sample_index_both = furthest_point_sampling(pc_both.transpose(1, 2), max(n_samples_list))
     sample_index1, sample_index2 = sample_index_both[:batch_size], sample_index_both[batch_size:]
 
-    lv0_index = torch.arange(n_points, device=pc1.device)[None, :].expand(batch_size, n_points)
-    xyzs1, xyzs2, sample_indices1, sample_indices2 = [pc1], [pc2], [lv0_index], [lv0_index]
-    # one gather at the largest size; smaller levels are prefixes of it (pwc3d_core.py:22-26)
+    key = (batch_size, n_points, pc1.device)
+    lv0_index = _LEVEL0_INDEX.get(key)
+    if lv0_index is None:  # a constant: made once (kept only when made outside a stream capture, whose memory belongs to the graph)
+        lv0_index = torch.arange(n_points, device=pc1.device)[None, :].expand(batch_size, n_points)
+        if not (pc1.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _LEVEL0_INDEX[key] = lv0_index
+    xyzs1, xyzs2, sample_indices1, sample_indices2, both = [pc1], [pc2], [lv0_index], [lv0_index], [pc_both]
+    # one gather at the largest size for both clouds; smaller levels are prefixes of it (pwc3d_core.py:22-26)
     n_max = max(n_samples_list)
-    top1 = batch_indexing_channel_first(pc1, sample_index1[:, :n_max])
-    top2 = batch_indexing_channel_first(pc2, sample_index2[:, :n_max])
+    top = batch_indexing_channel_first(pc_both, sample_index_both[:, :n_max])
     for n_samples in n_samples_list:
         sample_indices1.append(sample_index1[:, :n_samples])
         sample_indices2.append(sample_index2[:, :n_samples])
-        xyzs1.append(top1[:, :, :n_samples])
-        xyzs2.append(top2[:, :, :n_samples])
+        xyzs1.append(top[:batch_size, :, :n_samples])
+        xyzs2.append(top[batch_size:, :, :n_samples])
+        both.append(top[:, :, :n_samples])
+    if return_both:
+        return xyzs1, xyzs2, sample_indices1, sample_indices2, both
     return xyzs1, xyzs2, sample_indices1, sample_indices2
+
+
+def _stacked(a, b):
+    """The tensor [a; b] (stacked on dim 0) if ``a`` and ``b`` are its two halves already, else None."""
+    if (a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype and a.device == b.device and a._base is not None
+            and a._base is b._base and a._base.dim() == a.dim() and a._base.shape[0] == 2 * a.shape[0] and a._base.shape[1:] == a.shape[1:]
+            and a._base.stride() == a.stride() and a.data_ptr() == a._base.data_ptr()
+            and b.data_ptr() == a.data_ptr() + a.shape[0] * a.stride(0) * a.element_size()):
+        return a._base
+    return None
 
 
 class FeaturePyramid3D(nn.Module):
@@ -52,7 +77,12 @@ class FeaturePyramid3D(nn.Module):
         assert len(xyzs) == len(self.pyramid_mlps) + 1
         # the layers' neighbour searches (pointconv.py:46) need the coordinates only: all levels in one launch up front
         knns = k_nearest_neighbor_multi([(xyzs[i], xyzs[i + 1]) for i in range(len(xyzs) - 1)], self.pyramid_convs[0].k)
-        feats = [self.level0_mlp(torch.zeros_like(xyzs[0]))]
+        # level 0: the MLP of an all-zero input (pwc3d_core.py:51-52), i.e. ONE vector for every point (eval-mode BatchNorm
+        # is per point): computed on a single point and broadcast -- a stride-0 view the next layer's kernel reads as it is
+        if xyzs[0].is_cuda and not self.training and not torch.is_grad_enabled():
+            feats = [self.level0_mlp(xyzs[0].new_zeros((1, 3, 1))).expand(xyzs[0].shape[0], -1, xyzs[0].shape[2])]
+        else:
+            feats = [self.level0_mlp(torch.zeros_like(xyzs[0]))]
         for i in range(len(xyzs) - 1):
             # the MLP writes the PointConv layer's gather rows [xyz | features] directly: no packing pass
             feats.append(self.pyramid_convs[i](xyzs[i], self.pyramid_mlps[i](feats[-1], rows_xyz=xyzs[i]), xyzs[i + 1], knn_indices=knns[i]))
@@ -134,8 +164,13 @@ class Correlation3D(nn.Module):
             return None
         w = self._weights()
         batch_size = feat_both.shape[0] // 2
-        wt = w["w_ab_t"].repeat_interleave(batch_size, dim=0)
-        bias = w["bias_ab"].repeat_interleave(batch_size, dim=0)[:, None, :]
+        if w.get("stacked_for") == batch_size:  # per-sample copies of the two weight blocks: constants of the batch size
+            wt, bias = w["stacked_wt"], w["stacked_bias"]
+        else:
+            wt = w["w_ab_t"].repeat_interleave(batch_size, dim=0)
+            bias = w["bias_ab"].repeat_interleave(batch_size, dim=0)[:, None, :]
+            if not (wt.is_cuda and torch.cuda.is_current_stream_capturing()):  # (a capturing graph owns what is allocated inside it)
+                w["stacked_wt"], w["stacked_bias"], w["stacked_for"] = wt, bias, batch_size
         rows = torch.baddbmm(bias, feat_both.float().transpose(1, 2), wt)
         return rows[:batch_size], rows[batch_size:]
 
@@ -145,7 +180,8 @@ class Correlation3D(nn.Module):
         if not self.fusable:
             return None
         if feat1.shape[2] == feat2.shape[2]:
-            return self.project_stacked(torch.cat([feat1, feat2], dim=0))
+            both = _stacked(feat1, feat2)  # (the two frames' features usually ARE the halves of one [2B,C,N] tensor)
+            return self.project_stacked(both if both is not None else torch.cat([feat1, feat2], dim=0))
         w = self._weights()
         batch_size = feat1.shape[0]
         p1 = torch.baddbmm(w["bias_ab"][0][None, None, :], feat1.float().transpose(1, 2), w["w_ab_t"][0][None].expand(batch_size, -1, -1))

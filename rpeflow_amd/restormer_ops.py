@@ -183,7 +183,7 @@ def attention_apply(qkv, m_packed, residual=None, bias=None):
     with torch.cuda.device(qkv.device):
         rc = _lib.lib().rpe_pointwise_conv(ctypes.c_void_p(qkv.data_ptr() + 4 * 2 * C * P), 3 * C * P, B, C, P, _ptr(m_packed),
                                            m_packed[0].numel(), C, _NULL, _ptr(bias.float().contiguous()) if bias is not None else _NULL,
-                                           0, 0.1, _ptr(res) if res is not None else _NULL, _ptr(out), _lib.stream_of(qkv))
+                                           0, 0.1, _ptr(res) if res is not None else _NULL, C * P, _ptr(out), _lib.stream_of(qkv))
     _lib.check(rc, "attention_apply")
     return out
 

@@ -109,12 +109,21 @@ def pointwise_conv(x, weight, bias=None, stride=1, residual=None, inplace=False,
     if bias is not None:  # (an epilogue's shift already contains the block's bias: callers pass one or the other)
         shift = bias if shift is None else shift + (bias if scale is None else bias * scale)
     if x.is_cuda and 2.0 * B * P * C * cout <= _PW_MAX_FLOPS:
-        xf = _f32(xf).contiguous()
-        res = None if residual is None else _f32(residual).reshape(B, cout, P).contiguous()
-        out = res if (inplace and res is not None and res.data_ptr() == residual.data_ptr()) else torch.empty((B, cout, P), dtype=torch.float32, device=x.device)
-        _launch(xf, "pointwise_conv", _lib.lib().rpe_pointwise_conv, _ptr(xf), C * P, B, C, P, _ptr(_pw_packed_weight(weight)), 0, cout,
+        # a channel slice of a wider tensor (samples dense, batch stride larger) is read / added where it lies
+        dense = lambda t, c: t.stride(2) == 1 and t.stride(1) == P and t.stride(0) >= c * P
+        xf = _f32(xf)
+        if not dense(xf, C):
+            xf = xf.contiguous()
+        res = None
+        if residual is not None:
+            res = _f32(residual).reshape(B, cout, P)
+            if not dense(res, cout):
+                res = res.contiguous()
+        reuse = inplace and res is not None and res.is_contiguous() and res.data_ptr() == residual.data_ptr()
+        out = res if reuse else torch.empty((B, cout, P), dtype=torch.float32, device=x.device)
+        _launch(xf, "pointwise_conv", _lib.lib().rpe_pointwise_conv, _ptr(xf), xf.stride(0), B, C, P, _ptr(_pw_packed_weight(weight)), 0, cout,
                 _ptr(scale) if scale is not None else _NULL, _ptr(shift.contiguous()) if shift is not None else _NULL,
-                _ACT_CODE[kind], 0.1, _ptr(res) if res is not None else _NULL, _ptr(out))
+                _ACT_CODE[kind], 0.1, _ptr(res) if res is not None else _NULL, res.stride(0) if res is not None else 0, _ptr(out))
         return out.reshape((B, cout) + tuple(spatial))
     w = weight.reshape(cout, -1)
     wb = w.unsqueeze(0).expand(B, -1, -1)  # batch stride 0: one strided-batched GEMM, the weight read once per sample from L2
@@ -472,27 +481,43 @@ def batch_indexing_channel_last(batched_data: torch.Tensor, batched_indices: tor
 
 
 # ------------------------------------------------------------------ 3-D interpolation / warp
-def _interpolate(input_xyz, input_features, query_xyz, knn_indices, k, scale=1.0):
-    input_xyz, input_features, query_xyz = _f32(input_xyz), _f32(input_features), _f32(query_xyz)
+def _interpolate(input_xyz, input_features, query_xyz, knn_indices, k, scale=1.0, residual=None):
+    """``input_features``: [B,C,M], or a pair of such tensors standing for their channel-wise concatenation (never built);
+    ``residual`` [B,C,Q]: added to the result inside the launch."""
+    pair = isinstance(input_features, (list, tuple))
+    feat_a, feat_b = (input_features if pair else (input_features, None))
+    input_xyz, feat_a, query_xyz = _f32(input_xyz), _f32(feat_a), _f32(query_xyz)
     B, _, M = input_xyz.shape
-    C, Q = input_features.shape[1], query_xyz.shape[2]
-    out = torch.empty((B, C, Q), dtype=torch.float32, device=input_xyz.device)
+    Ca, Q = feat_a.shape[1], query_xyz.shape[2]
+    Cb, b_args = 0, (_NULL, 0, 0, 0)
+    if feat_b is not None:
+        feat_b = _f32(feat_b)
+        assert feat_b.shape[0] == B and feat_b.shape[2] == M
+        Cb, b_args = feat_b.shape[1], (_ptr(feat_b), *feat_b.stride())
+    r_args = (_NULL, 0, 0, 0)
+    if residual is not None:
+        residual = _f32(residual)
+        assert residual.shape == (B, Ca + Cb, Q)
+        r_args = (_ptr(residual), *residual.stride())
+    out = torch.empty((B, Ca + Cb, Q), dtype=torch.float32, device=input_xyz.device)
     knn_indices = knn_indices if knn_indices.stride(2) == 1 and knn_indices.stride(0) == Q * knn_indices.stride(1) \
         else knn_indices.contiguous()
     _launch(input_xyz, "knn_interpolation", _lib.lib().rpe_knn_interpolate,
-            _ptr(input_xyz), *input_xyz.stride(), _ptr(input_features), *input_features.stride(),
+            _ptr(input_xyz), *input_xyz.stride(), _ptr(feat_a), *feat_a.stride(), Ca, *b_args, Cb,
             _ptr(query_xyz), *query_xyz.stride(), _ptr(knn_indices), knn_indices.stride(1),
-            B, M, Q, C, int(k), float(scale), _ptr(out))
+            B, M, Q, int(k), float(scale), *r_args, _ptr(out))
     return out
 
 
 def knn_interpolation(input_xyz, input_features, query_xyz, k=3, knn_indices=None, return_indices=False):
     """utils.py:140-156.  [B,3,M], [B,C,M], [B,3,Q] -> [B,C,Q]: KNN kernel + one fused kernel
     (the reference: KNN + 2 gathers + norm + clamp + reciprocal + 2 reductions + multiply).
+    ``input_features`` may be a PAIR of tensors ([B,Ca,M], [B,Cb,M]) standing for torch.cat(pair, dim=1): the decoder
+    interpolates the coarser level's [flow | flow features] (RPEFlow_core.py:352) -- the result is [B,Ca+Cb,Q] either way.
     ``knn_indices`` [B,Q,>=k]: the k nearest inputs of every query when the caller has them -- the decoder interpolates
     level l + 1 -> l inside the recurrence and again for the final up-sampling of the same two clouds
     (RPEFlow_core.py:352, 426-430); ``return_indices``: also return them."""
-    _lib.require_gpu(input_xyz, input_features, query_xyz, op="knn_interpolation")
+    _lib.require_gpu(input_xyz, query_xyz, op="knn_interpolation")
     if knn_indices is None:
         knn_indices = k_nearest_neighbor(input_xyz, query_xyz, k)
     out = _interpolate(input_xyz, input_features, query_xyz, knn_indices, k)
@@ -500,12 +525,11 @@ def knn_interpolation(input_xyz, input_features, query_xyz, k=3, knn_indices=Non
 
 
 def backwarp_3d(xyz1, xyz2, flow12, k=3):
-    """utils.py:159-169.  The "-flow12" features are negated inside the kernel."""
+    """utils.py:159-169.  The "-flow12" features are negated and "xyz2 +" is added inside the interpolation kernel."""
     _lib.require_gpu(xyz1, xyz2, flow12, op="backwarp_3d")
     xyz1_warp = xyz1 + flow12
     knn_indices = k_nearest_neighbor(xyz1_warp, xyz2, k)
-    flow21 = _interpolate(xyz1_warp, flow12, xyz2, knn_indices, k, scale=-1.0)
-    return xyz2 + flow21
+    return _interpolate(xyz1_warp, flow12, xyz2, knn_indices, k, scale=-1.0, residual=xyz2)
 
 
 # ------------------------------------------------------------------ 2-D sampling
@@ -524,18 +548,40 @@ def mesh_grid(n, h, w, device, channel_first=True):
     return mesh_grid_cache[key]
 
 
+def _sample(sources, B, H, W, xy_ptr, xy_strides, P, add_grid, border, like):
+    """rpe_bilinear_sample over ``sources`` = [(map [B,C,H,W], (scale_even, scale_odd) or None, subtract [B,C,P] or None), ...]."""
+    assert 1 <= len(sources) <= 4
+    table, keep, C = (_lib.SampleSource * len(sources))(), [], 0
+    for i, (m, scale, sub) in enumerate(sources):
+        m = _f32(m)
+        assert m.dim() == 4 and m.shape[0] == B and tuple(m.shape[2:]) == (H, W)
+        if m.stride(3) != 1 or m.stride(2) != W:
+            m = m.contiguous()
+        se, so = (1.0, 1.0) if scale is None else (float(scale[0]), float(scale[1]))
+        sub_args = (None, 0, 0, 0)
+        if sub is not None:
+            sub = _f32(sub)
+            assert sub.shape == (B, m.shape[1], P)
+            sub_args = (sub.data_ptr(), *sub.stride())
+        table[i] = _lib.SampleSource(m.data_ptr(), m.stride(0), m.stride(1), m.shape[1], se, so, *sub_args)
+        keep += [m, sub]
+        C += m.shape[1]
+    out = torch.empty((B, C, P), dtype=torch.float32, device=like.device)
+    _launch(like, "bilinear_sample", _lib.lib().rpe_bilinear_sample, ctypes.byref(table), len(sources), B, H, W,
+            xy_ptr, *xy_strides, P, int(add_grid), int(border), _ptr(out))
+    return out
+
+
 def backwarp_2d(x, flow12, padding_mode):
     """utils.py:186-198.  x [B,C,H,W], flow12 [B,2,H,W]; padding 'border' or 'zeros'."""
     assert x.size()[-2:] == flow12.size()[-2:]
     if padding_mode not in ("border", "zeros"):
         raise NotImplementedError("backwarp_2d: padding_mode %r" % (padding_mode,))
     _lib.require_gpu(x, flow12, op="backwarp_2d")
-    x, flow12 = _f32(x).contiguous(), _f32(flow12).contiguous()
+    x, flow12 = _f32(x), _f32(flow12).contiguous()
     B, C, H, W = x.shape
-    out = torch.empty_like(x)
-    _launch(x, "backwarp_2d", _lib.lib().rpe_bilinear_sample, _ptr(x), B, C, H, W,
-            _ptr(flow12), 2 * H * W, H * W, 1, H * W, 1, int(padding_mode == "border"), _ptr(out))
-    return out
+    out = _sample([(x, None, None)], B, H, W, _ptr(flow12), (2 * H * W, H * W, 1), H * W, True, padding_mode == "border", x)
+    return out.view(B, C, H, W)
 
 
 def resize_frames(x, size, divisor=0.0, pair_split=False):
@@ -586,18 +632,48 @@ def upsample2x_pair(a, b, scale_a=1.0):
 
 def grid_sample_wrapper(feat_2d, xy):
     """utils.py:288-294.  feat_2d [B,C,H,W], xy [B,2,N] -> [B,C,N]; zeros outside the image."""
-    _lib.require_gpu(feat_2d, xy, op="grid_sample_wrapper")
-    feat_2d, xy = _f32(feat_2d).contiguous(), _f32(xy)
-    B, C, H, W = feat_2d.shape
-    N = xy.shape[2]
-    out = torch.empty((B, C, N), dtype=torch.float32, device=feat_2d.device)
-    _launch(feat_2d, "grid_sample_wrapper", _lib.lib().rpe_bilinear_sample, _ptr(feat_2d), B, C, H, W,
-            _ptr(xy), *xy.stride(), N, 0, 0, _ptr(out))
+    return grid_sample_sources([(feat_2d, None, None)], xy)
+
+
+def grid_sample_sources(sources, xy):
+    """grid_sample_wrapper(torch.cat([m * scale ...], dim=1), xy) - torch.cat([subtract ...], dim=1) in ONE launch, without the
+    concatenated map: ``sources`` = [(map [B,C_i,H,W], scale, subtract), ...] (at most four maps of one size); ``scale`` None or
+    (even-channel factor, odd-channel factor) applied to the map's values as they are read; ``subtract`` None or [B,C_i,N],
+    taken off that map's samples.  What the 3-D correlation fuser does around its two calls (RPEFlow_core.py:103-111)."""
+    first = sources[0][0]
+    _lib.require_gpu(first, xy, op="grid_sample_wrapper")
+    xy = _f32(xy)
+    B, _, H, W = first.shape
+    return _sample(sources, B, H, W, _ptr(xy), xy.stride(), xy.shape[2], False, False, first)
+
+
+def project_points(xyz1, xyz2, camera_info, scale_x, scale_y):
+    """project_pc2image (utils.py:260-285) of both frames' clouds + the sensor -> feature-map rescale (RPEFlow_core.py:316-324):
+    [2B,2,N] (frame 1's samples, then frame 2's; [B,2,N] with ``xyz2`` None), one launch."""
+    _lib.require_gpu(xyz1, op="project_pc2image")
+    xyz1 = _f32(xyz1)
+    B, _, N = xyz1.shape
+    b_args, n = (_NULL, 0, 0, 0), B
+    if xyz2 is not None:
+        xyz2 = _f32(xyz2)
+        assert xyz2.shape == xyz1.shape
+        b_args, n = (_ptr(xyz2), *xyz2.stride()), 2 * B
+    intr_args, cx, cy = (_NULL, 0), 0.0, 0.0
+    if camera_info["projection_mode"] == "parallel":
+        cx, cy = float(camera_info["cx"]), float(camera_info["cy"])
+    else:
+        intr = torch.stack([camera_info["f"], camera_info["cx"], camera_info["cy"]], dim=1).float().contiguous()
+        assert intr.shape == (B, 3)
+        intr_args = (_ptr(intr), 3)
+    out = torch.empty((n, 2, N), dtype=torch.float32, device=xyz1.device)
+    _launch(xyz1, "project_pc2image", _lib.lib().rpe_project_points, _ptr(xyz1), *xyz1.stride(), *b_args, B, N, *intr_args, cx, cy,
+            float(scale_x), float(scale_y), _ptr(out))
     return out
 
 
 @torch.no_grad()
-def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=None, subtract_last=None, append=None):
+def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=None, subtract_last=None, append=None,
+                              feat_3d_tail=None, tail_scale=(1.0, 1.0)):
     """utils.py:297-317.  xy [B,2,N], feat_2d [B,C2,H,W], feat_3d [B,C3,N], nn_indices [B,H*W]
     -> [B,C3+3,H,W].  Two launches (per-point rows, then per-pixel gather + correlation); the
     reference runs grid_sample over all N points, three gathers, a product, a mean and a concat.
@@ -605,7 +681,9 @@ def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=
     fuser of the same (map, points) pair computes it anyway; the per-point bilinear taps are then not repeated.
     ``subtract_last`` [B,n,H,W]: subtracted from the last n projected channels; ``append`` [B,m,H,W]: concatenated behind the
     result (-> [B,C3+3+m,H,W]) -- the two steps the 2-D correlation fuser puts behind this call (RPEFlow_core.py:82-83), inside
-    the second launch."""
+    the second launch.  ``feat_3d_tail`` [B,Ct,N] with ``tail_scale`` = (even-channel factor, odd-channel factor): feat_3d is
+    torch.cat([feat_3d, feat_3d_tail * scale], dim=1) without that tensor (the fuser's [cost volume | flow_3d xy in map units],
+    :371-373)."""
     _lib.require_gpu(xy, feat_2d, feat_3d, op="project_feat_with_nn_corr")
     xy, feat_2d, feat_3d = _f32(xy), _f32(feat_2d).contiguous(), _f32(feat_3d)
     B, C2, H, W = feat_2d.shape
@@ -615,7 +693,13 @@ def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=
     else:
         assert nn_indices.shape == (B, H * W)
     nn_indices = nn_indices.to(torch.int64).contiguous()
-    C3, N = feat_3d.shape[1], feat_3d.shape[2]
+    C3a, N = feat_3d.shape[1], feat_3d.shape[2]
+    tail_args, C3b = (_NULL, 0, 0, 0), 0
+    if feat_3d_tail is not None:
+        feat_3d_tail = _f32(feat_3d_tail)
+        assert feat_3d_tail.shape[0] == B and feat_3d_tail.shape[2] == N
+        C3b, tail_args = feat_3d_tail.shape[1], (_ptr(feat_3d_tail), *feat_3d_tail.stride())
+    C3 = C3a + C3b
     n_sub = n_app = 0
     if subtract_last is not None:
         subtract_last = _f32(subtract_last).contiguous()
@@ -633,7 +717,8 @@ def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=
         assert sampled_2d.shape == (B, C2, N)
         sm_strides = sampled_2d.stride()
     _launch(feat_2d, "project_feat_with_nn_corr", _lib.lib().rpe_project_feat_nn_corr,
-            _ptr(xy), *xy.stride(), _ptr(feat_2d), C2, H, W, _ptr(sampled_2d), *sm_strides, _ptr(feat_3d), *feat_3d.stride(), C3,
+            _ptr(xy), *xy.stride(), _ptr(feat_2d), C2, H, W, _ptr(sampled_2d), *sm_strides, _ptr(feat_3d), *feat_3d.stride(), C3a,
+            *tail_args, C3b, float(tail_scale[0]), float(tail_scale[1]),
             _ptr(nn_indices), _ptr(subtract_last), n_sub, _ptr(append), n_app, B, N, _ptr(rows), _ptr(out))
     return out
 

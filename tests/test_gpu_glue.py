@@ -377,9 +377,10 @@ def test_default_ids_and_sampling_against_64_reference_clouds(golden_dir):
     (host-side perspect2parallel, utils.py:320-346 via RPEFlow.py:56-69, then build_pc_pyramid's furthest-point sampling,
     pwc3d_core.py:11-13), on 64 clouds of 32 large-motion frame pairs (tests/golden/ids_fps_sweep.npz: the reference's full
     sampling orders, and its z' wherever torch.log on the build container's CPU was not the correctly rounded logarithm).
-    x', y' bit for bit; z' differs from the reference exactly where the reference is off the correctly rounded value, by one
-    ulp; and the sampling order -- chaotic in these values -- is counted cloud by cloud.  Measured: 32 of 524 288 z' one ulp
-    apart (28 clouds touched), 0 of 64 sampling orders different."""
+    x', y' bit for bit; z' = (f log z + 1) s differs from the reference exactly where the reference's log is off the correctly
+    rounded value (one ulp of log z, which the product with f and the two roundings behind it turn into at most two ulps of
+    z'); and the sampling order -- chaotic in these values -- is counted cloud by cloud.  Measured: 32 of 524 288 z' apart
+    (28 clouds touched), 0 of 64 sampling orders different."""
     from rpeflow_amd.csrc import furthest_point_sampling
     from rpeflow_amd.model import RPEFlow
     g = G(golden_dir, "ids_fps_sweep")
@@ -402,7 +403,7 @@ def test_default_ids_and_sampling_against_64_reference_clouds(golden_dir):
             m = g["patch_cloud"] == c
             ref[2][g["patch_pos"][m]] = g["patch_val"][m]                       # ... and this is the cloud the reference computed
             ulps = np.abs(got[j].view(np.int32).astype(np.int64) - ref.view(np.int32).astype(np.int64))
-            assert ulps.max() <= 1 and int((ulps != 0).sum()) == int(m.sum()) and not ulps[:2].any()
+            assert ulps.max() <= 2 and int((ulps != 0).sum()) == int(m.sum()) and not ulps[:2].any()
             off_values += int(m.sum())
             touched += bool(m.any())
             if not np.array_equal(order[j].astype(np.uint16), g["order"][c]):
@@ -592,3 +593,135 @@ def test_project_feat_with_the_fusers_two_elementwise_steps_inside():
         assert torch.equal(only_sub, ref[:, :C3 + 3])
         sampled = U.grid_sample_wrapper(f2, xy)
         assert torch.equal(U.project_feat_with_nn_corr(xy, f2, f3, nn, sampled_2d=sampled, subtract_last=sub, append=app), ref)
+
+
+# ---------------------------------------------------------------- round 5: the glue between the operators inside their launches
+@pytest.mark.parametrize("mode", ["parallel", "perspective"])
+def test_project_points_equals_the_reference_op_sequence(mode):
+    """rpe_project_points == project_pc2image (utils.py:260-285) + the in-place rescale (RPEFlow_core.py:316-324) of both frames,
+    computed with the reference's own tensor ops on the CPU: bit for bit (fp32 adds / muls / divs round alike on both sides)."""
+    g = torch.Generator().manual_seed(12)
+    B, N = 3, 1000
+    xyz1 = torch.randn(B, 3, N, generator=g) * 5 + torch.tensor([0.0, 0.0, 30.0])[None, :, None]
+    top = torch.randn(2 * B, 3, 2 * N, generator=g) * 5 + torch.tensor([0.0, 0.0, 30.0])[None, :, None]
+    xyz2 = top[B:, :, :N]  # a strided prefix view, as the pyramid hands its levels over
+    sx, sy = 239 / 29, 143 / 17
+    if mode == "parallel":
+        cam = {"projection_mode": "parallel", "cx": 14.5, "cy": 8.5}
+        ref = [torch.stack([p[:, 0] + cam["cx"], p[:, 1] + cam["cy"]], 1) for p in (xyz1, xyz2)]
+    else:
+        f, cx, cy = torch.tensor([1050.0, 900.0, 1000.0]), torch.tensor([479.5, 400.0, 500.25]), torch.tensor([269.5, 300.0, 250.75])
+        cam = {"projection_mode": "perspective", "f": f, "cx": cx, "cy": cy}
+        ref = [torch.stack([cx[:, None] + (f[:, None] / p[:, 2]) * p[:, 0], cy[:, None] + (f[:, None] / p[:, 2]) * p[:, 1]], 1) for p in (xyz1, xyz2)]
+    for r in ref:
+        r[:, 0] *= sx
+        r[:, 1] *= sy
+    cam_dev = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in cam.items()}
+    got = U.project_points(xyz1.to(DEV), top.to(DEV)[B:, :, :N], cam_dev, sx, sy)
+    assert got.shape == (2 * B, 2, N) and torch.equal(got.cpu(), torch.cat(ref, 0))
+    assert torch.equal(U.project_points(xyz1.to(DEV), None, cam_dev, sx, sy).cpu(), ref[0])
+
+
+def test_grid_sample_sources_equals_the_fusers_op_sequence():
+    """grid_sample_sources([(corr, -, -), (flow, (sx, sy), flow_3d_xy), (events, -, -)], xy) == what CorrFeatureFuser3D computes
+    around its two grid_sample_wrapper calls (RPEFlow_core.py:103-111): flow * scale, cat, sample, -=, sample, cat -- bit for bit
+    against those steps through the one-source operator and PyTorch; points outside the map, odd sizes, a channel-sliced source."""
+    g = torch.Generator().manual_seed(13)
+    for B, C, E, H, W, N in [(2, 81, 32, 18, 30, 512), (1, 5, 3, 7, 9, 100), (3, 81, 128, 9, 15, 256)]:
+        corr, flow = torch.randn(B, C, H, W, generator=g).to(DEV), torch.randn(B, 2, H, W, generator=g).to(DEV)
+        wide = torch.randn(B, E + 3, H, W, generator=g).to(DEV)
+        events = wide[:, 1:E + 1]  # not contiguous: batch stride (E + 3) H W
+        xy = (torch.rand(B, 2, N, generator=g) * torch.tensor([W + 3.0, H + 3.0])[None, :, None] - 1.5).to(DEV)
+        flow_3d = torch.randn(B, 3, N, generator=g).to(DEV)
+        sx, sy = (30 - 1) / (W - 1), (18 - 1) / (H - 1)
+        scaled = flow * torch.tensor([sx, sy], device=DEV).view(1, 2, 1, 1)
+        a = U.grid_sample_wrapper(torch.cat([corr, scaled], 1), xy)
+        a[:, -2:] -= flow_3d[:, :2]
+        ref = torch.cat([a, U.grid_sample_wrapper(events.contiguous(), xy)], 1)
+        got = U.grid_sample_sources([(corr, None, None), (flow, (sx, sy), flow_3d[:, :2]), (events, None, None)], xy)
+        assert got.shape == ref.shape and torch.equal(got, ref)
+    # and the one-source form against the oracle (the operator's own parity lives in test_glue_ops_against_*)
+    f = torch.randn(2, 7, 6, 11, generator=g)
+    xy = torch.rand(2, 2, 50, generator=g) * torch.tensor([10.0, 5.0])[None, :, None]
+    close(U.grid_sample_sources([(f.to(DEV), None, None)], xy.to(DEV)), O.grid_sample_wrapper(f.numpy(), xy.numpy()), 3e-6)
+
+
+def test_knn_interpolation_of_a_pair_and_backwarp_residual():
+    """knn_interpolation(xyz, (a, b), q) == knn_interpolation(xyz, cat([a, b]), q), and backwarp_3d's "xyz2 + flow21" inside the
+    launch == the separate add: bit for bit; strided sources (channel slices, prefix views)."""
+    g = torch.Generator().manual_seed(14)
+    coarse, fine = torch.randn(2, 3, 300, generator=g).to(DEV), torch.randn(2, 3, 700, generator=g).to(DEV)
+    wide = torch.randn(2, 80, 400, generator=g).to(DEV)
+    a, b = wide[:, 2:5, :300], wide[:, 10:74, :300]
+    ref = U.knn_interpolation(coarse, torch.cat([a, b], 1), fine)
+    got = U.knn_interpolation(coarse, (a, b), fine)
+    assert got.shape == (2, 67, 700) and torch.equal(got, ref)
+    assert torch.equal(U.knn_interpolation(coarse, (a, wide[:, :0, :300]), fine), ref[:, :3])  # an empty second tensor
+    xyz1, xyz2, flow = coarse, torch.randn(2, 3, 300, generator=g).to(DEV), 0.1 * torch.randn(2, 3, 300, generator=g).to(DEV)
+    warped = U.backwarp_3d(xyz1, xyz2, flow)
+    w = xyz1 + flow
+    idx = U.k_nearest_neighbor(w, xyz2, 3)
+    assert torch.equal(warped, xyz2 + U._interpolate(w, flow, xyz2, idx, 3, scale=-1.0))
+    close(warped, O.backwarp_3d(xyz1.cpu().numpy(), xyz2.cpu().numpy(), flow.cpu().numpy()), 1e-5)
+
+
+def test_project_feat_with_a_scaled_tail():
+    """project_feat_with_nn_corr(..., feat_3d, feat_3d_tail=t, tail_scale=(sx, sy)) == the call on cat([feat_3d, t * (sx, sy)])
+    (RPEFlow_core.py:371-373), with and without the caller's samples, on the coarse-map kernel and the per-pixel one."""
+    g = torch.Generator().manual_seed(15)
+    for B, C2, C3, H, W, N in [(2, 81, 32, 9, 15, 256), (1, 20, 7, 36, 60, 900), (4, 81, 192, 72, 120, 2048)]:
+        xy = (torch.rand(B, 2, N, generator=g) * torch.tensor([W - 1.0, H - 1.0])[None, :, None]).to(DEV)
+        f2, f3 = torch.randn(B, C2, H, W, generator=g).to(DEV), torch.randn(B, C3, N, generator=g).to(DEV)
+        flow = torch.randn(B, 3, N, generator=g).to(DEV)
+        nn = torch.randint(0, N, (B, H * W), generator=g).to(DEV)
+        sub, app = torch.randn(B, 2, H, W, generator=g).to(DEV), torch.randn(B, 5, H, W, generator=g).to(DEV)
+        sx, sy = (W - 1) / 29, (H - 1) / 17
+        tail = flow[:, :2] * torch.tensor([sx, sy], device=DEV).view(1, 2, 1)
+        ref = U.project_feat_with_nn_corr(xy, f2, torch.cat([f3, tail], 1), nn, subtract_last=sub, append=app)
+        got = U.project_feat_with_nn_corr(xy, f2, f3, nn, subtract_last=sub, append=app, feat_3d_tail=flow[:, :2], tail_scale=(sx, sy))
+        assert torch.equal(got, ref)
+        sampled = U.grid_sample_wrapper(f2, xy)
+        assert torch.equal(U.project_feat_with_nn_corr(xy, f2, f3, nn, sampled_2d=sampled, subtract_last=sub, append=app,
+                                                       feat_3d_tail=flow[:, :2], tail_scale=(sx, sy)), ref)
+
+
+def test_pointwise_conv_reads_channel_slices_where_they_lie():
+    """conv_module(1x1, x, residual=r) with x and r channel slices of wider tensors (batch stride larger than C P) == the call on
+    contiguous copies: the flow heads add the up-sampled flow, a slice of [flow | features] (RPEFlow_core.py:409-410)."""
+    torch.manual_seed(16)
+    conv = torch.nn.Conv1d(64, 3, 1).to(DEV)
+    wide_x, wide_r = torch.randn(4, 70, 512, device=DEV), torch.randn(4, 67, 512, device=DEV)
+    x, r = wide_x[:, 3:67], wide_r[:, :3]
+    with torch.no_grad():
+        got = U.conv_module(conv, x, residual=r)
+        assert torch.equal(got, U.conv_module(conv, x.contiguous(), residual=r.contiguous()))
+        close(got, (r + conv(x)).cpu().numpy(), 1e-5)
+        odd = U.conv_module(conv, wide_x[:, 3:67, :511], residual=wide_r[:, :3, :511])  # not dense per sample: copied, same values
+        close(odd, (wide_r[:, :3, :511] + conv(wide_x[:, 3:67, :511])).cpu().numpy(), 1e-5)
+
+
+def test_pyramid_of_stacked_clouds_and_constant_level0_feature():
+    """build_pc_pyramid on the two halves of one [2B,3,N] tensor (no cat, one gather) == on separate tensors; FeaturePyramid3D's
+    level-0 feature computed on one point and broadcast == computed on every point (pwc3d_core.py:51-52), bit for bit."""
+    g = torch.Generator().manual_seed(17)
+    both = (torch.randn(4, 3, 2000, generator=g) * 5).to(DEV)
+    a, b = both[:2].clone(), both[2:].clone()
+    x1, x2, i1, i2, stacked = P3.build_pc_pyramid(both[:2], both[2:], [512, 128], return_both=True)
+    y1, y2, j1, j2 = P3.build_pc_pyramid(a, b, [512, 128])
+    for u, v in zip(x1 + x2 + i1 + i2, y1 + y2 + j1 + j2):
+        assert torch.equal(u, v)
+    for lvl in range(3):
+        assert torch.equal(stacked[lvl], torch.cat([x1[lvl], x2[lvl]], 0))
+    torch.manual_seed(18)
+    pyramid = P3.FeaturePyramid3D([16, 32, 64], norm="batch_norm", k=16).to(DEV).eval()
+    for m in pyramid.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.5, 2.0)
+    with torch.no_grad():
+        feats = pyramid(stacked)
+        full = pyramid.level0_mlp(torch.zeros_like(stacked[0]))
+        assert feats[0].shape == full.shape and torch.equal(feats[0], full)
+        assert feats[0].stride(2) == 0  # ONE vector, broadcast
+    with torch.enable_grad():
+        assert pyramid(stacked)[0].stride(2) != 0  # (with autograd on: the reference's op sequence)

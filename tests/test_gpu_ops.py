@@ -114,6 +114,23 @@ def test_knn_matrix_kernel_shapes(B, M, Q, D, k):
     assert np.array_equal(cf.cpu().numpy(), oi)
 
 
+@pytest.mark.parametrize("B,M,Q,D,k", [
+    # the decoder's mid-size searches, which the size gate keeps on the insertion kernel: forced through the matrix kernel
+    # (RPE_KNN_ALGO_MATRIX) and through the insertion kernel (RPE_KNN_ALGO_INSERT), both = the oracle, ties included
+    (4, 2048, 2048, 3, 16), (4, 1024, 1024, 3, 16), (4, 1024, 2048, 3, 3), (2, 256, 300, 3, 3), (3, 300, 70, 2, 4), (1, 1024, 17, 3, 16),
+    (2, 4096, 1000, 3, 16), (2, 260, 33, 1, 2),
+])
+def test_knn_forced_kernels_agree_on_mid_size_searches(B, M, Q, D, k):
+    r = I.rng(7400 + M + Q + k)
+    inp, qry = I.ids_cloud(r, B, M, D), I.ids_cloud(r, B, Q, D)
+    inp[:, M // 2:M // 2 + 20] = inp[:, :20]  # duplicated points: equal distances in some rows
+    oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True)
+    for algo in ("matrix", "insert", "auto"):
+        idx, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k, algo=algo)
+        assert np.array_equal(idx.cpu().numpy(), oi), algo
+        assert_bits_equal(dist.cpu().numpy(), od, algo)
+
+
 def test_knn_duplicates_and_strided_views():
     r = I.rng(7100)
     base = I.unit_cloud(r, 2, 150, 3)
