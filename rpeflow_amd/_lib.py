@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RPE_HIP_LIB") or os.path.join(_HERE, "csrc", "librpeflow_hip.so")  # (RPE_HIP_LIB: diagnostic builds, tools/exp)
+LIB_PATH = os.environ.get("RPE_HIP_LIB") or os.path.join(_HERE, "csrc", "librpeflow_hip.so")  # (RPE_HIP_LIB: diagnostic builds, e.g. tools/corr_energy_probes.sh)
 
 _c_f32p = ctypes.c_void_p
 _c_i64 = ctypes.c_int64

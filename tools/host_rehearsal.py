@@ -14,7 +14,13 @@ staging -- the contended resource: cores and DRAM bandwidth -- does all of its w
 Prints one JSON line: per-rank batches/s (capacity of the host side; a rank needs 64 per second to keep an MI355X at
 15.6 ms per batch fed), CPU seconds per batch, cores in use.
 
-    python tools/host_rehearsal.py --ranks 8 --batches 96
+``--real-rank R`` (round 5): rank R is a REAL rank -- the true rpeflow_amd.evaluate.evaluate() on the box's GPU (model, HIP-graph
+replay with the next batch's sampling inside, copy stream, device accumulators, a world-size-1 nccl group for its collective)
+moving the whole of every batch over the PCIe link -- while the other ranks play the host side of their GPUs beside it under the
+same core quota (their copy threads move 1 / 64 of every tensor, so the link is the real rank's).  Its batches/s against the
+same run with ``--ranks 1`` is what seven neighbours cost a rank; hipGraphLaunch host time p50 / p99 is reported with it.
+
+    python tools/host_rehearsal.py --ranks 8 --batches 96 [--real-rank 0]
 """
 import argparse
 import json
@@ -42,6 +48,12 @@ def child(args):
     dev = torch.device("cuda", 0) if args.device == "cuda" else torch.device("cpu")
     if dev.type == "cuda":
         torch.cuda.set_device(dev)
+    real = args.real_rank is not None and rank == args.real_rank
+    if args.real_rank is not None:
+        # the real rank's own world-size-1 nccl group (new_group is collective over the default group: every rank calls it)
+        solo = dist.new_group(ranks=[args.real_rank], backend="nccl") if dev.type == "cuda" else None
+    if real:
+        return real_child(args, rank, world, dev, solo, dist)
     n = world * args.batches * args.batch
     data = SyntheticPairs(n, args.height, args.width, 8192, distinct=world * args.distinct, cache=True, pin=args.pinned)
     mine = E.shard_indices(n, rank, world)
@@ -71,17 +83,63 @@ def child(args):
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
     if rank == 0:
-        rates = [g["batches_per_s"] for g in gathered]
-        print(json.dumps({
-            "what": "host side of a %d-rank evaluation on one node, rehearsed on one box (tools/host_rehearsal.py)" % world,
-            "ranks": world, "usable_cores": runtime.usable_cores(), "batch": args.batch, "frame": [args.height, args.width],
-            "batches_per_rank": args.batches, "staging": "none (samples pinned)" if args.pinned else "pinned ring of host batches",
-            "copy_fraction": float(os.environ.get("RPE_PIPE_COPY_FRACTION", "1")), "replay_stand_in_ms": args.host_ms,
-            "batches_per_s_per_rank": rates, "min_batches_per_s": min(rates), "needed_batches_per_s": args.need,
-            "feeds_the_gpus": bool(min(rates) >= args.need), "frame_pairs_per_s_capacity": round(sum(rates) * args.batch, 1),
-            "cores_in_use_total": round(sum(g["cores_in_use"] for g in gathered), 2), "per_rank": gathered}), flush=True)
+        report(args, world, gathered, runtime)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def real_child(args, rank, world, dev, solo, dist):
+    """The real rank: evaluate() over args.batches batches (its shard's worth), timed like the host-only ranks time theirs."""
+    import torch
+    from rpeflow_amd import evaluate as E
+    from rpeflow_amd import runtime
+    from rpeflow_amd.model import RPEFlow
+    from rpeflow_amd.synthetic import SyntheticPairs, load_seeded_parameters
+    model = load_seeded_parameters(RPEFlow()).to(dev).eval()
+    forward = E.GraphedForward(model)
+    n = args.batches * args.batch
+    data = SyntheticPairs(n, args.height, args.width, 8192, distinct=args.distinct, cache=True, pin=args.pinned, first_seed=1000 + rank * args.distinct)
+    t_gen = data.prepare(threads=2)
+    workers = E.default_workers() if args.workers is None else args.workers
+    warm = SyntheticPairs(3 * args.batch, args.height, args.width, 8192, distinct=args.distinct, first_seed=1000 + rank * args.distinct)
+    warm.cache = data.cache
+    E.evaluate(model, warm, args.batch, dev, 0, 1, group=solo, forward=forward, workers=workers)  # capture, MIOpen search, rings: untimed
+    torch.cuda.synchronize()
+    dist.barrier()  # everyone's set is generated, this rank's graph is captured: the host-only ranks warm their pipelines up now
+    dist.barrier()  # the start line
+    forward.host_times = []
+    stats = {}
+    t0, c0 = time.perf_counter(), time.process_time()
+    metrics, _ = E.evaluate(model, data, args.batch, dev, 0, 1, group=solo, forward=forward, workers=workers, stats=stats)
+    torch.cuda.synchronize()
+    dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+    launch = sorted(forward.host_times)
+    pct = lambda q: round(launch[min(len(launch) - 1, int(q * len(launch)))] * 1e3, 3) if launch else None
+    out = {"rank": rank, "real": True, "batches_per_s": round(args.batches / dt, 2), "ms_per_batch": round(dt / args.batches * 1e3, 3),
+           "cpu_s_per_batch": round(cpu / args.batches, 5), "cores_in_use": round(cpu / dt, 2), "loader_threads": stats.get("workers", workers),
+           "h2d_MB_per_batch": round(stats["bytes"] / max(1, stats["batches"]) / 1e6, 1), "hipGraphLaunch_host_ms": {"p50": pct(0.5), "p99": pct(0.99), "max": pct(1.0)},
+           "collective": "world-size-1 nccl group" if solo is not None else "none", "epe2d": metrics["EPE2D"], "generator_s_untimed": round(t_gen, 2)}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, out)
+    if rank == 0:
+        report(args, world, gathered, runtime)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def report(args, world, gathered, runtime):
+    rates = [g["batches_per_s"] for g in gathered]
+    real = [g for g in gathered if g.get("real")]
+    print(json.dumps({
+        "what": "host side of a %d-rank evaluation on one node, rehearsed on one box (tools/host_rehearsal.py)" % world,
+        "ranks": world, "usable_cores": runtime.usable_cores(), "batch": args.batch, "frame": [args.height, args.width],
+        "batches_per_rank": args.batches, "staging": "none (samples pinned)" if args.pinned else "pinned ring of host batches",
+        "copy_fraction_host_only_ranks": float(os.environ.get("RPE_PIPE_COPY_FRACTION", "1")), "replay_stand_in_ms": args.host_ms,
+        "real_rank": real[0] if real else None,
+        "batches_per_s_per_rank": rates, "min_batches_per_s": min(rates), "needed_batches_per_s": args.need,
+        "feeds_the_gpus": bool(min(r for g, r in zip(gathered, rates) if not g.get("real")) >= args.need) if len(real) < world else None,
+        "frame_pairs_per_s_capacity": round(sum(rates) * args.batch, 1),
+        "cores_in_use_total": round(sum(g["cores_in_use"] for g in gathered), 2), "per_rank": gathered}), flush=True)
 
 
 def main():
@@ -97,6 +155,7 @@ def main():
     p.add_argument("--workers", type=int, default=None)
     p.add_argument("--pinned", action="store_true", help="cached set in pinned memory: no staging pass")
     p.add_argument("--device", choices=["cuda", "cpu"], default="cuda")
+    p.add_argument("--real-rank", type=int, default=None, help="this rank runs the true evaluate() on the GPU; the others stay host-only")
     p.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     args = p.parse_args()
     if args.child:
@@ -108,13 +167,35 @@ def main():
     for r in range(args.ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.ranks), LOCAL_WORLD_SIZE=str(args.ranks),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("RPE_PIPE_COPY_FRACTION", str(1.0 / args.ranks))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child"] + sys.argv[1:], env=env, cwd=ROOT))
+        if args.real_rank is None:
+            env.setdefault("RPE_PIPE_COPY_FRACTION", str(1.0 / args.ranks))
+        elif r == args.real_rank:
+            env["RPE_PIPE_COPY_FRACTION"] = "1"
+            env["RPE_EVAL_TIMELINE"] = "1"  # (host seconds inside graph.replay() per batch)
+        else:
+            env.setdefault("RPE_PIPE_COPY_FRACTION", str(1.0 / 64))
+        # own session per rank: a timeout (or Ctrl-C) of this launcher takes every rank's process group down with it
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child"] + sys.argv[1:], env=env, cwd=ROOT, start_new_session=True))
     rc = 0
-    for proc in procs:
-        rc = proc.wait() or rc
+    try:
+        for proc in procs:
+            rc = proc.wait() or rc
+    finally:
+        import signal
+        for proc in procs:
+            if proc.poll() is None:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
     raise SystemExit(rc)
 
 
+def _terminate(signum, frame):
+    raise SystemExit(128 + signum)
+
+
 if __name__ == "__main__":
+    import signal
+    signal.signal(signal.SIGTERM, _terminate)  # `timeout` sends SIGTERM: unwind through main()'s finally, which reaps the ranks
     main()
