@@ -1526,10 +1526,16 @@ __global__ __launch_bounds__(256) void sqdist_kernel(const float *__restrict__ a
 #ifndef RPE_KNN_WAVE_TARGET
 #define RPE_KNN_WAVE_TARGET 2048
 #endif
-int pick_qw(int B, int Q) {
+// queries per wave of the insertion / lane-minimum kernels.  Two queries a wave is NOT offered to the selection kernel (k >= 2):
+// measured (tools/knn_gate_table.py with RPE_KNN_WAVE_TARGET = 1024 / 2048 / 4096 builds, profiles/r05_knn_gate_table.txt) the
+// QW = 2 instantiation is the slow one at every size it was picked for -- 4 x (1024 -> 1024), k = 16: 55.9 us against 36.6 with one
+// query a wave and 45.5 with four; k = 3: 38.5 against 14.8 -- so a search too small for four queries a wave takes one.
+int pick_qw(int B, int Q, int k) {
     const long target = RPE_KNN_WAVE_TARGET;  // waves wanted in flight: 256 CUs x 4 SIMDs x 2 (1024 ... 4096 measure the same; 8192 and more are slower)
-    for (int qw = 8; qw > 1; qw >>= 1)
+    for (int qw = 8; qw > 1; qw >>= 1) {
+        if (qw == 2 && k >= 2) continue;
         if ((long)B * ((Q + qw - 1) / qw) >= target) return qw;
+    }
     return 1;
 }
 
@@ -1622,7 +1628,7 @@ int launch_group(const rpe_knn_job *const *jobs, char *const *ws, int njobs, boo
         else hipLaunchKernelGGL(knn_tie_replay_kernel<1>, rgrid, rblock, lds, st, packed, touts, B, k);
         return rpe_launch_status();
     }
-    const int qw = pick_qw(B, (int)total_q);
+    const int qw = pick_qw(B, (int)total_q, k);
     if (D == 3) return launch_knn_d<3>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
     if (D == 2) return launch_knn_d<2>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);
     return launch_knn_d<1>(qw, packed, njobs, max_q, min_m, max_m, B, k, tie_mode, st);

@@ -199,7 +199,9 @@ class HotPathWorkload(torch.nn.Module):
             n = xyz1.shape[-1]
             scale, centre, grid = self.scale[level], self.centre[level], self.grid[level]
             f_2d_both, f_3d_both = self.feats_2d_both[level], feats_both[level]
-            with t.span("torch_glue"):  # project_pc2image 'parallel' + rescale (RPEFlow_core.py:316-324)
+            # project_pc2image 'parallel' + rescale (RPEFlow_core.py:316-324): one launch with the native operators, tensor ops
+            # ("torch_glue") with a port of the reference
+            with t.span("project_pc2image" if shares else "torch_glue"):
                 if shares:
                     xy_both = project_points(xyz1, xyz2, self.camera, self.scale_xy[level][0], self.scale_xy[level][1])
                 else:
@@ -221,10 +223,10 @@ class HotPathWorkload(torch.nn.Module):
                 project_feat_with_nn_corr(xy_both, f_2d_both, f_3d_both, nn_proj_both[..., 0], **({"sampled_2d": sampled} if shares else {}))
 
             if level == 5:
-                with t.span("torch_glue"):
-                    if shares:  # constants, as rpeflow_amd.model keeps them
-                        last_flow_3d, last_flow_feat_3d = self.zero_flow_3d, self.zero_flow_feat_3d
-                    else:
+                if shares:  # constants, as rpeflow_amd.model keeps them
+                    last_flow_3d, last_flow_feat_3d = self.zero_flow_3d, self.zero_flow_feat_3d
+                else:
+                    with t.span("torch_glue"):
                         last_flow_3d = torch.zeros(B, 3, n, device=xyz1.device)
                         last_flow_feat_3d = torch.zeros(B, 64, n, device=xyz1.device)
                 xyz2_warp, f2_2d_warp = xyz2, f2_2d
@@ -274,7 +276,9 @@ class HotPathWorkload(torch.nn.Module):
             with t.span("project_feat"):
                 project_feat_with_nn_corr(xy1, self.flow_feat_2d[level], flow_feat_3d, nn_proj1[..., 0], **({"sampled_2d": sampled} if shares else {}))
 
-            with t.span("torch_glue"):  # conv_last_3d + the residual flow (RPEFlow_core.py:409-410)
+            # conv_last_3d + the residual flow (RPEFlow_core.py:409-410): the 1x1 kernel with the residual in its epilogue, or a
+            # library convolution and an add
+            with t.span("flow_head_3d" if shares else "torch_glue"):
                 if shares:
                     flows_3d.append(conv_module(self.flow_head_3d, flow_feat_3d, residual=last_flow_3d))
                 else:

@@ -86,5 +86,9 @@ def hotpath_bytes(B, sizes, n_points=8192):
     out["flow_estimator_3d"] = sum(2 * conv1x1(B, C[l], 64, N[l]) + pointconv(B, N[l], N[l], 195, 128, False)
                                    + pointconv(B, N[l], N[l], 128, 128, False) + conv1x1(B, 128, 128, N[l])
                                    + conv1x1(B, 128, 64, N[l]) for l in lv)
-    out["torch_glue"] = sum(4 * B * N[l] * (2 * 2 * 2 + 2 * 67 + 3 * 3 + 64) for l in lv)  # projections, zero fills, flow head
+    # project_pc2image + rescale of both clouds (read x, y; write u, v), and the flow head (read 64 features + 3 flow, write 3);
+    # a port of the reference passed as ``ops`` reports both, with its zero fills, under "torch_glue" -- the same bytes
+    out["project_pc2image"] = sum(4 * 2 * B * N[l] * (2 + 2) for l in lv)
+    out["flow_head_3d"] = sum(4 * B * N[l] * (64 + 3 + 3) + 4 * 64 * 3 for l in lv)
+    out["torch_glue"] = out["project_pc2image"] + out["flow_head_3d"]
     return out

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""What clock does the correlation microbench (BASELINE config 2) run at, and is its cycle count constant?
+"""What clock does the correlation microbench (BASELINE config 2) -- or, with --op, one of the level-1 1x1 layers -- run at, and is
+its cycle count constant?
 
 Three instruments gave three answers in round 4 (hwmon 157 / 2350 MHz, the round-3 power trace 1964 MHz, GRBM_GUI_ACTIVE
 1.5-2.0 GHz).  This tool uses the one that is measured on the device the kernel runs on, in the stream it runs in:
@@ -71,14 +72,28 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--launches", type=int, default=400)
     p.add_argument("--out", default=None)
+    p.add_argument("--op", default="corr", choices=["corr", "pw_in", "pw_mid", "pw_out"],
+                   help="corr: the correlation microbench; pw_*: the level-1 cross block's 1x1 layers over 4 x 144 x 240 "
+                        "(96 -> 510 project_in, 96 -> 96, 255 -> 96 + residual project_out)")
     args = p.parse_args()
+    torch.set_grad_enabled(False)
     dev = torch.device("cuda", 0)
     bdf, hdir = hwmon_dir(dev)
     report = {"device": torch.cuda.get_device_name(dev), "pci": bdf, "hwmon_dir": hdir, "launches": args.launches}
 
     # 1. idle against busy
-    x = torch.randn(1, 256, 544, 960, device=dev)
-    y = torch.randn(1, 256, 544, 960, device=dev)
+    if args.op == "corr":
+        x = torch.randn(1, 256, 544, 960, device=dev)
+        y = torch.randn(1, 256, 544, 960, device=dev)
+        launch = lambda a, b: ops.correlation2d(a, b, 4)
+    else:
+        from rpeflow_amd import utils as U
+        cin, cout, res = {"pw_in": (96, 510, False), "pw_mid": (96, 96, False), "pw_out": (255, 96, True)}[args.op]
+        conv = torch.nn.Conv2d(cin, cout, 1, bias=False).to(dev)
+        x = torch.randn(4, cin, 144, 240, device=dev)
+        y = torch.randn(4, cout, 144, 240, device=dev)  # the residual of project_out
+        launch = (lambda a, b: U.conv_module(conv, a, residual=b)) if res else (lambda a, b: U.conv_module(conv, a))
+    report["op"] = args.op
     torch.cuda.synchronize()
     time.sleep(1.0)
     idle = runtime.ShaderClock(dev)
@@ -94,7 +109,7 @@ def main():
     report["kinds"] = {}
     for name, (a, b) in kinds.items():
         for _ in range(150):  # settle
-            ops.correlation2d(a, b, 4)
+            launch(a, b)
         torch.cuda.synchronize()
         mon = Hwmon(hdir)
         mon.start()
@@ -103,7 +118,7 @@ def main():
         s.record()
         with clock:
             for _ in range(args.launches):
-                ops.correlation2d(a, b, 4)
+                launch(a, b)
         e.record()
         torch.cuda.synchronize()
         mon.stop_flag.set()

@@ -1,5 +1,5 @@
 """Single hot-path operators at the forward's level-1 shapes, for rocprofv3 --pmc / --kernel-trace runs.
-Usage: python3 tools/prof_ops.py <pointconv|knn16|knn3|knn2d|corr3d|project> [iters]"""
+Usage: python3 tools/prof_ops.py <pointconv|knn16|knn3|knn2d|corr3d|project|pw_l1> [iters]"""
 import os
 import sys
 
@@ -52,6 +52,11 @@ with torch.no_grad():
         nn = k_nearest_neighbor(xy, U.mesh_grid(B, H, W, dev).reshape(B, 2, -1), 1)[..., 0]
         sampled = U.grid_sample_wrapper(feat2d, xy)  # what the 3-D fuser of the pair has already (the decoder levels pass it on)
         step = lambda: (U.project_feat_with_nn_corr(xy, feat2d, feat3d, nn), U.project_feat_with_nn_corr(xy, feat2d, feat3d, nn, sampled_2d=sampled))
+    elif which == "pw_l1":  # the level-1 cross block's GDFN project_in: 96 -> 510 channels over 4 x 144 x 240 (restormer_arch.py:207-222), 13.5 GFLOP
+        from rpeflow_amd import utils as U
+        conv = torch.nn.Conv2d(96, 510, 1, bias=False).to(dev)
+        x = torch.randn(4, 96, 144, 240, device=dev)
+        step = lambda: U.conv_module(conv, x)
     else:
         raise SystemExit("unknown operator " + which)
     for _ in range(iters):
