@@ -104,7 +104,7 @@ def pmc_traffic(suffix):
     return None, None
 
 
-def clocked(frac, clock, dev):
+def clocked(frac, clock, dev, launches=0):
     """Extra fields of a roofline object: the clock the shader engines ran at DURING the timed launches -- two clock stamps on the
     stream around them (rpeflow_amd.runtime.ShaderClock: d s_memtime / d s_memrealtime), else the hwmon reading of this very
     device, else null -- and the fraction scaled to the nominal clock, null unless the clock is plausible and the result <= 1."""
@@ -114,6 +114,7 @@ def clocked(frac, clock, dev):
     at_nominal = round(frac * NOMINAL_SCLK_MHZ / sclk, 4) if sclk else None
     cycles, ticks, khz = clock.raw()
     return {"sclk_MHz": sclk, "sclk_source": source if sclk else None, "sclk_stamp_raw": {"shader_cycles": cycles, "wall_ticks": ticks, "wall_kHz": khz},
+            "shader_cycles_per_launch": round(cycles / launches) if (sclk and launches) else None,  # (compare: GRBM_GUI_ACTIVE / 8 of the PMC pass)
             "frac_at_nominal_clock": at_nominal if (at_nominal is not None and at_nominal <= 1.0) else None}
 
 
@@ -146,7 +147,7 @@ def corr_microbench(dev, iters=40):
     frac = gbs / HBM_PEAK_GBS
     return {"kernel": "corr_mfma_dma_kernel<2,8,2,3,3,true>", "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(frac, 4), "traffic": traffic, "traffic_source": source, "us_per_launch": round(us, 1),
-            **clocked(frac, clock, dev), "copy_GBs_measured": round(copy_gbs, 1), "frac_of_measured_copy_bw": round(gbs / copy_gbs, 4),
+            **clocked(frac, clock, dev, iters), "copy_GBs_measured": round(copy_gbs, 1), "frac_of_measured_copy_bw": round(gbs / copy_gbs, 4),
             "frac_of_guide_copy_bw": round(gbs / HBM_COPY_GBS, 4),
             "algorithmic_bytes": alg, "workload": "correlation2d 1x256x544x960 md=4 fp32 NCHW (BASELINE config 2)"}
 
@@ -163,14 +164,15 @@ def knn_microbench(dev, iters=30):
         ops.k_nearest_neighbor(cloud, query, k)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    clock = runtime.ShaderClock(dev)
     s.record()
-    with clock:
-        for _ in range(iters):
-            ops.k_nearest_neighbor(cloud, query, k)
+    for _ in range(iters):
+        ops.k_nearest_neighbor(cloud, query, k)
     e.record()
     torch.cuda.synchronize()
-    us = s.elapsed_time(e) / iters * 1e3  # (the two one-wave stamp kernels inside the pair: ~4 us over >= 5 ms of launches)
+    us = s.elapsed_time(e) / iters * 1e3
+    # (no engine-clock fields here: the stamps read XCD 0's cycle counter, which stands still while that XCD idles -- the tail of
+    # the tied rows' replay launch keeps a few waves busy and the rest of the chip gated: 1430 "MHz" was read over these launches.
+    # The correlation loop keeps every XCD busy from the first stamp to the second; there the reading is the clock.)
     from rpeflow_amd.csrc.wrapper import k_nearest_neighbor_ties
     for _ in range(5):
         k_nearest_neighbor_ties(cloud, query, k, ties="index")
@@ -189,7 +191,7 @@ def knn_microbench(dev, iters=30):
     frac = tflops / MFMA_F32_PEAK_TFLOPS
     return {"kernel": "knn_mfma_kernel<3, true> + knn_tie_replay_kernel<3> (the sweep, then its tied rows redone the libstdc++ way by a second launch)",
             "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(frac, 4),
-            "traffic": traffic, "traffic_source": source, **clocked(frac, clock, dev),
+            "traffic": traffic, "traffic_source": source,
             "us_per_launch": round(us, 1), "launches": 2, "pairs_per_s": round(pairs / us * 1e6), "algorithmic_bytes": 4 * B * D * (M + Q) + 8 * B * Q * k,
             "us_per_launch_lowest_index_ties": round(us_index, 1),  # the same search without the libstdc++ restatement of equal distances
             "frac_lowest_index_ties": round(pairs * (2 * D + 3) / us_index / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),

@@ -63,7 +63,12 @@ class ShaderClock:
     (rpe_clock_stamp: s_memtime and s_memrealtime read by one wave) in front of and one behind the launches;
     ``c.mhz()`` (after the stream has been synchronised) = d(shader cycles) / d(constant-rate ticks) x the constant rate.
     ``None`` -- never a number -- when the result is not a plausible engine clock (e.g. a part whose s_memtime does not
-    follow the engine clock): callers fall back to ``hwmon_sclk_mhz`` or print null."""
+    follow the engine clock): callers fall back to ``hwmon_sclk_mhz`` or print null.
+    Measured on gfx950 (profiles/r05_corr_clock.json): the counter follows the engine clock -- 1.6 MHz over an idle half
+    second, 2395 MHz under a compute loop with constant operands, 2023 MHz when the same loop hits the package power limit --
+    and the cycles per launch it gives (804 k) equal GRBM_GUI_ACTIVE / 8 of a PMC pass (801 k).  The one-wave stamp kernel runs
+    on the XCD that takes the first workgroup of a dispatch, and an idle XCD's counter stands still: the reading is the clock
+    only for stretches that keep the whole chip busy (a launch with a long thin tail reads low)."""
 
     def __init__(self, device):
         import ctypes

@@ -19,6 +19,8 @@ replay with the next batch's sampling inside, copy stream, device accumulators, 
 moving the whole of every batch over the PCIe link -- while the other ranks play the host side of their GPUs beside it under the
 same core quota (their copy threads move 1 / 64 of every tensor, so the link is the real rank's).  Its batches/s against the
 same run with ``--ranks 1`` is what seven neighbours cost a rank; hipGraphLaunch host time p50 / p99 is reported with it.
+``--pace R``: the host-only ranks take at most R batches per second -- ranks whose GPU needs 15 ms a batch do not ask for more;
+unpaced they run at the host's capacity (80-100 batches/s) and take more than a real neighbour's share of the cores.
 
     python tools/host_rehearsal.py --ranks 8 --batches 96 [--real-rank 0]
 """
@@ -65,11 +67,18 @@ def child(args):
         pipe = InputPipeline(data, indices, args.batch, dev, workers=workers)
         t0, c0 = time.perf_counter(), time.process_time()
         spin = 0.0
+        period = 1.0 / args.pace if args.pace > 0 else 0.0
+        due = time.perf_counter()
         for batch, upcoming in pipe.pairs():
             t_end = time.perf_counter() + args.host_ms * 1e-3  # the host side of one replay: hipGraphLaunch + the loop
             while time.perf_counter() < t_end:
                 pass
             spin += args.host_ms * 1e-3
+            if period:  # a real rank is paced by its GPU: it asks for the next batch when the replay is done, not earlier
+                due = max(due + period, time.perf_counter() - 4 * period)
+                wait = due - time.perf_counter()
+                if wait > 0:
+                    time.sleep(wait)
         if dev.type == "cuda":
             torch.cuda.synchronize()
         return time.perf_counter() - t0, time.process_time() - c0, spin, pipe.stats
@@ -135,6 +144,7 @@ def report(args, world, gathered, runtime):
         "ranks": world, "usable_cores": runtime.usable_cores(), "batch": args.batch, "frame": [args.height, args.width],
         "batches_per_rank": args.batches, "staging": "none (samples pinned)" if args.pinned else "pinned ring of host batches",
         "copy_fraction_host_only_ranks": float(os.environ.get("RPE_PIPE_COPY_FRACTION", "1")), "replay_stand_in_ms": args.host_ms,
+        "host_only_ranks_paced_at_batches_per_s": args.pace or None,
         "real_rank": real[0] if real else None,
         "batches_per_s_per_rank": rates, "min_batches_per_s": min(rates), "needed_batches_per_s": args.need,
         "feeds_the_gpus": bool(min(r for g, r in zip(gathered, rates) if not g.get("real")) >= args.need) if len(real) < world else None,
@@ -155,6 +165,8 @@ def main():
     p.add_argument("--workers", type=int, default=None)
     p.add_argument("--pinned", action="store_true", help="cached set in pinned memory: no staging pass")
     p.add_argument("--device", choices=["cuda", "cpu"], default="cuda")
+    p.add_argument("--pace", type=float, default=0.0, help="host-only ranks take at most this many batches per second, as ranks paced by a GPU do "
+                                                            "(0: as fast as the host side goes -- the capacity measurement)")
     p.add_argument("--real-rank", type=int, default=None, help="this rank runs the true evaluate() on the GPU; the others stay host-only")
     p.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     args = p.parse_args()

@@ -57,9 +57,12 @@ if has pmc; then
   pmc knn16 a b c -- python3 $GRAFT_REPO_ROOT/tools/prof_ops.py knn16 6
   pmc pointconv a b c -- python3 $GRAFT_REPO_ROOT/tools/prof_ops.py pointconv 6
   pmc corr a b c d e -- python3 $GRAFT_REPO_ROOT/tools/prof_corr.py 0 6
+  pmc pw a b c -- python3 $GRAFT_REPO_ROOT/tools/prof_ops.py pw_l1 8
   $S knn_mfma_kernel $OUT/knn16_pmc.json "k_nearest_neighbor 3-D k=16, B=8, 8192 -> 4096: the sweep kernel (tools/prof_ops.py knn16 6)" /tmp/pmc_knn16_a /tmp/pmc_knn16_b /tmp/pmc_knn16_c
   $S knn_tie_replay_kernel $OUT/knn16_replay_pmc.json "the same search: its tied rows' second launch (tools/prof_ops.py knn16 6)" /tmp/pmc_knn16_a /tmp/pmc_knn16_b /tmp/pmc_knn16_c
   $S pointconv_fused_kernel $OUT/pointconv_pmc.json "PointConvNoSampling 195->128, B=4, N=4096 (tools/prof_ops.py pointconv 6)" /tmp/pmc_pointconv_a /tmp/pmc_pointconv_b /tmp/pmc_pointconv_c
+  $S pointwise_conv_kernel $OUT/pw_l1_pmc.json "1x1 convolution 96 -> 510 over 4 x 144 x 240, the level-1 cross block's project_in (tools/prof_ops.py pw_l1 8)" /tmp/pmc_pw_a /tmp/pmc_pw_b /tmp/pmc_pw_c
+  python3 tools/experiments/write_bw.py > $OUT/pw_l1_memory_floors.txt 2>/dev/null
   $S corr_mfma_dma_kernel $OUT/corr_microbench_pmc.json "correlation2d 1x256x544x960 md=4 fp32 (tools/prof_corr.py 0 6)" /tmp/pmc_corr_a /tmp/pmc_corr_b /tmp/pmc_corr_c /tmp/pmc_corr_d /tmp/pmc_corr_e
 fi
 if has fps; then
@@ -74,7 +77,9 @@ if has knn2d; then  # the nearest-point searches of the five levels: binned agai
 fi
 if has hotpath; then  # the hot-path sequence alone, eager, kernel stats; and which generic ATen kernels are left in it / in the forward
   (cd /tmp && rm -rf /tmp/p6 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p6 -- python3 $GRAFT_REPO_ROOT/bench.py --workload hotpath --eager --steps 10 --warmup 2 --no-cpu-baseline --no-corr-microbench --backend none > /tmp/p6.log 2>&1)
-  cp $(find /tmp/p6 -name "*kernel_stats.csv" | head -1) $OUT/hotpath_kernel_stats.csv
+  cp $(find /tmp/p6 -name "*kernel_stats.csv" | head -1) $OUT/hotpath_process_kernel_stats.csv   # (the whole process: model construction and warm-up included)
+  (cd /tmp && rm -rf /tmp/p7 && rocprofv3 --kernel-trace --output-format csv -d /tmp/p7 -- python3 $GRAFT_REPO_ROOT/tools/prof_forward.py 10 hotpath > /tmp/p7.log 2>&1)
+  TRACE_TOP=200 python3 tools/trace_window.py $(find /tmp/p7 -name "*kernel_trace.csv" | head -1) 10 > $OUT/hotpath_kernel_stats.txt   # per STEP: between two marker kernels
   python3 bench.py --workload hotpath --no-cpu-baseline --no-corr-microbench > $OUT/bench_hotpath.json 2> $OUT/bench_hotpath.err
   python3 tools/aten_gpu_census.py hotpath > $OUT/aten_census_hotpath.txt 2>/dev/null
   python3 tools/aten_gpu_census.py forward > $OUT/aten_census_forward.txt 2>/dev/null
@@ -82,7 +87,8 @@ fi
 if has rehearsal; then  # the 8-rank host side: host-only ranks; then with a real rank among them, and that rank alone
   timeout -k 5 300 python3 tools/host_rehearsal.py --ranks 8 --batches 384 2>/dev/null | grep "^{" > $OUT/host_rehearsal_default.json
   timeout -k 5 600 python3 tools/host_rehearsal.py --ranks 1 --batches 256 --real-rank 0 2>/dev/null | grep "^{" > $OUT/host_rehearsal_real_alone.json
-  timeout -k 5 600 python3 tools/host_rehearsal.py --ranks 8 --batches 256 --real-rank 0 2>/dev/null | grep "^{" > $OUT/host_rehearsal_real_rank0.json
+  timeout -k 5 600 python3 tools/host_rehearsal.py --ranks 8 --batches 256 --real-rank 0 2>/dev/null | grep "^{" > $OUT/host_rehearsal_real_rank0_unpaced.json
+  timeout -k 5 600 python3 tools/host_rehearsal.py --ranks 8 --batches 256 --real-rank 0 --pace 66 2>/dev/null | grep "^{" > $OUT/host_rehearsal_real_rank0.json
 fi
 if has corrclock; then  # engine clock over the very launches of the correlation microbench, per operand kind
   python3 tools/corr_clock.py --out $OUT/corr_clock.json > $OUT/corr_clock.log 2>&1
