@@ -183,7 +183,7 @@ int rpe_im2col(const float *x, int B, int C, int H, int W, int kh, int kw, int s
  * w_j = 1/max(||in_xyz[:,knn_j] - q_xyz||_2, 1e-8), normalised over the k neighbours;
  * out[b][c][q] = sum_j (scale*F[b][c][knn_j]) * w_j.  scale = -1 gives backwarp_3d's
  * "-flow12" features (utils.py:166-167) without a negation pass.
- * F: channels [0, C) from `feat`, [C, C + C_b) from `feat_b` (NULL with C_b = 0) -- the decoder interpolates the coarser
+ * F: channels [0, C) from `feat`, [C, C + C_b) from `feat_b` (either may be NULL with a count of 0) -- the decoder interpolates the coarser
  * level's [flow | flow features] (RPEFlow_core.py:352), two tensors that are never concatenated here.
  * `residual` [B, C + C_b, Q] through strides, or NULL: out = fl(residual + sum) (backwarp_3d's "xyz2 + flow21", utils.py:169).
  * Point/feature tensors channel-first through strides (sb, channel stride, point stride);

@@ -677,7 +677,7 @@ RPE_API int rpe_knn_interpolate(const float *in_xyz, int64_t x_sb, int64_t x_sd,
                                 const float *q_xyz, int64_t q_sb, int64_t q_sd, int64_t q_sn, const int64_t *knn, int64_t knn_row_stride,
                                 int B, int M, int Q, int k, float scale, const float *residual, int64_t r_sb, int64_t r_sc, int64_t r_sn,
                                 float *out, rpe_stream_t stream) {
-    if (!in_xyz || !feat || !q_xyz || !knn || !out || B < 0 || M <= 0 || Q < 0 || C < 0 || C_b < 0 || k < 1 || (C_b > 0 && !feat_b)) return RPE_EINVAL;
+    if (!in_xyz || !q_xyz || !knn || !out || B < 0 || M <= 0 || Q < 0 || C < 0 || C_b < 0 || k < 1 || (C > 0 && !feat) || (C_b > 0 && !feat_b)) return RPE_EINVAL;
     if (k > 8) return RPE_EUNSUPPORTED;
     const int CT = C + C_b;
     if (B == 0 || Q == 0 || CT == 0) return 0;

@@ -253,8 +253,8 @@ class HotPathWorkload(torch.nn.Module):
 
             if shares:
                 with t.span("grid_sample"):  # corr fuser 3D (:376; RPEFlow_core.py:103-111 in one launch)
-                    inv = (1.0 / self.scale_xy[level][0], 1.0 / self.scale_xy[level][1])
-                    sampled = grid_sample_sources([(corr_2d, None, None), (self.flow_2d[level], inv, last_flow_3d[:, :2]), (ef_2d, None, None)], xy1)
+                    to_sensor = ((sw - 1) / (w - 1), (sh - 1) / (h - 1))  # the 2-D flow in sensor units (:103-104)
+                    sampled = grid_sample_sources([(corr_2d, None, None), (self.flow_2d[level], to_sensor, last_flow_3d[:, :2]), (ef_2d, None, None)], xy1)
                 with t.span("project_feat"):  # corr fuser 2D (:371-373, :82-83)
                     project_feat_with_nn_corr(xy1, corr_2d, corr_3d, nn_proj1[..., 0], sampled_2d=sampled[:, :corr_2d.shape[1]],
                                               feat_3d_tail=last_flow_3d[:, :2], tail_scale=self.scale_xy[level])

@@ -13,7 +13,7 @@ from .pointconv import PointConvDownSampling, PointConvNoSampling
 from .utils import MLP1d, MLP2d, batch_indexing_channel_first
 
 
-_LEVEL0_INDEX = {}
+_LEVEL0_INDEX = {}  # constants of the pyramid by (batch, points, device): the level-0 index; the zero point of the level-0 feature
 
 
 def build_pc_pyramid(pc1, pc2, n_samples_list, sample_index_both=None, return_both=False):
@@ -80,7 +80,12 @@ class FeaturePyramid3D(nn.Module):
         # level 0: the MLP of an all-zero input (pwc3d_core.py:51-52), i.e. ONE vector for every point (eval-mode BatchNorm
         # is per point): computed on a single point and broadcast -- a stride-0 view the next layer's kernel reads as it is
         if xyzs[0].is_cuda and not self.training and not torch.is_grad_enabled():
-            feats = [self.level0_mlp(xyzs[0].new_zeros((1, 3, 1))).expand(xyzs[0].shape[0], -1, xyzs[0].shape[2])]
+            zero = _LEVEL0_INDEX.get(("zero point", xyzs[0].device))
+            if zero is None:  # (a constant, like the level-0 index: kept unless made inside a stream capture)
+                zero = xyzs[0].new_zeros((1, 3, 1))
+                if not torch.cuda.is_current_stream_capturing():
+                    _LEVEL0_INDEX[("zero point", xyzs[0].device)] = zero
+            feats = [self.level0_mlp(zero).expand(xyzs[0].shape[0], -1, xyzs[0].shape[2])]
         else:
             feats = [self.level0_mlp(torch.zeros_like(xyzs[0]))]
         for i in range(len(xyzs) - 1):

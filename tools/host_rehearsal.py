@@ -47,13 +47,16 @@ def child(args):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.set_num_threads(max(1, runtime.usable_cores() // world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cuda", 0) if args.device == "cuda" else torch.device("cpu")
+    real = args.real_rank is not None and rank == args.real_rank
+    # host-only neighbours of a real rank may stay off the GPU altogether (--neighbours cpu): eight processes on ONE device share
+    # its hardware queues, which a node with a GPU per rank does not
+    on_gpu = args.device == "cuda" and (real or args.real_rank is None or args.neighbours == "cuda")
+    dev = torch.device("cuda", 0) if on_gpu else torch.device("cpu")
     if dev.type == "cuda":
         torch.cuda.set_device(dev)
-    real = args.real_rank is not None and rank == args.real_rank
     if args.real_rank is not None:
         # the real rank's own world-size-1 nccl group (new_group is collective over the default group: every rank calls it)
-        solo = dist.new_group(ranks=[args.real_rank], backend="nccl") if dev.type == "cuda" else None
+        solo = dist.new_group(ranks=[args.real_rank], backend="nccl") if args.device == "cuda" else None
     if real:
         return real_child(args, rank, world, dev, solo, dist)
     n = world * args.batches * args.batch
@@ -117,7 +120,7 @@ def real_child(args, rank, world, dev, solo, dist):
     dist.barrier()  # everyone's set is generated, this rank's graph is captured: the host-only ranks warm their pipelines up now
     dist.barrier()  # the start line
     forward.host_times = []
-    stats = {}
+    stats = {"timeline": True}  # device time per batch: forward, metric sums, and the gap before the next batch's first launch
     t0, c0 = time.perf_counter(), time.process_time()
     metrics, _ = E.evaluate(model, data, args.batch, dev, 0, 1, group=solo, forward=forward, workers=workers, stats=stats)
     torch.cuda.synchronize()
@@ -127,6 +130,7 @@ def real_child(args, rank, world, dev, solo, dist):
     out = {"rank": rank, "real": True, "batches_per_s": round(args.batches / dt, 2), "ms_per_batch": round(dt / args.batches * 1e3, 3),
            "cpu_s_per_batch": round(cpu / args.batches, 5), "cores_in_use": round(cpu / dt, 2), "loader_threads": stats.get("workers", workers),
            "h2d_MB_per_batch": round(stats["bytes"] / max(1, stats["batches"]) / 1e6, 1), "hipGraphLaunch_host_ms": {"p50": pct(0.5), "p99": pct(0.99), "max": pct(1.0)},
+           "device_ms_per_batch": {k: stats.get("timeline_ms", {}).get(k) for k in ("forward", "accumulate", "gap", "host_loop")},
            "collective": "world-size-1 nccl group" if solo is not None else "none", "epe2d": metrics["EPE2D"], "generator_s_untimed": round(t_gen, 2)}
     gathered = [None] * world
     dist.all_gather_object(gathered, out)
@@ -144,7 +148,7 @@ def report(args, world, gathered, runtime):
         "ranks": world, "usable_cores": runtime.usable_cores(), "batch": args.batch, "frame": [args.height, args.width],
         "batches_per_rank": args.batches, "staging": "none (samples pinned)" if args.pinned else "pinned ring of host batches",
         "copy_fraction_host_only_ranks": float(os.environ.get("RPE_PIPE_COPY_FRACTION", "1")), "replay_stand_in_ms": args.host_ms,
-        "host_only_ranks_paced_at_batches_per_s": args.pace or None,
+        "host_only_ranks_paced_at_batches_per_s": args.pace or None, "host_only_ranks_on": args.neighbours if args.real_rank is not None else "cuda",
         "real_rank": real[0] if real else None,
         "batches_per_s_per_rank": rates, "min_batches_per_s": min(rates), "needed_batches_per_s": args.need,
         "feeds_the_gpus": bool(min(r for g, r in zip(gathered, rates) if not g.get("real")) >= args.need) if len(real) < world else None,
@@ -167,6 +171,8 @@ def main():
     p.add_argument("--device", choices=["cuda", "cpu"], default="cuda")
     p.add_argument("--pace", type=float, default=0.0, help="host-only ranks take at most this many batches per second, as ranks paced by a GPU do "
                                                             "(0: as fast as the host side goes -- the capacity measurement)")
+    p.add_argument("--neighbours", choices=["cuda", "cpu"], default="cuda", help="with --real-rank: the host-only ranks keep their device ring and copy "
+                                                                                 "stream on the (shared) GPU, or stay on the host: stage 1 only")
     p.add_argument("--real-rank", type=int, default=None, help="this rank runs the true evaluate() on the GPU; the others stay host-only")
     p.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     args = p.parse_args()
