@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(PwArgs a) {
         for (int t = 0; t < 4; ++t) acc[o][t] = pw_f32x4{0.f, 0.f, 0.f, 0.f};
     const bool p_in = p0 < P;
     // four channel groups per round: all their loads are issued before the first matrix instruction waits for one
-    constexpr int U = 4;
+    constexpr int U = 4;  // (rounds of 2 / 8 / 12 groups measure the same: 174 / 161 / 177 against 165 us on the level-1 project_in)
     for (int kt0 = 0; kt0 < a.ktiles; kt0 += U) {
         float xv[U][4], av[U][OT];
 #pragma unroll
