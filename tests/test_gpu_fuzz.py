@@ -46,10 +46,13 @@ def cloud(r, B, N, D):
     return (centres[:, r.integers(0, 8, N)] + r.normal(0, 0.05, (B, N, D))).astype(np.float32)
 
 
+BASES = {"knn": 910000, "fps": 920000, "corr": 930000, "sample": 940000, "interp": 950000, "project": 960000}  # first seed per operator
+
+
 def run(case, name):
     """Calls case(rng, seed) with fresh seeds until the budget is used; returns the number of cases."""
     t0, n = time.perf_counter(), 0
-    base = {"knn": 910000, "fps": 920000, "corr": 930000, "sample": 940000, "interp": 950000, "project": 960000}[name]
+    base = BASES[name]
     while n < 2 or time.perf_counter() - t0 < BUDGET:
         seed = base + n
         try:
@@ -158,3 +161,68 @@ def test_fuzz_project_feat_with_nn_corr():
         ref = O.project_feat_with_nn_corr(xy, f2, f3)
         assert got.shape == ref.shape and np.abs(got - ref).max() <= 5e-6 * max(1.0, float(np.abs(ref).max())), (B, C2, C3, H, W_, N)
     assert run(case, "project") >= 2
+
+
+def _close_sum(got, ref, what):
+    """fp32 sums of thousands of terms: 2e-6 of the largest output + 1e-4 relative (the module tests' rule)."""
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=2e-6 * float(np.abs(ref).max()) + 1e-6, err_msg=str(what))
+
+
+@torch.no_grad()
+def test_fuzz_pointconv_modules():
+    from rpeflow_amd import pointconv as PC
+    from tests.test_oracle_golden import _shapes_pointconv
+
+    def case(r, seed):
+        C, Cout = int(r.integers(1, 200)), int(r.choice([8, 16, 32, 64, 96, 128, 192]))
+        B, M = int(r.integers(1, 4)), int(r.integers(16, 600))
+        down = r.random() < 0.5
+        Q = int(r.integers(1, M + 1)) if down else M
+        norm = "batch_norm" if (down and r.random() < 0.5) else None
+        xyz = np.ascontiguousarray(I.ids_cloud(r, B, M).transpose(0, 2, 1))
+        feat = r.standard_normal((B, C, M), dtype=np.float32)
+        cls = PC.PointConvDownSampling if down else PC.PointConvNoSampling
+        params = I.fill_params(_shapes_pointconv(C, Cout, norm), seed)
+        m = cls(C, Cout, norm=norm)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        m = m.to(DEV).eval()
+        sampled = np.ascontiguousarray(xyz[:, :, :Q])
+        out = m(dev(xyz), dev(feat), dev(sampled)) if down else m(dev(xyz), dev(feat))
+        ref = O.pointconv(params, xyz, feat, sampled_xyz=sampled if down else None, k=16, norm=norm)
+        _close_sum(out.cpu().numpy(), ref, (B, C, Cout, M, Q, down, norm))
+    BASES["pointconv"] = 970000
+    assert run(case, "pointconv") >= 2
+
+
+@torch.no_grad()
+def test_fuzz_correlation3d_module():
+    from rpeflow_amd import pwc3d_core as P3
+    from tests.test_oracle_golden import _shapes_corr3d
+
+    def case(r, seed):
+        C = int(r.choice([16, 32, 48, 64, 96, 128, 192]))
+        B, N = int(r.integers(1, 4)), int(r.integers(16, 400))
+        xyz1 = np.ascontiguousarray(I.ids_cloud(r, B, N).transpose(0, 2, 1))
+        xyz2 = (xyz1 + r.standard_normal(xyz1.shape, dtype=np.float32) * np.float32(r.choice([0.02, 0.2, 2.0]))).astype(np.float32)
+        feat1, feat2 = r.standard_normal((B, C, N), dtype=np.float32), r.standard_normal((B, C, N), dtype=np.float32)
+        params = I.fill_params(_shapes_corr3d(C), seed)
+        m = P3.Correlation3D(C, C, k=16)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+        m = m.to(DEV).eval()
+        out = m(dev(xyz1), dev(feat1), dev(xyz2), dev(feat2))
+        _close_sum(out.cpu().numpy(), O.correlation3d(params, xyz1, feat1, xyz2, feat2, k=16), (B, C, N))
+    BASES["corr3d"] = 980000
+    assert run(case, "corr3d") >= 2
+
+
+def test_fuzz_gathers():
+    def case(r, seed):
+        B, C, N = int(r.integers(1, 5)), int(r.integers(1, 70)), int(r.integers(1, 3000))
+        shape = tuple(int(v) for v in r.integers(1, 40, int(r.integers(1, 3))))
+        data = r.standard_normal((B, C, N), dtype=np.float32)
+        idx = r.integers(0, N, (B,) + shape).astype(np.int64)
+        assert np.array_equal(U.batch_indexing_channel_first(dev(data), dev(idx)).cpu().numpy(), O.batch_indexing_channel_first(data, idx))
+        last = np.ascontiguousarray(data.transpose(0, 2, 1))
+        assert np.array_equal(U.batch_indexing_channel_last(dev(last), dev(idx)).cpu().numpy(), O.batch_indexing_channel_last(last, idx))
+    BASES["gather"] = 990000
+    assert run(case, "gather") >= 2
