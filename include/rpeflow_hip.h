@@ -451,14 +451,17 @@ int rpe_eval_accumulate(const float *flow2d, const float *target2d, int target2d
                         double *workspace, double *acc, rpe_stream_t stream);
 
 /* ---- diagnostics -------------------------------------------------------------
- * When the stream reaches this point one wave stores slot2[0] = the shader-engine cycle counter (s_memtime) and slot2[1] =
- * the constant-rate counter (s_memrealtime, wall_clock64).  A one-thread kernel, usable inside a captured HIP graph:
- *   - timelines of multi-stream replays that rocprofv3 serialises read slot2[1] (rpeflow_amd.model.StampTrace,
+ * When the stream reaches this point, one wave PER XCD stores slot16[2 x] = that XCD's engine cycle counter (s_memtime) and
+ * slot16[2 x + 1] = the constant-rate counter (s_memrealtime, wall_clock64), x = the XCD it runs on (0..7; sixteen one-wave
+ * workgroups, dealt round robin over the XCDs; an entry no workgroup reached keeps its old value: zero the slots first).
+ * Usable inside a captured HIP graph:
+ *   - timelines of multi-stream replays that rocprofv3 serialises read the constant-rate entries (rpeflow_amd.model.StampTrace,
  *     tools/stamp_timeline.py);
- *   - two stamps bracket a stretch of a stream: d[0] / d[1] x the constant rate = the clock the engines actually ran at
- *     (rpeflow_amd.runtime.ShaderClock; bench.py's roofline objects carry it).
+ *   - two stamps bracket a stretch of a stream: per XCD, d(cycle counter) / d(constant-rate counter) x the constant rate = the
+ *     clock that XCD ran at (rpeflow_amd.runtime.ShaderClock; bench.py's roofline_corr carries it).  The cycle counters of
+ *     different XCDs must not be mixed: an XCD that idles stops counting.
  * wall_khz (host pointer, may be NULL): receives the constant rate of the current device (hipDeviceAttributeWallClockRate). */
-int rpe_clock_stamp(unsigned long long *slot2, int *wall_khz, rpe_stream_t stream);
+int rpe_clock_stamp(unsigned long long *slot16, int *wall_khz, rpe_stream_t stream);
 
 #ifdef RPE_EXPERIMENTAL /* only in a library built with -DRPE_EXPERIMENTAL (python -m rpeflow_amd.build --experimental) */
 /* Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation

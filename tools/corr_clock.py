@@ -4,7 +4,7 @@ its cycle count constant?
 
 Three instruments gave three answers in round 4 (hwmon 157 / 2350 MHz, the round-3 power trace 1964 MHz, GRBM_GUI_ACTIVE
 1.5-2.0 GHz).  This tool uses the one that is measured on the device the kernel runs on, in the stream it runs in:
-rpe_clock_stamp (s_memtime + s_memrealtime read by one wave) in front of and behind the launches
+rpe_clock_stamp (s_memtime + s_memrealtime read by one wave on every XCD) in front of and behind the launches
 (rpeflow_amd.runtime.ShaderClock).
 
 1. Does s_memtime follow the engine clock on gfx950?  An idle stretch (two stamps with a host sleep between them) against a
@@ -102,6 +102,7 @@ def main():
         time.sleep(0.5)
     torch.cuda.synchronize()
     cycles, ticks, khz = idle.raw()
+    report["idle_MHz_per_xcd"] = idle.mhz_per_xcd()
     report["idle"] = {"shader_cycles": cycles, "wall_ticks": ticks, "wall_kHz": khz, "MHz": round(cycles / max(1, ticks) * khz / 1e3, 2),
                       "seconds_by_wall_counter": round(ticks / khz / 1e3, 4)}
 
@@ -124,9 +125,10 @@ def main():
         mon.stop_flag.set()
         mon.join()
         us = s.elapsed_time(e) / args.launches * 1e3
-        cycles, ticks, khz = clock.raw()
+        cycles, ticks, khz = clock.raw()  # (the median XCD's pair)
         mhz = cycles / max(1, ticks) * khz / 1e3
-        report["kinds"][name] = {"us_per_launch": round(us, 2), "stamp_MHz": round(mhz, 1), "shader_cycles_per_launch": round(cycles / args.launches),
+        report["kinds"][name] = {"us_per_launch": round(us, 2), "stamp_MHz": round(mhz, 1), "stamp_MHz_per_xcd": clock.mhz_per_xcd(),
+                                 "shader_cycles_per_launch": round(cycles / args.launches),
                                  "us_by_wall_counter": round(ticks / khz * 1e3 / args.launches, 2), **mon.summary()}
         print(name, report["kinds"][name], flush=True)
     k = report["kinds"]
