@@ -106,17 +106,17 @@ def pmc_traffic(suffix):
 
 def clocked(frac, clock, dev, launches=0):
     """Extra fields of a roofline object: the clock the shader engines ran at DURING the timed launches -- two clock stamps on the
-    stream around them, each one (s_memtime, s_memrealtime) pair per XCD (rpeflow_amd.runtime.ShaderClock: an XCD's cycle counter
-    only against itself; null if the XCDs disagree by more than 10 %), else the hwmon reading of this very device, else null --
-    and the fraction scaled to the nominal clock, null unless the clock is plausible and the result <= 1."""
-    sclk, source = clock.mhz(), "clock stamps around the timed launches, one pair per XCD (median of d s_memtime / d s_memrealtime x the constant rate)"
+    stream around them, every compute unit's cycle counter compared with itself only (rpeflow_amd.runtime.ShaderClock), else the
+    hwmon reading of this very device, else null -- and the fraction scaled to the nominal clock, null unless the clock is
+    plausible and the result <= 1."""
+    sclk, source = clock.mhz(), "two per-compute-unit clock stamps around the timed launches (median over the units of d s_memtime / d s_memrealtime x the constant rate)"
     if sclk is None:
         sclk, source = runtime.hwmon_sclk_mhz(dev), "hwmon sclk of this device, one reading after the loop"
     at_nominal = round(frac * NOMINAL_SCLK_MHZ / sclk, 4) if sclk else None
     cycles, ticks, khz = clock.raw()
-    return {"sclk_MHz": sclk, "sclk_source": source if sclk else None, "sclk_MHz_per_xcd": clock.mhz_per_xcd(),
+    return {"sclk_MHz": sclk, "sclk_source": source if sclk else None, "sclk_MHz_per_xcd": clock.mhz_per_xcd(), "sclk_units_read": clock.units(),
             "sclk_stamp_raw": {"shader_cycles": cycles, "wall_ticks": ticks, "wall_kHz": khz},
-            "shader_cycles_per_launch": round(cycles / launches) if (sclk and launches) else None,  # (compare: GRBM_GUI_ACTIVE / 8 of the PMC pass)
+            "shader_cycles_per_launch": round(cycles / launches) if (sclk and launches) else None,  # (the median unit; compare: GRBM_GUI_ACTIVE / 8 of the PMC pass)
             "frac_at_nominal_clock": at_nominal if (at_nominal is not None and at_nominal <= 1.0) else None}
 
 

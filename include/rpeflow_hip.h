@@ -451,17 +451,19 @@ int rpe_eval_accumulate(const float *flow2d, const float *target2d, int target2d
                         double *workspace, double *acc, rpe_stream_t stream);
 
 /* ---- diagnostics -------------------------------------------------------------
- * When the stream reaches this point, one wave PER XCD stores slot16[2 x] = that XCD's engine cycle counter (s_memtime) and
- * slot16[2 x + 1] = the constant-rate counter (s_memrealtime, wall_clock64), x = the XCD it runs on (0..7; sixteen one-wave
- * workgroups, dealt round robin over the XCDs; an entry no workgroup reached keeps its old value: zero the slots first).
- * Usable inside a captured HIP graph:
- *   - timelines of multi-stream replays that rocprofv3 serialises read the constant-rate entries (rpeflow_amd.model.StampTrace,
- *     tools/stamp_timeline.py);
- *   - two stamps bracket a stretch of a stream: per XCD, d(cycle counter) / d(constant-rate counter) x the constant rate = the
- *     clock that XCD ran at (rpeflow_amd.runtime.ShaderClock; bench.py's roofline_corr carries it).  The cycle counters of
- *     different XCDs must not be mixed: an XCD that idles stops counting.
- * wall_khz (host pointer, may be NULL): receives the constant rate of the current device (hipDeviceAttributeWallClockRate). */
-int rpe_clock_stamp(unsigned long long *slot16, int *wall_khz, rpe_stream_t stream);
+ * rpe_clock_stamp: when the stream reaches this point one thread stores slot2[0] = the engine cycle counter (s_memtime) and
+ *   slot2[1] = the constant-rate counter (s_memrealtime, wall_clock64: 100 MHz).  Usable inside a captured HIP graph: the
+ *   constant-rate entries are the timelines of multi-stream replays that rocprofv3 serialises (rpeflow_amd.model.StampTrace,
+ *   tools/stamp_timeline.py), the kernel is the marker tools/trace_window.py looks for.  The cycle counters of two stamps must
+ *   NOT be subtracted: they may come from different XCDs / shader engines, whose counters are not one clock.
+ * rpe_clock_stamp_all: the same pair of counters stored per COMPUTE UNIT -- slots[2 key], slots[2 key + 1], key = XCC_ID << 8 |
+ *   HW_ID[15:8] (shader engine, array, CU), 2048 keys: `slots` is 4096 values, zeroed by the caller; 8192 one-wave workgroups
+ *   cover the chip.  Two of these bracket a stretch of the stream; for every key both reached, d(cycles) / d(ticks) x the
+ *   constant rate = the clock that compute unit ran at (rpeflow_amd.runtime.ShaderClock takes the median; bench.py's
+ *   roofline_corr carries it).  wall_khz (host pointer, may be NULL): that rate on the current device
+ *   (hipDeviceAttributeWallClockRate).                                                                              */
+int rpe_clock_stamp(unsigned long long *slot2, rpe_stream_t stream);
+int rpe_clock_stamp_all(unsigned long long *slots, int *wall_khz, rpe_stream_t stream);
 
 #ifdef RPE_EXPERIMENTAL /* only in a library built with -DRPE_EXPERIMENTAL (python -m rpeflow_amd.build --experimental) */
 /* Writes the lane/register map of v_mfma_f32_4x4x1_16b_f32 the correlation

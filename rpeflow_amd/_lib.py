@@ -48,7 +48,8 @@ _PROTOTYPES = {
     "rpe_corr3d_n2n": [_c_ptr] * 7 + [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_correlation2d_backward": [_c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_knn_multi": [_c_ptr, _c_int, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr],
-    "rpe_clock_stamp": [_c_ptr, _c_ptr, _c_ptr],
+    "rpe_clock_stamp": [_c_ptr, _c_ptr],
+    "rpe_clock_stamp_all": [_c_ptr, _c_ptr, _c_ptr],
     "rpe_gather_channel_first": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_gather_channel_last": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_pointwise_conv": [_c_ptr, _c_i64, _c_int, _c_int, _c_i64, _c_ptr, _c_i64, _c_int, _c_ptr, _c_ptr, _c_int, _c_float,

@@ -12,30 +12,44 @@ RPE_API const char *rpe_error_string(int code) {
 }
 
 namespace {
-// s_memtime (the free-running counter of an XCD's engine clock) and s_memrealtime (the constant-rate reference clock) read back to
-// back, ONCE PER XCD: sixteen one-wave workgroups are dealt round robin over the eight XCDs, each stores its pair in the slot of
-// the XCD it runs on (HW_REG_XCC_ID).  The cycle counters of different XCDs are not one clock -- an XCD that idles while the
-// others work (an 8-workgroup launch, a thin tail) stops counting -- so a stretch is measured per XCD, from that XCD's own two
-// stamps: d(shader) / d(wall) x the wall rate = the clock that XCD ran at.
+// one thread stores the engine cycle counter and the constant-rate counter: a marker for timelines (the constant-rate entry)
 __global__ void clock_stamp_kernel(unsigned long long *slot) {
-    unsigned xcc;
+    slot[0] = clock64();
+    slot[1] = wall_clock64();
+}
+
+// The engine clock over a stretch of a stream, from two of these stamps: a few thousand one-wave workgroups cover the chip,
+// each stores s_memtime (engine cycles) and s_memrealtime (constant rate) in the slot of the compute unit it runs on
+// (HW_REG_XCC_ID, and the shader-engine / array / CU fields of HW_REG_HW_ID: 8 x 256 slots).  A slot is only ever compared
+// with itself: the cycle counters of different parts of the chip are not one clock -- two stamps taken wherever a one-workgroup
+// kernel landed read 1455 "MHz" after 8-workgroup launches had let counters drift apart, one slot per XCD gave negative
+// differences -- and under the package power limit the XCDs do not run at one clock either.  (Probes that run BESIDE the
+// measured launches were tried: they take compute units and a hardware queue from them.)
+__global__ __launch_bounds__(64) void clock_stamp_all_kernel(unsigned long long *slots) {
+    if (threadIdx.x != 0) return;
+    unsigned xcc, hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 7u;
-    if (threadIdx.x == 0) {
-        slot[2 * xcc] = clock64();
-        slot[2 * xcc + 1] = wall_clock64();
-    }
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned key = ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);  // HW_ID[15:8]: CU_ID, SH_ID, SE_ID
+    slots[2 * key] = clock64();
+    slots[2 * key + 1] = wall_clock64();
 }
 }  // namespace
 
-RPE_API int rpe_clock_stamp(unsigned long long *slot16, int *wall_khz, rpe_stream_t stream) {
-    if (!slot16) return RPE_EINVAL;
+RPE_API int rpe_clock_stamp(unsigned long long *slot2, rpe_stream_t stream) {
+    if (!slot2) return RPE_EINVAL;
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot2);
+    return rpe_launch_status();
+}
+
+RPE_API int rpe_clock_stamp_all(unsigned long long *slots, int *wall_khz, rpe_stream_t stream) {
+    if (!slots) return RPE_EINVAL;
     if (wall_khz) {
         int device = 0;
         hipError_t e = hipGetDevice(&device);
         if (e == hipSuccess) e = hipDeviceGetAttribute(wall_khz, hipDeviceAttributeWallClockRate, device);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(clock_stamp_kernel, dim3(16), dim3(64), 0, (hipStream_t)stream, slot16);
+    hipLaunchKernelGGL(clock_stamp_all_kernel, dim3(8192), dim3(64), 0, (hipStream_t)stream, slots);
     return rpe_launch_status();
 }

@@ -484,18 +484,18 @@ class StampTrace:
     rpeflow_amd.model.TRACE = StampTrace(device) before the (captured) forward, read() after a replay."""
 
     def __init__(self, device, slots=1024):
-        self.buf = torch.zeros((slots, 8, 2), dtype=torch.int64, device=device)  # per stamp and XCD: (engine cycles, constant-rate ticks)
+        self.buf = torch.zeros((slots, 2), dtype=torch.int64, device=device)  # per stamp: (engine cycles, constant-rate ticks)
         self.names = []
 
     def __call__(self, name):
         from . import _lib
         i = len(self.names)
         self.names.append(name)
-        _lib.check(_lib.lib().rpe_clock_stamp(self.buf.data_ptr() + 128 * i, None, _lib.stream_of(self.buf)), "stamp")
+        _lib.check(_lib.lib().rpe_clock_stamp(self.buf.data_ptr() + 16 * i, _lib.stream_of(self.buf)), "stamp")
 
     def read(self):
         """[(name, microseconds since the first stamp)] in issue order."""
-        v = self.buf[:len(self.names), :, 1].max(dim=1).values.cpu().tolist()  # the constant-rate clock is one clock: any XCD's reading
+        v = self.buf[:len(self.names), 1].cpu().tolist()  # (the constant-rate entries: ONE clock, unlike the cycle counters)
         return [(n, (t - v[0]) / 100.0) for n, t in zip(self.names, v)]
 
 

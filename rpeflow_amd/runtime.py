@@ -58,26 +58,27 @@ SCLK_PLAUSIBLE_MHZ = (500.0, 2500.0)  # an engine clock outside this range on an
 
 
 class ShaderClock:
-    """The clock the shader engines ran at over a stretch of the CURRENT stream of ``device``, measured on the device the
-    work runs on and inside the stream it runs in: ``with ShaderClock(dev) as c: <launches>`` puts one clock stamp
-    (rpe_clock_stamp: per XCD, s_memtime and s_memrealtime read by one wave) in front of and one behind the launches;
-    ``c.mhz()`` (after the stream has been synchronised) = the median over the XCDs of d(cycle counter) / d(constant-rate ticks)
-    x the constant rate.  ``None`` -- never a number -- when the result is not a plausible engine clock, or when the XCDs
-    disagree by more than 25 %: the stretch did not keep the whole chip busy (an idle XCD's counter stands still), and
-    callers fall back to ``hwmon_sclk_mhz`` or print null.  (Under the package power limit the XCDs do NOT run at one clock:
-    1735 ... 2029 MHz were read over one loop of the correlation microbench, 1886 ... 2018 over another; with constant operands
-    2368 ... 2417.  ``mhz_per_xcd()`` gives them all.)
-    Measured on gfx950 (profiles/r05_corr_clock*.json): the counter follows the engine clock -- 1.6 MHz over an idle half
-    second, 2395 MHz under a compute loop with constant operands, 2023 MHz when the same loop hits the package power limit --
-    and the cycles per launch it gives equal GRBM_GUI_ACTIVE / 8 of a PMC pass (801 k).  The XCDs' counters are NOT one clock:
-    a first version that took both stamps wherever a single workgroup landed read 1455 "MHz" (and 1430 for a launch with a
-    thin tail) after a stretch of 8-workgroup launches had let the counters drift apart; hence one pair per XCD."""
+    """The clock the shader engines ran at over a stretch of the CURRENT stream of ``device``, measured on the device the work
+    runs on, in the stream it runs in: ``with ShaderClock(dev) as c: <launches>`` puts one rpe_clock_stamp_all in front of and
+    one behind the launches (every compute unit's engine cycle counter s_memtime and the constant-rate s_memrealtime, stored
+    per compute unit); ``c.mhz()`` (after the stream has been synchronised) = the median over the compute units of
+    d(cycles) / d(ticks) x the constant rate, ``c.mhz_per_xcd()`` the median of each XCD.  ``None`` -- never a number -- when
+    that is not a plausible engine clock: callers fall back to ``hwmon_sclk_mhz`` or print null.
+    A compute unit's counter is only ever compared with itself.  The cycle counters of different parts of the chip are not one
+    clock: two stamps taken wherever a one-workgroup kernel landed agreed with GRBM_GUI_ACTIVE / 8 in seven runs and read 1455
+    "MHz" in the eighth (after a stretch of 8-workgroup launches the counters had drifted apart), one slot per XCD gave negative
+    differences; and probes that run BESIDE the measured launches take compute units and a hardware queue from them (the
+    correlation loop slowed from 402 to 492 us, or stalled behind the probes' queue).  Under the package power limit the XCDs
+    do not run at one clock either.  An idle compute unit's counter stands still: the reading is the clock only for stretches that
+    keep the chip busy."""
+
+    KEYS = 2048
 
     def __init__(self, device):
         import ctypes
         import torch
         self.device = torch.device(device)
-        self.slots = torch.zeros((2, 8, 2), dtype=torch.int64, device=self.device)  # [stamp][XCD][(cycles, ticks)]
+        self.slots = torch.zeros((2, self.KEYS, 2), dtype=torch.int64, device=self.device)  # [stamp][compute unit][(cycles, ticks)]
         self.khz = ctypes.c_int(0)
 
     def _stamp(self, i):
@@ -85,7 +86,7 @@ class ShaderClock:
         import torch
         from . import _lib
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().rpe_clock_stamp(self.slots[i].data_ptr(), ctypes.byref(self.khz), _lib.stream_of(self.slots)), "clock_stamp")
+            _lib.check(_lib.lib().rpe_clock_stamp_all(self.slots[i].data_ptr(), ctypes.byref(self.khz), _lib.stream_of(self.slots)), "clock_stamp_all")
 
     def __enter__(self):
         self._stamp(0)
@@ -94,31 +95,36 @@ class ShaderClock:
     def __exit__(self, *exc):
         self._stamp(1)
 
-    def per_xcd(self):
-        """[(d cycles, d ticks)] for every XCD both stamps reached."""
+    def per_unit(self):
+        """{key: (d cycles, d ticks)} for every compute unit both stamps reached."""
         first, second = self.slots.tolist()
-        return [(b[0] - a[0], b[1] - a[1]) for a, b in zip(first, second) if a[1] > 0 and b[1] > a[1]]
+        return {k: (b[0] - a[0], b[1] - a[1]) for k, (a, b) in enumerate(zip(first, second)) if a[1] > 0 and b[1] > a[1] and b[0] > a[0]}
 
     def raw(self):
-        """(d shader cycles, d constant-rate ticks, constant rate in kHz) of the median XCD."""
-        pairs = sorted(self.per_xcd(), key=lambda p: p[0] / p[1])
+        """(d engine cycles, d constant-rate ticks, constant rate in kHz) of the median compute unit."""
+        pairs = sorted(self.per_unit().values(), key=lambda p: p[0] / p[1])
         if not pairs:
             return 0, 0, self.khz.value
         cycles, ticks = pairs[len(pairs) // 2]
         return cycles, ticks, self.khz.value
 
     def mhz_per_xcd(self):
+        """Median clock of the compute units of each XCD (XCDs no unit of which was reached by both stamps are left out)."""
         khz = self.khz.value
-        return [round(c / t * khz / 1e3, 1) for c, t in self.per_xcd()] if khz > 0 else []
+        by = {}
+        for k, (c, t) in self.per_unit().items():
+            by.setdefault(k >> 8, []).append(c / t * khz / 1e3)
+        return [round(sorted(v)[len(v) // 2], 1) for _, v in sorted(by.items())] if khz > 0 else []
+
+    def units(self):
+        return len(self.per_unit())
 
     def mhz(self):
-        per = sorted(self.mhz_per_xcd())
-        if not per:
+        cycles, ticks, khz = self.raw()
+        if ticks <= 0 or khz <= 0:
             return None
-        mhz = per[len(per) // 2]
-        if not (SCLK_PLAUSIBLE_MHZ[0] <= mhz <= SCLK_PLAUSIBLE_MHZ[1]) or per[-1] - per[0] > 0.25 * mhz:
-            return None
-        return mhz
+        mhz = round(cycles / ticks * khz / 1e3, 1)
+        return mhz if SCLK_PLAUSIBLE_MHZ[0] <= mhz <= SCLK_PLAUSIBLE_MHZ[1] else None
 
 
 def hwmon_sclk_mhz(device):

@@ -4,8 +4,8 @@ its cycle count constant?
 
 Three instruments gave three answers in round 4 (hwmon 157 / 2350 MHz, the round-3 power trace 1964 MHz, GRBM_GUI_ACTIVE
 1.5-2.0 GHz).  This tool uses the one that is measured on the device the kernel runs on, in the stream it runs in:
-rpe_clock_stamp (s_memtime + s_memrealtime read by one wave on every XCD) in front of and behind the launches
-(rpeflow_amd.runtime.ShaderClock).
+rpe_clock_stamp_all (s_memtime + s_memrealtime of every compute unit, each compared with itself only) in front of and behind
+the launches (rpeflow_amd.runtime.ShaderClock).
 
 1. Does s_memtime follow the engine clock on gfx950?  An idle stretch (two stamps with a host sleep between them) against a
    busy one: a counter at a constant rate gives the same MHz for both, the engine clock does not.
@@ -127,7 +127,7 @@ def main():
         us = s.elapsed_time(e) / args.launches * 1e3
         cycles, ticks, khz = clock.raw()  # (the median XCD's pair)
         mhz = cycles / max(1, ticks) * khz / 1e3
-        report["kinds"][name] = {"us_per_launch": round(us, 2), "stamp_MHz": round(mhz, 1), "stamp_MHz_per_xcd": clock.mhz_per_xcd(),
+        report["kinds"][name] = {"us_per_launch": round(us, 2), "stamp_MHz": round(mhz, 1), "stamp_MHz_per_xcd": clock.mhz_per_xcd(), "units_read": clock.units(),
                                  "shader_cycles_per_launch": round(cycles / args.launches),
                                  "us_by_wall_counter": round(ticks / khz * 1e3 / args.launches, 2), **mon.summary()}
         print(name, report["kinds"][name], flush=True)

@@ -28,8 +28,8 @@ for _ in range(3):
     call()
 torch.cuda.synchronize()
 from rpeflow_amd import _lib
-probe = torch.zeros(16, dtype=torch.int64, device=dev)
-mark = lambda: _lib.lib().rpe_clock_stamp(probe.data_ptr(), None, torch.cuda.current_stream().cuda_stream)  # marker kernel
+probe = torch.zeros(2, dtype=torch.int64, device=dev)
+mark = lambda: _lib.lib().rpe_clock_stamp(probe.data_ptr(), torch.cuda.current_stream().cuda_stream)  # marker kernel
 step = call
 if "graph" in sys.argv:  # replay the forward as one HIP graph, as bench.py does
     graph = torch.cuda.CUDAGraph()
