@@ -465,3 +465,26 @@ def test_knn_equal_distances_follow_torch_topk(B, M, Q, D, k):
     low, dist = W.k_nearest_neighbor_with_distances(dev(inp), dev(qry), k, ties="index")
     oi, od = O.k_nearest_neighbor(inp, qry, k, return_dists=True, ties="index")
     assert np.array_equal(low.cpu().numpy(), oi)
+
+
+def test_shader_clock_reads_every_compute_unit():
+    """rpe_clock_stamp_all through rpeflow_amd.runtime.ShaderClock (bench.py's roofline_corr carries its reading): two stamps
+    around a stretch of full-chip work reach (nearly) every compute unit, each unit's cycle counter is compared with itself
+    only, and the median is a plausible engine clock -- or None, never an implausible number."""
+    from rpeflow_amd import runtime
+    a = torch.randn(1, 64, 144, 240, device="cuda:0")
+    b = torch.randn(1, 64, 144, 240, device="cuda:0")
+    for _ in range(20):
+        ops.correlation2d(a, b, 4)
+    clock = runtime.ShaderClock("cuda:0")
+    with clock:
+        for _ in range(200):
+            ops.correlation2d(a, b, 4)
+    torch.cuda.synchronize()
+    assert clock.units() >= 128
+    cycles, ticks, khz = clock.raw()
+    assert cycles > 0 and ticks > 0 and khz > 0
+    mhz = clock.mhz()
+    assert mhz is None or runtime.SCLK_PLAUSIBLE_MHZ[0] <= mhz <= runtime.SCLK_PLAUSIBLE_MHZ[1]
+    assert 1 <= len(clock.mhz_per_xcd()) <= 8
+    print("engine clock over the loop: %s MHz, per XCD %s, %d compute units read" % (mhz, clock.mhz_per_xcd(), clock.units()))
