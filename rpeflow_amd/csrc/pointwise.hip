@@ -231,7 +231,16 @@ RPE_API int rpe_pointwise_conv(const float *x, int64_t x_batch_stride, int B, in
         else hipLaunchKernelGGL((pointwise_conv_ksplit_kernel<false>), grid, dim3(256), 0, st, a);
         return rpe_launch_status();
     }
-    if (a.n_otiles >= 16 && wgs1 >= 4 * 1024) return launch_pw<4>(a, B, vec, st);
-    if (a.n_otiles >= 8 && wgs1 >= 2 * 1024) return launch_pw<2>(a, B, vec, st);
+#ifndef RPE_PW_OT4_MIN_TILES
+#define RPE_PW_OT4_MIN_TILES 16
+#endif
+#ifndef RPE_PW_OT2_MIN_TILES
+#define RPE_PW_OT2_MIN_TILES 8
+#endif
+#ifndef RPE_PW_OT2_MIN_WGS
+#define RPE_PW_OT2_MIN_WGS 2048
+#endif
+    if (a.n_otiles >= RPE_PW_OT4_MIN_TILES && wgs1 >= 4 * 1024) return launch_pw<4>(a, B, vec, st);
+    if (a.n_otiles >= RPE_PW_OT2_MIN_TILES && wgs1 >= RPE_PW_OT2_MIN_WGS) return launch_pw<2>(a, B, vec, st);
     return launch_pw<1>(a, B, vec, st);
 }

@@ -22,6 +22,7 @@ from rpeflow_amd.csrc import wrapper as W  # noqa: E402
 
 DEV = "cuda:0"
 BUDGET = float(os.environ.get("RPE_FUZZ_SECONDS", "4"))
+OFFSET = int(os.environ.get("RPE_FUZZ_SEED_OFFSET", "0"))  # a long run on fresh seeds: RPE_FUZZ_SECONDS=300 RPE_FUZZ_SEED_OFFSET=10000000
 
 
 def dev(a):
@@ -52,7 +53,7 @@ BASES = {"knn": 910000, "fps": 920000, "corr": 930000, "sample": 940000, "interp
 def run(case, name):
     """Calls case(rng, seed) with fresh seeds until the budget is used; returns the number of cases."""
     t0, n = time.perf_counter(), 0
-    base = BASES[name]
+    base = BASES[name] + OFFSET
     while n < 2 or time.perf_counter() - t0 < BUDGET:
         seed = base + n
         try:
