@@ -242,5 +242,9 @@ RPE_API int rpe_pointwise_conv(const float *x, int64_t x_batch_stride, int B, in
 #endif
     if (a.n_otiles >= RPE_PW_OT4_MIN_TILES && wgs1 >= 4 * 1024) return launch_pw<4>(a, B, vec, st);
     if (a.n_otiles >= RPE_PW_OT2_MIN_TILES && wgs1 >= RPE_PW_OT2_MIN_WGS) return launch_pw<2>(a, B, vec, st);
+    // 5 .. 7 output tiles from many input channels: three waves of two tiles read x once instead of twice (tools/pw_census.py,
+    // 144 x 240: 255 -> 96 108 -> 103 us, 215 -> 81 94 -> 86, 113 -> 81 53 -> 51; below ~100 input channels the same rule loses:
+    // 96 -> 96 46 -> 51, 67 -> 96 36 -> 39)
+    if (a.n_otiles >= 5 && a.ktiles >= 28 && wgs1 >= RPE_PW_OT2_MIN_WGS) return launch_pw<2>(a, B, vec, st);
     return launch_pw<1>(a, B, vec, st);
 }
