@@ -760,7 +760,7 @@ RPE_API int rpe_project_points(const float *xyz_a, int64_t a_sb, int64_t a_sd, i
                                float scale_y, float *out, rpe_stream_t stream) {
     if (!xyz_a || !out || B < 0 || N < 0) return RPE_EINVAL;
     if (B == 0 || N == 0) return 0;
-    if (2 * B > 65535) return RPE_EUNSUPPORTED;
+    if (B > 32767) return RPE_EUNSUPPORTED;  // (both frames ride in grid.y)
     hipLaunchKernelGGL(project_points_kernel, dim3((N + 255) / 256, xyz_b ? 2 * B : B), dim3(256), 0, (hipStream_t)stream, xyz_a, a_sb, a_sd, a_sn,
                        xyz_b, b_sb, b_sd, b_sn, B, N, intrinsics, intr_sb, cx, cy, scale_x, scale_y, out);
     return rpe_launch_status();
