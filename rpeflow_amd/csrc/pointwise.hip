@@ -33,6 +33,65 @@ struct PwArgs {
     int64_t res_bstride;  // floats between samples of res (Cout * P for a dense tensor; larger for a channel slice of a wider one)
 };
 
+// Epilogue of pointwise_conv_kernel.  D layout: lane (g = lane >> 4, j), register r: output 16 ot + 4 g + r, position p0 + t of
+// tile t.  v = act(scale * acc + shift) [+ residual].  The activation is ONE select per value whatever its kind -- identity,
+// relu and leaky_relu are "u > 0 ? u : alt" with alt = u * 1, +0, u * slope (bit for bit fmaxf(u, 0) and u >= 0 ? u : u * slope
+// for a slope >= 0, signed zeros and NaNs included) -- and the affine pairs are read a tile (four rows) at a time: with the
+// tests on act / scale / shift inside the loops the compiler emitted ~4 scalar branches per output VALUE (260 branches a wave,
+// a wait on every scale / shift pair).
+template <int OT, bool VEC>
+__device__ __forceinline__ void pw_finish(const PwArgs &a, const pw_f32x4 (&acc)[OT][4], int ot0, int g, int b, int64_t p0) {
+    const int64_t P = a.P;
+    const int oc0 = 16 * ot0 + 4 * g;
+    const float alt_scale = a.act == 1 ? 0.0f : (a.act == 2 ? a.slope : 1.0f);
+    const unsigned alt_keep = a.act == 1 ? 0u : ~0u;
+    float *yb = a.y + ((int64_t)b * a.Cout + oc0) * P + p0;
+    const float *rb = a.res ? a.res + (int64_t)b * a.res_bstride + (int64_t)oc0 * P + p0 : nullptr;
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+        // the tile's sums stay in the accumulation registers until its turn: the compiler would move all 16 OT vectors out
+        // behind the loop (148 registers, two waves a SIMD instead of three)
+        pw_f32x4 d[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            d[t] = acc[o][t];
+            asm volatile("" : "+a"(d[t]));
+        }
+        float sc[4] = {1.0f, 1.0f, 1.0f, 1.0f}, sh[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // (the tile's affine pairs: one wait per tile)
+        if (a.scale) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[r] = a.scale[min(oc0 + 16 * o + r, a.Cout - 1)];
+        }
+        if (a.shift) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh[r] = a.shift[min(oc0 + 16 * o + r, a.Cout - 1)];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (oc0 + 16 * o + r >= a.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float u = sc[r] * d[t][r] + sh[r];
+                const float alt = __uint_as_float(__float_as_uint(u * alt_scale) & alt_keep);
+                v[t] = u > 0.f ? u : alt;
+            }
+            const int64_t off = (int64_t)(16 * o + r) * P;
+            if (VEC) {  // P % 4 == 0 and 16-byte aligned bases: the four positions are in range together
+                if (rb) {
+                    const float4 rr = *reinterpret_cast<const float4 *>(rb + off);
+                    v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
+                }
+                *reinterpret_cast<float4 *>(yb + off) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (p0 + t < P) yb[off + t] = rb ? v[t] + rb[off + t] : v[t];
+            }
+        }
+    }
+}
+
 template <int OT, bool VEC>
 __global__ __launch_bounds__(256) void pointwise_conv_kernel(PwArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -80,36 +139,7 @@ __global__ __launch_bounds__(256) void pointwise_conv_kernel(PwArgs a) {
                 for (int t = 0; t < 4; ++t) acc[o][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][o], xv[u][t], acc[o][t], 0, 0, 0);
     }
     if (!p_in) return;
-    // D layout: lane (g = lane >> 4, j), register r: output 16 ot + 4 g + r, position p0 + t of tile t
-    const int g = k;
-#pragma unroll
-    for (int o = 0; o < OT; ++o) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int oc = 16 * (ot0 + o) + 4 * g + r;
-            if (oc >= a.Cout) continue;
-            const float sc = a.scale ? a.scale[oc] : 1.0f, sh = a.shift ? a.shift[oc] : 0.0f;
-            float v[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                float u = sc * acc[o][t][r] + sh;
-                v[t] = a.act == 1 ? fmaxf(u, 0.f) : (a.act == 2 ? (u >= 0.f ? u : u * a.slope) : u);
-            }
-            const int64_t off = ((int64_t)b * a.Cout + oc) * P + p0;
-            const int64_t roff = (int64_t)b * a.res_bstride + (int64_t)oc * P + p0;
-            if (VEC) {
-                if (a.res) {
-                    const float4 rr = *reinterpret_cast<const float4 *>(a.res + roff);
-                    v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
-                }
-                *reinterpret_cast<float4 *>(a.y + off) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (p0 + t < P) a.y[off + t] = a.res ? v[t] + a.res[roff + t] : v[t];
-            }
-        }
-    }
+    pw_finish<OT, VEC>(a, acc, ot0, k, b, p0);
 }
 
 // The same layer on the coarse maps (a few hundred workgroups at most): there a launch is a chain of K / 16 load-wait-multiply
@@ -156,6 +186,28 @@ __global__ __launch_bounds__(256) void pointwise_conv_ksplit_kernel(PwArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], xv[u][t], acc[t], 0, 0, 0);
     }
+    // wave 0 finishes the tile: its affine pairs (and residual rows) are requested BEFORE the barrier, so that they arrive while the
+    // other waves' sums do; activation as in pw_finish (one select per value, no branches)
+    const int oc0 = 16 * ot + 4 * k;
+    float sc[4] = {1.0f, 1.0f, 1.0f, 1.0f}, sh[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float4 rr[4];
+    const bool finisher = wave == 0 && p_in;
+    const float *rb = a.res ? a.res + (int64_t)b * a.res_bstride + (int64_t)oc0 * P + p0 : nullptr;
+    if (finisher) {
+        if (a.scale) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[r] = a.scale[min(oc0 + r, a.Cout - 1)];
+        }
+        if (a.shift) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh[r] = a.shift[min(oc0 + r, a.Cout - 1)];
+        }
+        if (VEC && rb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (oc0 + r < a.Cout) rr[r] = *reinterpret_cast<const float4 *>(rb + (int64_t)r * P);
+        }
+    }
     if (wave > 0) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -163,37 +215,34 @@ __global__ __launch_bounds__(256) void pointwise_conv_ksplit_kernel(PwArgs a) {
             for (int r = 0; r < 4; ++r) part[wave - 1][lane][4 * t + r] = acc[t][r];
     }
     __syncthreads();
-    if (wave > 0 || !p_in) return;
+    if (!finisher) return;
 #pragma unroll
     for (int w = 0; w < 3; ++w)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[t][r] += part[w][lane][4 * t + r];
-    const int g = k;
+    const float alt_scale = a.act == 1 ? 0.0f : (a.act == 2 ? a.slope : 1.0f);
+    const unsigned alt_keep = a.act == 1 ? 0u : ~0u;
+    float *yb = a.y + ((int64_t)b * a.Cout + oc0) * P + p0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int oc = 16 * ot + 4 * g + r;
-        if (oc >= a.Cout) continue;
-        const float sc = a.scale ? a.scale[oc] : 1.0f, sh = a.shift ? a.shift[oc] : 0.0f;
+        if (oc0 + r >= a.Cout) continue;
         float v[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            float u = sc * acc[t][r] + sh;
-            v[t] = a.act == 1 ? fmaxf(u, 0.f) : (a.act == 2 ? (u >= 0.f ? u : u * a.slope) : u);
+            const float u = sc[r] * acc[t][r] + sh[r];
+            const float alt = __uint_as_float(__float_as_uint(u * alt_scale) & alt_keep);
+            v[t] = u > 0.f ? u : alt;
         }
-        const int64_t off = ((int64_t)b * a.Cout + oc) * P + p0;
-        const int64_t roff = (int64_t)b * a.res_bstride + (int64_t)oc * P + p0;
+        const int64_t off = (int64_t)r * P;
         if (VEC) {
-            if (a.res) {
-                const float4 rr = *reinterpret_cast<const float4 *>(a.res + roff);
-                v[0] += rr.x, v[1] += rr.y, v[2] += rr.z, v[3] += rr.w;
-            }
-            *reinterpret_cast<float4 *>(a.y + off) = make_float4(v[0], v[1], v[2], v[3]);
+            if (rb) v[0] += rr[r].x, v[1] += rr[r].y, v[2] += rr[r].z, v[3] += rr[r].w;
+            *reinterpret_cast<float4 *>(yb + off) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                if (p0 + t < P) a.y[off + t] = a.res ? v[t] + a.res[roff + t] : v[t];
+                if (p0 + t < P) yb[off + t] = rb ? v[t] + rb[off + t] : v[t];
         }
     }
 }
@@ -240,7 +289,10 @@ RPE_API int rpe_pointwise_conv(const float *x, int64_t x_batch_stride, int B, in
 #ifndef RPE_PW_OT2_MIN_WGS
 #define RPE_PW_OT2_MIN_WGS 2048
 #endif
-    if (a.n_otiles >= RPE_PW_OT4_MIN_TILES && wgs1 >= 4 * 1024) return launch_pw<4>(a, B, vec, st);
+#ifndef RPE_PW_OT4_MIN_WGS
+#define RPE_PW_OT4_MIN_WGS 8192  // (72 x 120 maps, 340 / 510 output channels: two tiles a wave 48 / 49 us, four 53 / 56)
+#endif
+    if (a.n_otiles >= RPE_PW_OT4_MIN_TILES && wgs1 >= RPE_PW_OT4_MIN_WGS) return launch_pw<4>(a, B, vec, st);
     if (a.n_otiles >= RPE_PW_OT2_MIN_TILES && wgs1 >= RPE_PW_OT2_MIN_WGS) return launch_pw<2>(a, B, vec, st);
     // 5 .. 7 output tiles from many input channels: three waves of two tiles read x once instead of twice (tools/pw_census.py,
     // 144 x 240: 255 -> 96 108 -> 103 us, 215 -> 81 94 -> 86, 113 -> 81 53 -> 51; below ~100 input channels the same rule loses:
