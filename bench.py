@@ -31,6 +31,7 @@ Extra objects on the line ("Measurement"):
                  host cores, bounded sample (rank 0, N=1 only)
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -411,18 +412,32 @@ def main():
 
     def timed(step):
         marks = [] if (on_gpu and os.environ.get("RPE_BENCH_STEP_TIMES")) else None  # diagnostic: per-step device times to stderr
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+        # The host runs one or two replays ahead of the device (a graph launch blocks beyond that), so a host pause longer than a
+        # step shows in the rate, and a full garbage collection of this process (200 k tracked objects) is a pause of 38-67 ms,
+        # measured here: one default run in ~20 read 15.9 instead of 15.0 ms with its evaluation leg right behind it at 15.5 as
+        # always.  Collect now, not inside the K steps.
+        t_gc = time.perf_counter()
+        gc.collect()
+        if marks is not None:
+            print("full collection: %.1f ms, %d objects tracked" % ((time.perf_counter() - t_gc) * 1e3, len(gc.get_objects())), file=sys.stderr, flush=True)
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                if marks is not None:
+                    marks.append(torch.cuda.Event(enable_timing=True))
+                    marks[-1].record()
+                step()
             if marks is not None:
                 marks.append(torch.cuda.Event(enable_timing=True))
                 marks[-1].record()
-            step()
-        if marks is not None:
-            marks.append(torch.cuda.Event(enable_timing=True))
-            marks[-1].record()
-        barrier()
-        dt = time.perf_counter() - t0
+            barrier()
+            dt = time.perf_counter() - t0
+        finally:
+            if gc_was_on:
+                gc.enable()
         if marks is not None:
             print("step ms:", [round(a.elapsed_time(b), 2) for a, b in zip(marks[:-1], marks[1:])], file=sys.stderr, flush=True)
         if dist is not None:
@@ -504,6 +519,8 @@ def main():
         # every other run went 5-8 % slow.  Up to 40 replays / 0.8 s: about one process in five, always the first on a
         # fresh machine, has ONE replay of ~48 ms instead of 18 among its first ~20 (per-step times, RPE_BENCH_STEP_TIMES=1;
         # same solvers, same numbers: a one-off stall of the runtime, not of a kernel), which read as 205 instead of 222.
+        gc.collect()
+        gc.freeze()  # (what exists now -- model, graphs, caches -- is permanent: later collections walk the new objects only)
         t_settle = time.perf_counter()
         n_replays = 0
         while n_replays < max(args.warmup, 1) or (n_replays < 40 and time.perf_counter() - t_settle < 0.8):

@@ -15,6 +15,7 @@ Counts stay below 2^53, so float64 sums of counts are exact; the value sums diff
 single-process run only by float64 re-association.
 """
 import argparse
+import gc
 import json
 import os
 import time
@@ -329,6 +330,10 @@ def main():
         model.load_state_dict(torch.load(args.weights, map_location=device)["state_dict"], strict=True)
     from .synthetic import SyntheticPairs
     data = SyntheticPairs(args.samples, args.height, args.width, args.points, dsec=args.dsec, events=args.raw_events)
+    # The model's ~200 k long-lived Python objects leave the collector's sight: a full collection of them is a 40-70 ms host
+    # pause (measured in bench.py), and the loop below runs one or two replays ahead of the device at most.
+    gc.collect()
+    gc.freeze()
     t0 = time.perf_counter()
     metrics, _ = evaluate(model, data, args.batch, device, rank, world, group=group, graph=False if args.eager else None)
     torch.cuda.synchronize()
