@@ -425,11 +425,13 @@ def main():
         try:
             barrier()
             t0 = time.perf_counter()
+            host = []  # when each step() returned, on the host's clock: free of charge, and a stalled launch shows as a gap
             for _ in range(args.steps):
                 if marks is not None:
                     marks.append(torch.cuda.Event(enable_timing=True))
                     marks[-1].record()
                 step()
+                host.append(time.perf_counter())
             if marks is not None:
                 marks.append(torch.cuda.Event(enable_timing=True))
                 marks[-1].record()
@@ -440,6 +442,11 @@ def main():
                 gc.enable()
         if marks is not None:
             print("step ms:", [round(a.elapsed_time(b), 2) for a, b in zip(marks[:-1], marks[1:])], file=sys.stderr, flush=True)
+        if on_gpu and len(host) > 2:
+            gaps = [round((b - a) * 1e3, 2) for a, b in zip([t0] + host[:-1], host)]
+            if max(gaps) > 2.5 * dt / args.steps * 1e3 or os.environ.get("RPE_BENCH_HOST_GAPS"):
+                print("host ms between step() returns (a gap far above the step time is a stalled launch): %s; drain %.2f" %
+                      (gaps, (t0 + dt - host[-1]) * 1e3), file=sys.stderr, flush=True)
         if dist is not None:
             t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -475,7 +482,7 @@ def main():
     # sequence already alive in the process, every other run's forward graph replayed 8 % slower (202-207 instead of
     # 218 frame-pairs/s, 4 of 8 runs; never in 30 captures without them) -- whatever the runtime derives its queue
     # mapping from depends on what was captured before.
-    epe_delta, dt, launch = None, None, None
+    epe_delta, dt, launch, step_clock = None, None, None, None
     eval_info = None
     if args.workload in ("forward", "eval"):
         from rpeflow_amd.model import RPEFlow
@@ -529,7 +536,9 @@ def main():
             if n_replays % 4 == 0:
                 sync()
         if args.workload == "forward":
-            dt = timed(fwd_step)
+            step_clock = runtime.ShaderClock(dev)
+            with step_clock:  # one stamp launch in front of and one behind the barriers that bracket the K steps: outside the timed region
+                dt = timed(fwd_step)
         n_eval = args.steps if args.workload == "eval" else args.eval_batches
         if forward is not None and n_eval > 0:
             dt_eval, eval_info = eval_leg(model, forward, dev, cfg, args.batch, n_eval, rank, world, dist, workers=args.eval_workers,
@@ -609,6 +618,19 @@ def main():
                                 "HIP events per category; roofline_frac = sum of algorithmic bytes (rpeflow_amd/roofline.py, SURVEY.md "
                                 "8d) / sum of category durations / 8 TB/s"},
         }
+        if step_clock is not None:
+            # what the device's own counters say about the K timed steps: a slow line with the usual cycles per step is a clock
+            # (power / thermal / a neighbour on the node), one with more cycles is work or stalls
+            torch.cuda.synchronize()
+            cycles, ticks, khz = step_clock.raw()
+            line["step_clock"] = {
+                "shader_cycles_per_step": round(cycles / args.steps) if ticks > 0 else None,
+                "ms_per_step_by_device_counter": round(ticks / khz / args.steps, 3) if (ticks > 0 and khz > 0) else None,
+                "cycles_per_us": round(cycles / ticks * khz / 1e3, 1) if (ticks > 0 and khz > 0) else None,
+                "cycles_per_us_per_xcd": step_clock.mhz_per_xcd(), "units_read": step_clock.units(),
+                "note": "two rpe_clock_stamp_all launches around the timed steps (outside their barriers), median compute unit.  A compute "
+                        "unit's cycle counter stands still while it is idle, and the forward does not keep every unit busy all the time: "
+                        "cycles_per_us is busy-weighted, BELOW the engine clock, and comparable between runs of this same command only"}
         if epe_delta is not None:
             line["epe_delta"] = epe_delta
         if eval_info is not None:

@@ -14,6 +14,10 @@ static inline int rpe_launch_status() {
     return e == hipSuccess ? 0 : (int)e;
 }
 
+// nn.ReLU as ATen computes it on the reference's CPU path: NaN stays NaN, -0 stays -0.
+// fmaxf(x, 0) returns 0 for both; the reference's evaluation masks NaN predictions (eval_withocc.py:86-87), so a NaN has to
+// reach the output as one.
+__device__ __forceinline__ float rpe_relu(float x) { return x < 0.f ? 0.f : x; }
 __device__ __forceinline__ int rpe_lane() { return (int)(threadIdx.x & (RPE_WAVE - 1)); }
 
 // wave-uniform value -> scalar register

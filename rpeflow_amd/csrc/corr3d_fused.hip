@@ -40,14 +40,14 @@ __device__ __forceinline__ void net_front(const Net3 &net, const float (&rel)[3]
         float s = net.b1[o];
 #pragma unroll
         for (int d = 0; d < 3; ++d) s = __fmaf_rn(net.w1[o * 3 + d], rel[d], s);
-        h1[o] = fmaxf(s, 0.f);
+        h1[o] = rpe_relu(s);
     }
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
         float s = net.b2[o];
 #pragma unroll
         for (int i = 0; i < 8; ++i) s = __fmaf_rn(net.w2[o * 8 + i], h1[i], s);
-        h2[o] = fmaxf(s, 0.f);
+        h2[o] = rpe_relu(s);
     }
     a0 = kk == 0 ? h2[0] : kk == 1 ? h2[1] : kk == 2 ? h2[2] : h2[3];
     a1 = kk == 0 ? h2[4] : kk == 1 ? h2[5] : kk == 2 ? h2[6] : h2[7];
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void corr3d_cost_kernel(
         wn = mfma16(na1, w3[1], wn);
         f32x4 prod;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) prod[r] = fmaxf(wn[r] + bias3, 0.f) * leaky(acc[p][r] + bias2, slope);
+        for (int r = 0; r < 4; ++r) prod[r] = rpe_relu(wn[r] + bias3) * leaky(acc[p][r] + bias2, slope);
         const float s = column_sum(prod);
         if (kk == 0) o[c] = s;
     }
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void corr3d_n2n_kernel(const float *__restrict
         const float bias3 = net.b3[c];
         f32x4 prod;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) prod[r] = fmaxf(wn[r] + bias3, 0.f) * src[r][16 * t];
+        for (int r = 0; r < 4; ++r) prod[r] = rpe_relu(wn[r] + bias3) * src[r][16 * t];
         const float s = column_sum(prod);
         if (kk == 0 && c < C) out[((int64_t)b * C + c) * N + n] = s;
     }

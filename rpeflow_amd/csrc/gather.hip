@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ x
         float u = in ? plane[(int64_t)y * W + xx] : 0.f;
         if (in_scale || in_shift || in_act) {
             u = a * u + s;
-            u = in_act == 1 ? fmaxf(u, 0.f) : (in_act == 2 ? (u >= 0.f ? u : u * in_slope) : u);
+            u = in_act == 1 ? rpe_relu(u) : (in_act == 2 ? (u >= 0.f ? u : u * in_slope) : u);
             u = in ? u : 0.f;
         }
         v[t] = u;

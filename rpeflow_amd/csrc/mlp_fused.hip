@@ -39,7 +39,7 @@ __device__ __forceinline__ f32x4 epilogue(f32x4 v, f32x4 scale, f32x4 shift, int
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float t = v[r] * scale[r] + shift[r];
-        if (act == 1) t = fmaxf(t, 0.f);
+        if (act == 1) t = rpe_relu(t);
         if (act == 2) t = t >= 0.f ? t : t * slope;
         y[r] = t;
     }

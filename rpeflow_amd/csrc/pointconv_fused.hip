@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256 * KS, KS == 1 ? 2 : 1) void pointconv_fused_ker
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = total[mt][nt][r] * sc + sh;
-                if (a.act == 1) v = fmaxf(v, 0.f);
+                if (a.act == 1) v = rpe_relu(v);
                 if (a.act == 2) v = leaky(v, a.act_slope);
                 y[r] = v;
             }

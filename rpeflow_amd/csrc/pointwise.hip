@@ -35,8 +35,8 @@ struct PwArgs {
 
 // Epilogue of pointwise_conv_kernel.  D layout: lane (g = lane >> 4, j), register r: output 16 ot + 4 g + r, position p0 + t of
 // tile t.  v = act(scale * acc + shift) [+ residual].  The activation is ONE select per value whatever its kind -- identity,
-// relu and leaky_relu are "u > 0 ? u : alt" with alt = u * 1, +0, u * slope (bit for bit fmaxf(u, 0) and u >= 0 ? u : u * slope
-// for a slope >= 0, signed zeros and NaNs included) -- and the affine pairs are read a tile (four rows) at a time: with the
+// relu and leaky_relu are "u < 0 ? alt : u" with alt = u * 1, +0, u * slope (nn.ReLU / nn.LeakyReLU as ATen computes them on the
+// reference's CPU path: NaN stays NaN, -0 stays -0) -- and the affine pairs are read a tile (four rows) at a time: with the
 // tests on act / scale / shift inside the loops the compiler emitted ~4 scalar branches per output VALUE (260 branches a wave,
 // a wait on every scale / shift pair).
 template <int OT, bool VEC>
@@ -74,7 +74,7 @@ __device__ __forceinline__ void pw_finish(const PwArgs &a, const pw_f32x4 (&acc)
             for (int t = 0; t < 4; ++t) {
                 const float u = sc[r] * d[t][r] + sh[r];
                 const float alt = __uint_as_float(__float_as_uint(u * alt_scale) & alt_keep);
-                v[t] = u > 0.f ? u : alt;
+                v[t] = u < 0.f ? alt : u;
             }
             const int64_t off = (int64_t)(16 * o + r) * P;
             if (VEC) {  // P % 4 == 0 and 16-byte aligned bases: the four positions are in range together
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void pointwise_conv_ksplit_kernel(PwArgs a) {
         for (int t = 0; t < 4; ++t) {
             const float u = sc[r] * acc[t][r] + sh[r];
             const float alt = __uint_as_float(__float_as_uint(u * alt_scale) & alt_keep);
-            v[t] = u > 0.f ? u : alt;
+            v[t] = u < 0.f ? alt : u;
         }
         const int64_t off = (int64_t)r * P;
         if (VEC) {

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(float *__restrict__ y, 
     float *row = y + ((int64_t)b * C + c) * P + p;
     auto f = [&](float v) {
         v = a * v + s;
-        return act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v >= 0.f ? v : v * slope) : v);
+        return act == 1 ? rpe_relu(v) : (act == 2 ? (v >= 0.f ? v : v * slope) : v);
     };
     if (p + 4 <= P && ((reinterpret_cast<uintptr_t>(row) & 15) == 0)) {
         float4 v = *reinterpret_cast<float4 *>(row);
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void affine_add_act_kernel(float *__restrict__
     const float *zrow = z + ((int64_t)b * C + c) * P + p;
     auto f = [&](float v, float w) {
         v = (a * v + s) + za * w;
-        return act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v >= 0.f ? v : v * slope) : v);
+        return act == 1 ? rpe_relu(v) : (act == 2 ? (v >= 0.f ? v : v * slope) : v);
     };
     if (p + 4 <= P && (((reinterpret_cast<uintptr_t>(row) | reinterpret_cast<uintptr_t>(zrow)) & 15) == 0)) {
         float4 v = *reinterpret_cast<float4 *>(row);
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void residual_tail_kernel(float *__restrict__ 
         const float a = scale ? scale[oc] : 1.0f, s = shift ? shift[oc] : 0.0f, za = zscale ? zscale[oc] : 1.0f;
         float *row = y + ((int64_t)b * Cout + oc) * P + p;
         float v = (a * *row + s) + za * acc[o];
-        *row = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v >= 0.f ? v : v * slope) : v);
+        *row = act == 1 ? rpe_relu(v) : (act == 2 ? (v >= 0.f ? v : v * slope) : v);
     }
 }
 

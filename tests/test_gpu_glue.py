@@ -700,6 +700,28 @@ def test_pointwise_conv_reads_channel_slices_where_they_lie():
         close(odd, (wide_r[:, :3, :511] + conv(wide_x[:, 3:67, :511])).cpu().numpy(), 1e-5)
 
 
+@pytest.mark.parametrize("cin", [1, 64])  # one channel group: the plain kernel; 16 groups on a small map: the K-split form
+@pytest.mark.parametrize("act", [None, "relu", "leaky_relu"])
+def test_activations_keep_nan_and_signed_zero_like_the_reference(cin, act):
+    """act(scale * (w . x) + shift) on NaN, infinities, signed zeros and denormals == the same expression in PyTorch on the CPU,
+    bit for bit: nn.ReLU / nn.LeakyReLU(0.1) keep a NaN a NaN and -0 a -0 there (the reference's evaluation masks NaN predictions,
+    eval_withocc.py:86-87); fmaxf(u, 0) would return 0 for both."""
+    special = np.array([np.nan, -0.0, 0.0, -1.5, 2.5, -np.inf, np.inf, -1e-45, 1e-45, -3e38, 3e38, 1.0], dtype=np.float32)
+    x = np.zeros((1, cin, 128), dtype=np.float32)
+    x[0, 0] = np.tile(special, 11)[:128]
+    w = np.zeros((1, cin, 1), dtype=np.float32)
+    w[0, 0, 0] = 1.0
+    fn = {None: lambda t: t, "relu": torch.relu, "leaky_relu": lambda t: torch.nn.functional.leaky_relu(t, 0.1)}[act]
+    for scale, shift in ((1.0, 0.0), (-1.0, -0.0), (0.5, 1.0)):  # (-1, -0): zeros come out as -0 in front of the activation
+        sc, sh = torch.tensor([scale]), torch.tensor([shift])
+        want = fn(torch.nn.functional.conv1d(torch.from_numpy(x), torch.from_numpy(w)) * sc.view(1, -1, 1) + sh.view(1, -1, 1))
+        got = U.pointwise_conv(dev(x), dev(w), None, 1, epilogue=(sc.to(DEV), sh.to(DEV), act))
+        bits = lambda t: t.detach().cpu().contiguous().numpy().view(np.uint32)
+        nan = torch.isnan(want).numpy()
+        assert np.array_equal(np.isnan(got.cpu().numpy()), nan)
+        assert np.array_equal(bits(got)[~nan], bits(want)[~nan]), (act, scale, shift)
+
+
 def test_pyramid_of_stacked_clouds_and_constant_level0_feature():
     """build_pc_pyramid on the two halves of one [2B,3,N] tensor (no cat, one gather) == on separate tensors; FeaturePyramid3D's
     level-0 feature computed on one point and broadcast == computed on every point (pwc3d_core.py:51-52), bit for bit."""
