@@ -50,7 +50,7 @@ __device__ __forceinline__ void pw_finish(const PwArgs &a, const pw_f32x4 (&acc)
 #pragma unroll
     for (int o = 0; o < OT; ++o) {
         // the tile's sums stay in the accumulation registers until its turn: the compiler would move all 16 OT vectors out
-        // behind the loop (148 registers, two waves a SIMD instead of three)
+        // behind the loop (148 registers at four tiles a wave: two waves a SIMD; 119 and four waves this way)
         pw_f32x4 d[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
