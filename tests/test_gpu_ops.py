@@ -488,3 +488,24 @@ def test_shader_clock_reads_every_compute_unit():
     assert mhz is None or runtime.SCLK_PLAUSIBLE_MHZ[0] <= mhz <= runtime.SCLK_PLAUSIBLE_MHZ[1]
     assert 1 <= len(clock.mhz_per_xcd()) <= 8
     print("engine clock over the loop: %s MHz, per XCD %s, %d compute units read" % (mhz, clock.mhz_per_xcd(), clock.units()))
+
+
+@pytest.mark.parametrize("B,M,Q,k,D", [(4, 8192, 4096, 16, 3), (4, 2048, 2048, 16, 3), (4, 4096, 8192, 3, 3), (4, 300, 200, 1, 3), (8, 4096, 34560, 1, 2), (2, 100, 64, 63, 3)])
+@pytest.mark.parametrize("where", ["cloud", "query", "one sample"])
+def test_nan_coordinates_never_produce_an_index_outside_the_cloud(B, M, Q, k, D, where):
+    """Every kernel family of k_nearest_neighbor (insertion, matrix + tie replay, nearest, binned 2-D) and furthest_point_sampling
+    on clouds with NaN coordinates: whatever order NaN distances end up in, the indices stay inside [0, M) -- the gathers that consume
+    them do not check."""
+    g = torch.Generator().manual_seed(7)
+    x, q = torch.randn(B, M, D, generator=g).to(DEV), torch.randn(B, Q, D, generator=g).to(DEV)
+    if where == "cloud":
+        x[:, ::7] = float("nan")
+    elif where == "query":
+        q[:, ::5, 0] = float("nan")
+    else:
+        x[1], q[1] = float("nan"), float("nan")
+    idx = W.k_nearest_neighbor(x, q, k)
+    assert idx.shape == (B, Q, k) and int(idx.min()) >= 0 and int(idx.max()) < M
+    if D == 3 and M > 256:
+        fps = W.furthest_point_sampling(x, M // 4)
+        assert int(fps.min()) >= 0 and int(fps.max()) < M

@@ -246,6 +246,31 @@ def test_sampling_one_batch_ahead_changes_nothing():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("what", ["one NaN coordinate", "whole cloud NaN"])
+def test_a_corrupt_sample_turns_nan_and_leaves_the_others_alone(what):
+    """A NaN in one sample's point cloud: that sample's flows come out NaN (the reference's evaluation masks NaN predictions,
+    eval_withocc.py:86-87), every other sample of the batch keeps its bits (samples are independent in eval mode,
+    eval_withocc.py:46), and no neighbour / sampling index leaves its cloud on the way (the gathers behind them do not check)."""
+    from rpeflow_amd.model import RPEFlow
+    torch.manual_seed(0)
+    model = RPEFlow().to("cuda:0").eval()
+    samples = [I.frame_pair(4100 + i, H=128, W=192, N=8192) for i in range(3)]
+    batch = {k: torch.stack([torch.from_numpy(s[k]) for s in samples]).to("cuda:0") for k in samples[0]}
+    with torch.no_grad():
+        clean = {k: v.clone() for k, v in model(batch).items() if k in ("flow_2d", "flow_3d")}
+        if what == "one NaN coordinate":
+            batch["pcs"][1, 0, 17] = float("nan")
+        else:
+            batch["pcs"][1, :3] = float("nan")
+        out = model(batch)
+    torch.cuda.synchronize()
+    for key in ("flow_2d", "flow_3d"):
+        assert torch.isfinite(clean[key]).all()
+        assert torch.equal(out[key][0], clean[key][0]) and torch.equal(out[key][2], clean[key][2]), key
+        assert torch.isnan(out[key][1]).all(), key
+
+
+@pytest.mark.gpu
 def test_every_pyramid_level_matches_the_reference(golden_dir):
     """Per-level intermediates: the up-sampled flows of all five decoder levels (what RPEFlow_core.decode returns,
     RPEFlow_core.py:426-432) against the reference's on the 128x192 golden sample."""
