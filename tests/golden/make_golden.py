@@ -483,8 +483,236 @@ def gen_eval():
     save("eval_accumulators", withocc=np.asarray(withocc, np.float64), noocc=np.asarray(noocc, np.float64))
 
 
+# ------------------------------------------------------------------ the reference model's own calls
+TRACE_CASE = dict(B=2, H=128, W=192, N=8192, first_seed=1000)
+# functions wrapped where the reference's modules bound them at import time (``from .csrc import ...``): (module, name) pairs
+TRACE_FUNCTIONS = {
+    "k_nearest_neighbor": ["RPEFlow_core", "pwc3d_core", "pointconv", "utils"],
+    "furthest_point_sampling": ["pwc3d_core"],
+    "correlation2d": ["RPEFlow_core"],
+    "batch_indexing_channel_first": ["utils", "pwc3d_core", "pointconv"],
+    "batch_indexing_channel_last": ["utils", "pointconv"],
+    "knn_interpolation": ["utils", "RPEFlow_core"],
+    "backwarp_3d": ["RPEFlow_core"],
+    "backwarp_2d": ["RPEFlow_core"],
+    "grid_sample_wrapper": ["utils", "RPEFlow_core"],
+    "project_feat_with_nn_corr": ["RPEFlow_core"],
+    "build_pc_pyramid": ["RPEFlow"],
+}
+TRACE_CLASSES = {"pointconv": ["PointConvDownSampling", "PointConvNoSampling"], "pwc3d_core": ["Correlation3D", "FlowEstimator3D", "FeaturePyramid3D"]}
+TRACE_GEOMETRY = {"input_xyz", "query_xyz", "xyz", "xyz1", "xyz2", "sampled_xyz", "xy", "flow12", "pc1", "pc2", "xyzs"}
+
+
+class _Recorder:
+    """Records calls (see tests/trace_io.py for the format); one instance per generated trace."""
+
+    def __init__(self):
+        import hashlib
+        self.sha = hashlib.sha1
+        self.calls, self.arrays, self.by_hash = [], {}, {}
+        self.enabled, self.stack, self.module_names = False, [], {}
+
+    # -- storage
+    def store(self, a):
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.int64:  # indices: narrowed for storage, widened again on load
+            a = a.astype(np.uint16 if (a.size == 0 or (a.min() >= 0 and a.max() < 65536)) else np.int32)
+        h = self.sha(str((a.dtype, a.shape)).encode() + a.tobytes()).hexdigest()
+        if h not in self.by_hash:
+            self.by_hash[h] = "a%04d" % len(self.arrays)
+            self.arrays[self.by_hash[h]] = a
+        return self.by_hash[h]
+
+    def describe(self, t, name, seed):
+        from tests import trace_io as TIO
+        rec = dict(shape=list(t.shape), dtype=str(t.dtype).replace("torch.", ""), strides=list(t.stride()), offset=int(t.storage_offset()))
+        v = t.detach().contiguous().numpy()
+        geometry = name in TRACE_GEOMETRY or not t.dtype.is_floating_point or (t.dim() == 3 and min(t.shape[1], t.shape[2]) <= 3 and t.numel() <= 65536)
+        if geometry or t.numel() * t.element_size() <= TIO.FULL_BYTES:
+            rec["key"] = self.store(v)
+        else:
+            scale, shift = float(np.float32(v.std())), float(np.float32(v.mean()))
+            rec["synthetic"] = dict(seed=seed, scale=scale, shift=shift)
+        return rec
+
+    def describe_output(self, out, seed):
+        from tests import trace_io as TIO
+        if isinstance(out, (list, tuple)):
+            return dict(kind="list", items=[self.describe_output(o, seed * 16 + i) for i, o in enumerate(out)])
+        rec = dict(kind="tensor", shape=list(out.shape), dtype=str(out.dtype).replace("torch.", ""))
+        v = out.detach().contiguous().numpy()
+        small_geometry = out.dim() == 3 and out.shape[1] <= 3 and out.numel() <= 65536
+        if not out.dtype.is_floating_point or out.numel() <= TIO.SAMPLE_ABOVE or small_geometry:
+            rec["key"] = self.store(v)
+        else:
+            rec["sampled"] = dict(seed=seed, n=TIO.N_SAMPLES)
+            rec["key"] = self.store(v.reshape(-1)[TIO.sample_positions(seed, v.size)])
+        return rec
+
+    # -- one call
+    def begin(self, fn_name, site, params, module=None):
+        """``params``: [(name, value, "pos" | "kw")] in call order."""
+        index = len(self.calls)
+        call = dict(index=index, fn=fn_name, site=site, parent=self.stack[-1] if self.stack else None, args=[])
+        if module is not None:
+            call["module"] = module
+        seen = []
+        for j, (name, value, passed) in enumerate(params):
+            a = dict(name=name, passed=passed)
+            if torch.is_tensor(value):
+                a["kind"] = "tensor"
+                same = [n for n, v in seen if v is value]
+                if same:
+                    a["same_as"] = same[0]
+                else:
+                    a["t"] = self.describe(value, name, seed=1_000_000 + index * 16 + j)
+                seen.append((name, value))
+            elif isinstance(value, (list, tuple)) and value and all(torch.is_tensor(v) for v in value):
+                a["kind"] = "tensor_list"
+                a["t"] = [self.describe(v, name, seed=2_000_000 + index * 64 + j * 8 + i) for i, v in enumerate(value)]
+            elif value is None:
+                a["kind"] = "none"
+            else:
+                a["kind"] = "value"
+                a["value"] = list(value) if isinstance(value, (list, tuple)) else value
+            call["args"].append(a)
+        self.calls.append(call)
+        self.stack.append(index)
+        return call
+
+    def finish(self, call, rerun, out):
+        """``rerun(args, kwargs)`` calls the reference function again; used when an argument was replaced by seeded values."""
+        from tests import trace_io as TIO
+        self.stack.pop()
+        synthetic = [a["name"] for a in call["args"] if a["kind"] == "tensor" and "t" in a and "synthetic" in a["t"]]
+        if synthetic:
+            call["synthetic_args"] = synthetic
+            trace = TIO.Trace.__new__(TIO.Trace)
+            trace.arrays = self.arrays
+            args, kwargs = TIO.Trace.arguments(trace, call, "cpu")
+            was, self.enabled = self.enabled, False
+            try:
+                out = rerun(args, kwargs)
+            finally:
+                self.enabled = was
+        call["out"] = self.describe_output(out, seed=3_000_000 + call["index"])
+
+
+def _site(skip_prefixes=("torch",)):
+    """file:line of the nearest frame that is reference code (models/...)."""
+    f = sys._getframe(2)
+    while f is not None:
+        name = f.f_code.co_filename
+        if name.startswith(REF) and not name.endswith("make_golden.py"):
+            return os.path.relpath(name, REF) + ":%d" % f.f_lineno
+        f = f.f_back
+    return "?"
+
+
+def _module_record(rec, mod):
+    cls = type(mod).__name__
+    norm = lambda m: {"BatchNorm1d": "batch_norm", "InstanceNorm1d": "instance_norm", "Identity": None}[type(m.norm_fn).__name__]
+    act = lambda m: {"ReLU": "relu", "LeakyReLU": "leaky_relu", "Identity": None}[type(m.activation_fn).__name__]
+    if cls.startswith("PointConv"):
+        ctor = dict(in_channels=mod.linear.in_features // 16 - 3, out_channels=mod.linear.out_features, norm=norm(mod), activation=act(mod), k=mod.k)
+    elif cls == "Correlation3D":
+        first = mod.cost_mlp.convs[0].conv_fn
+        ctor = dict(in_channels=(first.in_channels - 3) // 2, out_channels=first.out_channels, k=mod.k)
+    elif cls == "FlowEstimator3D":
+        ctor = dict(n_channels=[mod.point_conv1.linear.in_features // 16 - 3, mod.point_conv1.linear.out_features, mod.point_conv2.linear.out_features,
+                                mod.mlp.convs[-1].conv_fn.out_channels], norm=norm(mod.point_conv1), conv_last=mod.conv_last is not None, k=mod.point_conv1.k)
+    else:  # FeaturePyramid3D
+        chans = [mod.level0_mlp.convs[-1].conv_fn.out_channels] + [m.convs[-1].conv_fn.out_channels for m in mod.pyramid_mlps]
+        ctor = dict(n_channels=chans, norm=norm(mod.pyramid_convs[0]), k=mod.pyramid_convs[0].k)
+    return dict(name=rec.module_names[id(mod)], cls=cls, ctor=ctor)
+
+
+@torch.no_grad()
+def gen_call_trace():
+    """Every call the reference MODEL makes into the hot path during one forward (128 x 192 frames, B = 2, 8192 points, seeded
+    parameters): the four names of models/csrc, the section-8(a) glue functions of models/utils.py, build_pc_pyramid and the
+    PointConv / Correlation3D / FlowEstimator3D / FeaturePyramid3D forwards -- how each was called (positional / keyword),
+    shapes, dtypes, strides, storage offsets, values and outputs.  Format and storage policy: tests/trace_io.py."""
+    import importlib
+    import inspect
+    import json
+    from tests import trace_io as TIO
+
+    m = reference_model()
+    m.load_state_dict({k: T(v) for k, v in model_params(m).items()}, strict=True)
+    m.eval()
+    rec = _Recorder()
+    rec.module_names = {id(mod): name for name, mod in m.named_modules()}
+    undo = []
+
+    def wrap_function(fn_name, original):
+        sig = inspect.signature(original)
+
+        def wrapper(*args, **kwargs):
+            if not rec.enabled:
+                return original(*args, **kwargs)
+            names = list(sig.parameters)
+            params = [(names[i], v, "pos") for i, v in enumerate(args)] + [(k, v, "kw") for k, v in kwargs.items()]
+            call = rec.begin(fn_name, _site(), params)
+            out = original(*args, **kwargs)
+            rec.finish(call, lambda a, k: original(*a, **k), out)
+            return out
+        return wrapper
+
+    def wrap_forward(cls):
+        original = cls.forward
+        sig = inspect.signature(original)
+
+        def forward(self, *args, **kwargs):
+            if not rec.enabled:
+                return original(self, *args, **kwargs)
+            names = list(sig.parameters)[1:]
+            params = [(names[i], v, "pos") for i, v in enumerate(args)] + [(k, v, "kw") for k, v in kwargs.items()]
+            call = rec.begin(cls.__name__ + ".forward", _site(), params, module=_module_record(rec, self))
+            out = original(self, *args, **kwargs)
+            rec.finish(call, lambda a, k: original(self, *a, **k), out)
+            return out
+        cls.forward = forward
+        undo.append(lambda: setattr(cls, "forward", original))
+
+    for fn_name, modules in TRACE_FUNCTIONS.items():
+        wrapped = None
+        for mod_name in modules:
+            mod = importlib.import_module("models." + mod_name)
+            original = getattr(mod, fn_name)
+            wrapped = wrapped or wrap_function(fn_name, original)
+            setattr(mod, fn_name, wrapped)
+            undo.append(lambda mod=mod, fn_name=fn_name, original=original: setattr(mod, fn_name, original))
+    for mod_name, classes in TRACE_CLASSES.items():
+        for cls_name in classes:
+            wrap_forward(getattr(importlib.import_module("models." + mod_name), cls_name))
+
+    c = TRACE_CASE
+    samples = [I.frame_pair(c["first_seed"] + i, H=c["H"], W=c["W"], N=c["N"]) for i in range(c["B"])]
+    batch = {k: torch.stack([T(s[k]) for s in samples]) for k in samples[0]}
+    rec.enabled = True
+    try:
+        out = m(batch, is_Train=False)
+    finally:
+        rec.enabled = False
+        for u in reversed(undo):
+            u()
+    assert torch.isfinite(out["flow_2d"]).all() and torch.isfinite(out["flow_3d"]).all()
+
+    counts = {}
+    for call in rec.calls:
+        counts[call["fn"]] = counts.get(call["fn"], 0) + 1
+    print("calls:", len(rec.calls), counts)
+    meta = dict(case=c, parameters="tests.inputs.model_params over tests/golden/state_dict_keys.json", full_bytes=TIO.FULL_BYTES,
+                sample_above=TIO.SAMPLE_ABOVE, n_samples=TIO.N_SAMPLES, counts=counts, calls=rec.calls)
+    with open(os.path.join(OUT, "call_trace.json"), "w") as f:
+        json.dump(meta, f, separators=(",", ":"))
+    save("call_trace", **rec.arrays)
+    print("call_trace.json: %.0f KiB, %d arrays" % (os.path.getsize(os.path.join(OUT, "call_trace.json")) / 1024, len(rec.arrays)))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval", "fblocks", "model_bench", "model_bench_dsec", "model_stress", "blocks_general", "ids_sweep"]
+    which = sys.argv[1:] or ["knn", "fps", "sqdist", "corr", "glue", "blocks", "model", "model_dsec", "model_full", "events", "eval", "fblocks", "model_bench", "model_bench_dsec", "model_stress", "blocks_general", "ids_sweep", "call_trace"]
     for w in which:
         globals()["gen_" + w]()

@@ -1,8 +1,9 @@
 """Randomised parity of the hot-path operators against the oracle: shapes, layouts and cloud kinds drawn from a seeded stream,
 the same acceptance rules as the hand-written cases (indices and distance bit patterns exact for KNN, indices exact for FPS,
-<= 5e-6 for correlation and the samplers), for as long as RPE_FUZZ_SECONDS allows PER OPERATOR (default 4 s: a few dozen cases
-each inside the regular GPU suite; the round's long run -- profiles/r05_fuzz_parity.txt -- sets 240).  Every case is
-reproducible from its printed seed."""
+<= 5e-6 for correlation and the samplers).  Inside the regular GPU suite every operator runs a FIXED number of cases
+(RPE_FUZZ_CASES, default 200: the same seeds on every box, so what the record covers does not depend on the box's speed);
+the long runs (profiles/r05_fuzz_parity.txt, profiles/r06_fuzz_parity.txt) set RPE_FUZZ_SECONDS instead -- a time budget PER
+OPERATOR -- and RPE_FUZZ_SEED_OFFSET for fresh seeds.  Every case is reproducible from its printed seed."""
 import os
 import time
 
@@ -21,7 +22,8 @@ from rpeflow_amd import utils as U  # noqa: E402
 from rpeflow_amd.csrc import wrapper as W  # noqa: E402
 
 DEV = "cuda:0"
-BUDGET = float(os.environ.get("RPE_FUZZ_SECONDS", "4"))
+CASES = int(os.environ.get("RPE_FUZZ_CASES", "200"))          # the suite: this many seeds per operator, whatever the box
+BUDGET = float(os.environ.get("RPE_FUZZ_SECONDS", "0"))       # a long run: seeds until this many seconds are used (overrides CASES)
 OFFSET = int(os.environ.get("RPE_FUZZ_SEED_OFFSET", "0"))  # a long run on fresh seeds: RPE_FUZZ_SECONDS=300 RPE_FUZZ_SEED_OFFSET=10000000
 
 
@@ -51,10 +53,11 @@ BASES = {"knn": 910000, "fps": 920000, "corr": 930000, "sample": 940000, "interp
 
 
 def run(case, name):
-    """Calls case(rng, seed) with fresh seeds until the budget is used; returns the number of cases."""
+    """Calls case(rng, seed) with seeds base, base + 1, ...: CASES of them, or -- with RPE_FUZZ_SECONDS -- until that budget is
+    used; returns the number of cases."""
     t0, n = time.perf_counter(), 0
     base = BASES[name] + OFFSET
-    while n < 2 or time.perf_counter() - t0 < BUDGET:
+    while (time.perf_counter() - t0 < BUDGET or n < 2) if BUDGET > 0 else n < CASES:
         seed = base + n
         try:
             case(I.rng(seed), seed)

@@ -398,6 +398,16 @@ def test_correlation_full_size_properties():
     # shifted plane against torch: dy=+2, dx=-3 -> plane (2+4)*9 + (-3+4)
     sh = (a[:, :, :-2, 3:] * b[:, :, 2:, :-3]).mean(1)
     assert (out[:, 55, :-2, 3:] - sh).abs().max().item() < 2e-5
+    # all 81 planes (BASELINE config 2 in full) against the reference's naive recipe restated in fp32 PyTorch on the GPU:
+    # slices of the zero-padded second input, mean over channels (wrapper.py:56-65, correlation_test.cpp:27-42)
+    padded = torch.nn.functional.pad(b, (4, 4, 4, 4))
+    worst = 0.0
+    for i in range(9):
+        for j in range(9):
+            plane = (a * padded[:, :, i:i + 544, j:j + 960]).mean(1)
+            worst = max(worst, (out[:, i * 9 + j] - plane).abs().max().item())
+    assert worst < 2e-5, worst
+    del padded, plane
     out2 = ops.correlation2d(2.0 * a, b, 4)
     assert torch.equal(out2, 2.0 * out)
     # every kernel agrees on a crop, and the DMA-ring variants agree with the first MFMA kernel at full size
