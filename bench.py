@@ -17,11 +17,14 @@ Rank 0 prints ONE JSON line.  Started without a launcher (no WORLD_SIZE in the e
 process touches the GPU (cf. the reference's mp.spawn, train.py:289, 65).
 
 Extra objects on the line ("Measurement"):
-  roofline       the dominant single-kernel category of the step: algorithmic bytes per
-                 launch / average launch duration (HIP events inside the timed region)
-  hotpath        the hot-path operator sequence alone, per category: ms, algorithmic bytes,
-                 fraction of the 8 TB/s roofline, and the whole-forward hot-path fraction
-                 (sum of bytes / sum of durations / 8 TB/s)
+  roofline       the largest in-scope THROUGHPUT kernel of the step (pointconv_fused_kernel, level-1
+                 estimator layer): SURVEY 8(d) flops per launch / average launch duration (HIP
+                 events over back-to-back launches of that kernel) against the fp32 matrix peak
+  roofline_fps   the step's longest kernel, furthest-point sampling: latency-bound, us per
+                 dependent iteration against the synchronisation floor
+  hotpath        the hot-path operator sequence alone, per category: ms, algorithmic bytes AND
+                 flops, which roofline bounds it, floor = max(bytes / 8 TB/s, flops / 157.3 TF),
+                 frac = floor / measured; roofline_frac = sum of floors / sum of durations
   epe_delta      |EPE2D|, |EPE3D| differences of THIS configuration's output (the replayed
                  graph, untimed) against the reference's CPU forward on the same batch
   roofline_corr  BASELINE config 2, the correlation-only microbench 1x256x544x960 (N=1 only)
@@ -30,12 +33,15 @@ Extra objects on the line ("Measurement"):
   cpu_baseline   the PyTorch-CPU port of the reference fallback (oracle/torch_ref.py) on the
                  host cores, bounded sample (rank 0, N=1 only)
 """
-import argparse
-import gc
-import json
-import os
-import sys
 import time
+
+T_PROCESS = time.perf_counter()  # (before the heavy imports: a fresh box pages torch in for a minute or two, and that is start-up time)
+
+import argparse  # noqa: E402
+import gc  # noqa: E402
+import json  # noqa: E402
+import os  # noqa: E402
+import sys  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -51,6 +57,7 @@ try:
 except Exception:  # noqa: BLE001 -- a build without MIOpen reports none
     RUNTIME["miopen"] = None
 
+T_IMPORTED = time.perf_counter()
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak (SURVEY.md 8d prices KNN against it)
 H, W, NPTS = 544, 960, 8192  # the correlation microbench's frame (BASELINE config 2) and the default workload's
@@ -84,6 +91,8 @@ def parse():
     p.add_argument("--eval-raw-events", type=int, default=0, help="the evaluation's samples carry up to this many RAW events each ([n,4] float32, "
                    "as the reference's dataset loads them without a pre-processed file) instead of voxel grids; the input pipeline voxelises them on the device")
     p.add_argument("--eval-distinct", type=int, default=None, help="distinct samples of the evaluation's synthetic set (default: 16 per rank)")
+    p.add_argument("--no-staggered-warmup", action="store_true", help="N > 1: every rank runs its first forward (MIOpen's solver search) at once "
+                   "instead of rank 0 first and the others behind a barrier")
     p.add_argument("--share-gpu", action="store_true", help=argparse.SUPPRESS)  # tests: all ranks on the visible GPU(s), collective on gloo
     p.add_argument("--backend", choices=["nccl", "gloo", "none"], default="nccl",
                    help="process-group backend; nccl is RCCL.  A single rank joins a world-size-1 nccl group as well, so the one "
@@ -199,6 +208,48 @@ def knn_microbench(dev, iters=30):
             "us_per_launch_lowest_index_ties": round(us_index, 1),  # the same search without the libstdc++ restatement of equal distances
             "frac_lowest_index_ties": round(pairs * (2 * D + 3) / us_index / 1e6 / MFMA_F32_PEAK_TFLOPS, 4),
             "workload": "k_nearest_neighbor 3-D, 8 x (8192 -> 4096), k = 16, fp32, indices as torch.topk returns them"}
+
+
+def pointconv_microbench(dev, iters=40):
+    """The largest in-scope THROUGHPUT kernel of the step: FlowEstimator3D's first PointConv at pyramid level 1
+    (pwc3d_core.py:123,140 -> pointconv.py:100-119): B = 4, N = 4096, k = 16, 195 + 3 input channels -> 128, one launch of
+    pointconv_fused_kernel<1,2,4,2,1> (gather, weight net, the 16 x 198 weighted sums, nn.Linear 3168 -> 128, bias, activation).
+    Flops per launch = SURVEY 8(d)'s PointConv formula (rpeflow_amd.roofline.pointconv_flops); the rows and the neighbour table
+    are prepared outside the timed launches, which are that one kernel and nothing else."""
+    from rpeflow_amd import pointconv as PC
+    from rpeflow_amd import roofline
+    import rpeflow_amd.csrc as ops
+    B, N, C, Cout, k = 4, 4096, 195, 128, 16
+    g = torch.Generator(device="cpu").manual_seed(0)
+    xyz = (torch.rand(B, 3, N, generator=g) * 30).to(dev)
+    feat = torch.randn(B, C, N, generator=g).to(dev)
+    torch.manual_seed(0)
+    layer = PC.PointConvNoSampling(C, Cout, norm=None, k=k).to(dev).eval()
+    with torch.no_grad():
+        knn = ops.k_nearest_neighbor(xyz, xyz, k)
+        rows = PC.pack_rows(xyz, feat)
+        for _ in range(10):
+            layer(xyz, rows, knn)
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            layer(xyz, rows, knn)
+        e.record()
+        torch.cuda.synchronize()
+    us = s.elapsed_time(e) / iters * 1e3
+    flops = roofline.pointconv_flops(B, N, C, Cout, k)
+    alg = roofline.pointconv(B, N, N, C, Cout, False)
+    tflops = flops / us / 1e6
+    traffic, source = pmc_traffic("pointconv_pmc.json")
+    return {"kernel": "pointconv_fused_kernel<1,2,4,2,1> (PointConvNoSampling 195 -> 128 over 4 x 4096 points, k = 16: FlowEstimator3D.point_conv1 at pyramid level 1)",
+            "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": source, "us_per_launch": round(us, 1), "launches_per_step": 1,
+            "algorithmic_flops": flops, "algorithmic_bytes": alg, "hbm_GBs": round(alg / us / 1e3, 1),
+            "note": "the largest in-scope throughput kernel of the step (rocprof: 180 us a launch, two launches a step with its 128 -> 128 twin), "
+                    "timed here by HIP events over %d back-to-back launches of that kernel alone.  fp32 MFMA (v_mfma_f32_16x16x4_f32) against the "
+                    "dense fp32 matrix peak; arithmetic intensity %.0f flop/B, far right of the ridge.  The step's longest single kernel, "
+                    "furthest-point sampling, is latency-bound and reported as roofline_fps" % (iters, flops / alg)}
 
 
 usable_cores = runtime.usable_cores  # affinity mask capped by the cgroup CPU quota (the GPU box grants 16 of 256 cores)
@@ -334,7 +385,11 @@ def launch_ranks(n_ranks, argv):
         port = sock.getsockname()[1]
     procs = []
     for r in range(n_ranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # LOCAL_WORLD_SIZE: all ranks are on this node and share its cores -- runtime.configure() in the child gives each its
+        # share of OpenMP threads (this process's own OMP_NUM_THREADS, chosen for a single rank, carries the marker that lets
+        # the child re-derive it) and rpeflow_amd.evaluate.default_workers() its share of loader threads
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT))
     worst = 0
     while procs:
@@ -484,14 +539,31 @@ def main():
     # mapping from depends on what was captured before.
     epe_delta, dt, launch, step_clock = None, None, None, None
     eval_info = None
+    startup = {"imports_s": round(T_IMPORTED - T_PROCESS, 2)}  # this rank's way to its first step, seconds since its process started
     if args.workload in ("forward", "eval"):
         from rpeflow_amd.model import RPEFlow
         from rpeflow_amd.synthetic import load_seeded_parameters
         # (eval_withocc.py:159 sets cudnn.benchmark; measured here it buys <1 % and costs minutes of MIOpen search per process)
         model = load_seeded_parameters(RPEFlow()).to(dev).eval()  # the parameters of the committed model goldens
         batch = make_batch(args.batch, dev, first_seed=cfg["first_seed"] + rank * args.batch, H=H, W=W, dsec=cfg["dsec"])
-        for _ in range(max(args.warmup, 1)):
+        startup["model_and_batch_s"] = round(time.perf_counter() - T_PROCESS, 2)
+        # The first forward of a process runs MIOpen's solver search for every convolution shape and writes what it TIMED to the
+        # user's find database (~/.config/miopen), which every rank of the node shares.  Rank 0 goes first, alone; the others wait
+        # at a barrier and then read its results instead of searching: one search per node instead of one per rank (22.5 s to the
+        # first step with eight ranks searching at once on a fresh box), every rank on the same solvers, and no search timed while
+        # other ranks load the machine -- with eight ranks sharing ONE GPU (--share-gpu) the contended timings picked solvers that
+        # left the database 10 % slower for every later process on the box (16.6 instead of 15.0 ms per step, measured).
+        staggered = dist is not None and world > 1 and not args.no_staggered_warmup
+        if staggered and rank != 0:
+            dist.barrier()
+            startup["waited_for_rank0_s"] = round(time.perf_counter() - T_PROCESS, 2)
+        for i in range(max(args.warmup, 1)):
             out = model(batch)
+            if i == 0:  # HIP module loads + the solver search (rank 0) or the database reads (the others)
+                sync()
+                startup["first_step_s"] = round(time.perf_counter() - T_PROCESS, 2)
+                if staggered and rank == 0:
+                    dist.barrier()
         sync()
         assert torch.isfinite(out["flow_2d"]).all() and torch.isfinite(out["flow_3d"]).all(), "non-finite flow"
         fwd_step, launch, forward = (lambda: model(batch)), "eager", None
@@ -507,6 +579,7 @@ def main():
             forward = GraphedForward(model, warmup=0, ahead=not args.no_ahead)
             out = forward(batch, batch)  # capture + first replay (graph upload); announces the same batch again: steady state
             sync()
+            startup["graph_captured_s"] = round(time.perf_counter() - T_PROCESS, 2)
             entry = forward.entries[forward._key(batch)]
             fwd_step, launch = entry["graph"].replay, "one HIP graph per forward" + (
                 "" if args.no_ahead else "; furthest-point sampling runs one batch ahead (the next batch's FPS inside this graph)")
@@ -571,16 +644,27 @@ def main():
 
     totals = timer.totals_ms()
     line = None
+    startups = [startup]
+    if dist is not None and world > 1:  # every rank's start-up account, for rank 0's line
+        startups = [None] * world
+        dist.all_gather_object(startups, startup)
     if rank == 0:
         pairs = args.batch * args.steps * world
         alg = roofline.hotpath_bytes(args.batch, wl.sizes, NPTS)
-        table, sum_b, sum_ms = {}, 0, 0.0
+        alg_flops = roofline.hotpath_flops(args.batch, wl.sizes, NPTS)
+        table, sum_b, sum_f, sum_ms, sum_floor, sum_ms_tp, sum_floor_tp = {}, 0, 0, 0.0, 0.0, 0.0, 0.0
         for k, (ms, n) in sorted(totals.items(), key=lambda kv: -kv[1][0]):
             ms_step = ms / args.steps
-            b = alg.get(k, 0)
-            table[k] = {"ms": round(ms_step, 3), "algorithmic_MB": round(b / 1e6, 2),
-                        "frac": round(b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_step > 0 else None}
-            sum_b, sum_ms = sum_b + b, sum_ms + ms_step
+            b, f = alg.get(k, 0), alg_flops.get(k, 0)
+            floor_s, bound = roofline.floor_seconds(b, f)
+            latency = k in roofline.LATENCY_BOUND
+            table[k] = {"ms": round(ms_step, 3), "algorithmic_MB": round(b / 1e6, 2), "algorithmic_GFLOP": round(f / 1e9, 3),
+                        "bound": "latency" if latency else bound, "floor_ms": round(floor_s * 1e3, 4),
+                        "frac": round(floor_s / (ms_step * 1e-3), 4) if ms_step > 0 else None,
+                        "hbm_frac": round(b / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_step > 0 else None}
+            sum_b, sum_f, sum_ms, sum_floor = sum_b + b, sum_f + f, sum_ms + ms_step, sum_floor + floor_s
+            if not latency:
+                sum_ms_tp, sum_floor_tp = sum_ms_tp + ms_step, sum_floor_tp + floor_s
         fps_us = totals["fps+pyramid"][0] / totals["fps+pyramid"][1] * 1e3
         fps_bytes = roofline.fps(2 * args.batch, NPTS, 4096)
         line = {
@@ -600,24 +684,37 @@ def main():
                        "sharding": f"frame pairs over {world} rank(s), no data-path collective",
                        "launch": launch, "runtime": RUNTIME,
                        "process_group": ("%s, world size %d" % (args.backend, world)) if dist is not None else "none"},
-            "roofline": {"kernel": "fps_pruned2_kernel (furthest_point_sampling, 2B clouds 8192 -> 4096)", "bound": "latency",
-                         "achieved": round(fps_bytes / fps_us / 1e3, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(fps_bytes / fps_us / 1e3 / HBM_PEAK_GBS, 6), "algorithmic_bytes": fps_bytes,
-                         "traffic": pmc_traffic("fps_pmc.json")[0], "traffic_source": pmc_traffic("fps_pmc.json")[1],
-                         "us_per_launch": round(fps_us, 1), "launches_per_step": 1,
-                         "us_per_iteration": round(fps_us / 4095, 4), "iteration_sync_floor_us": 0.41,
-                         "note": "the dominant single kernel of the step.  FPS is 4095 DEPENDENT sampling iterations per cloud "
-                                 "(SURVEY.md 8d), one workgroup per cloud: bound by the per-iteration reduce-barrier-broadcast latency, "
-                                 "not by HBM or MFMA -- the HBM fraction is reported for form; compare us_per_iteration with "
-                                 "iteration_sync_floor_us (DESIGN.md 4.3).  roofline_corr is the bandwidth-bound kernel, "
-                                 "hotpath.roofline_frac the whole hot path"},
+            "roofline": pointconv_microbench(dev),
+            "roofline_fps": {"kernel": "fps_pruned2_kernel (furthest_point_sampling, 2B clouds 8192 -> 4096)", "bound": "latency",
+                             "achieved": round(fps_bytes / fps_us / 1e3, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(fps_bytes / fps_us / 1e3 / HBM_PEAK_GBS, 6), "algorithmic_bytes": fps_bytes,
+                             "traffic": pmc_traffic("fps_pmc.json")[0], "traffic_source": pmc_traffic("fps_pmc.json")[1],
+                             "us_per_launch": round(fps_us, 1), "launches_per_step": 1,
+                             "us_per_iteration": round(fps_us / 4095, 4), "iteration_sync_floor_us": 0.41,
+                             "frac_of_sync_floor": round(0.41 / (fps_us / 4095), 4),
+                             "note": "the step's longest single kernel.  FPS is 4095 DEPENDENT sampling iterations per cloud (SURVEY.md 8d), one "
+                                     "workgroup per cloud: bound by the per-iteration reduce-barrier-broadcast latency, not by HBM or MFMA -- the HBM "
+                                     "fraction is reported for form; the figure of merit is us_per_iteration against iteration_sync_floor_us "
+                                     "(DESIGN.md 4.3).  In the replayed forward it runs one batch ahead on its own stream, off the critical path"},
             "hotpath": {"frame_pairs_per_s": round(pairs / dt_hot, 3), "ms_per_step": round(dt_hot / args.steps * 1e3, 3),
-                        "roofline_frac": round(sum_b / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                        "algorithmic_bytes": sum_b, "kernel_ms": round(sum_ms, 3), "categories": table,
-                        "note": "the hot-path operator sequence of one forward alone (rpeflow_amd/hotpath.py), timed in this run with "
-                                "HIP events per category; roofline_frac = sum of algorithmic bytes (rpeflow_amd/roofline.py, SURVEY.md "
-                                "8d) / sum of category durations / 8 TB/s"},
+                        "roofline_frac": round(sum_floor / (sum_ms * 1e-3), 5),
+                        "roofline_frac_throughput_categories": round(sum_floor_tp / (sum_ms_tp * 1e-3), 5),
+                        "hbm_frac": round(sum_b / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "algorithmic_bytes": sum_b, "algorithmic_flops": sum_f, "floor_ms": round(sum_floor * 1e3, 4),
+                        "kernel_ms": round(sum_ms, 3), "categories": table,
+                        "note": "the hot-path operator sequence of one forward alone (rpeflow_amd/hotpath.py), timed in this run with HIP events "
+                                "per category.  Every category is priced at its roofline floor max(algorithmic bytes / 8 TB/s, algorithmic flops "
+                                "/ 157.3 TFLOP/s fp32 matrix peak) (rpeflow_amd/roofline.py = SURVEY.md 8d; `bound` says which side sets it; "
+                                "flops are the reference formulation's -- the binned nearest-pixel search evaluates far fewer pairs than the "
+                                "exhaustive B*Q*M it is priced at); frac = floor / measured.  roofline_frac = sum of floors / sum of durations "
+                                "over all categories; roofline_frac_throughput_categories leaves out the latency-bound furthest-point sampling "
+                                "(4095 dependent iterations, roofline_fps); hbm_frac is the bytes-only figure earlier rounds printed"},
         }
+        line["startup"] = {
+            "time_to_first_step_s": max(s.get("first_step_s", 0.0) for s in startups) or None,
+            "per_rank": startups,
+            "note": "seconds from the start of each rank's process: imports done, model and batch on the device, first forward finished "
+                    "(HIP module loads + MIOpen's solver search, cold user database on a fresh box), HIP graph captured"}
         if step_clock is not None:
             # what the device's own counters say about the K timed steps: a slow line with the usual cycles per step is a clock
             # (power / thermal / a neighbour on the node), one with more cycles is work or stalls

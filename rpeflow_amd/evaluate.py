@@ -219,9 +219,8 @@ def default_workers():
     most 4, at least ``RPE_MIN_LOADER_THREADS`` (default 1).  A batch is 0.2 GB of memcpy: one thread stages ~70 batches/s
     when eight ranks share a 16-core quota (tools/host_rehearsal.py) -- the main and the copy thread of a rank are mostly
     asleep, so the loaders may use the rank's whole share."""
-    from .runtime import usable_cores
-    local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    return max(int(os.environ.get("RPE_MIN_LOADER_THREADS", "1")), min(4, usable_cores() // max(1, local)))
+    from .runtime import cores_per_rank
+    return max(int(os.environ.get("RPE_MIN_LOADER_THREADS", "1")), min(4, cores_per_rank()))
 
 
 @torch.no_grad()
@@ -296,6 +295,24 @@ def evaluate(model, dataset, batch_size, device, rank=0, world_size=1, group=Non
     return finalize(acc), acc
 
 
+def first_forward_in_turn(step, rank, group=None):
+    """Runs ``step()`` -- a process's FIRST forward -- on rank 0 alone, then on the other ranks of ``group`` together.
+    The first forward runs MIOpen's solver search for every convolution shape and writes what it timed to the user's find
+    database, which the ranks of a node share: in turn, the node searches once instead of once per rank, every rank ends up on
+    the same solvers, and no search is timed while the other ranks load the machine (bench.py: 22.5 s to the first step with
+    eight ranks searching at once; eight ranks timing their searches on one shared GPU left a database 10 % slower)."""
+    import torch.distributed as dist
+    together = group is not None and dist.get_world_size(group) > 1
+    if together and rank != 0:
+        dist.barrier(group)
+    out = step()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if together and rank == 0:
+        dist.barrier(group)
+    return out
+
+
 def main():
     p = argparse.ArgumentParser(description="Sharded synthetic evaluation (one process per GPU; launch with torchrun for N > 1)")
     p.add_argument("--samples", type=int, default=8)
@@ -332,6 +349,10 @@ def main():
     data = SyntheticPairs(args.samples, args.height, args.width, args.points, dsec=args.dsec, events=args.raw_events)
     # The model's ~200 k long-lived Python objects leave the collector's sight: a full collection of them is a 40-70 ms host
     # pause (measured in bench.py), and the loop below runs one or two replays ahead of the device at most.
+    mine = shard_indices(len(data), rank, world)
+    if not args.raw_events:  # the first forward (solver search) rank by rank, on this rank's first batch (an empty shard: just the barrier)
+        first = to_device(collate([data[i] for i in mine[:args.batch]]), device) if mine else None
+        first_forward_in_turn((lambda: model(first)) if mine else (lambda: None), rank, group)
     gc.collect()
     gc.freeze()
     t0 = time.perf_counter()

@@ -125,10 +125,12 @@ class InputPipeline:
         # compute stream waits on the copy stream's), hipGraphLaunch on the compute stream blocks its caller for 20-30 ms two
         # launches out of three (ROCm 7.2, measured); the host-side wait costs nothing: the event is three batches old.
         self.sync_release = os.environ.get("RPE_PIPE_SYNC_RELEASE", "host")
+        self.poll_s = float(os.environ.get("RPE_PIPE_POLL_MS", "0.25")) * 1e-3
         self.depth = max(self.depth, int(os.environ.get("RPE_PIPE_DEPTH", self.depth)))
         # diagnostic (tools/host_rehearsal.py: N ranks sharing ONE PCIe link): move only this fraction of every tensor to the device
         self.copy_fraction = float(os.environ.get("RPE_PIPE_COPY_FRACTION", "1"))
         self.stats = {"batches": 0, "bytes": 0, "direct": 0}
+        self._account_lock = threading.Lock()
         self.trace = [] if os.environ.get("RPE_EVAL_TIMELINE") else None  # (batch, copy begin / end events, host time of issue)
         self._threads, self._stop, self._error = [], threading.Event(), None
 
@@ -167,10 +169,14 @@ class InputPipeline:
     def _worker(self):
         """One task = one SAMPLE of a batch (the first batch is resident after one sample's load time, not four).  Tasks and
         host slots are handed out in batch order under one lock: the copier's next batch can never starve for a slot."""
+        from .runtime import name_thread
+        name_thread("rpe-load")
+        t_cpu = time.thread_time()
         try:
             while True:
                 with self._next_lock:
                     if self._next >= len(self._tasks):
+                        self._account("rpe-load", t_cpu)
                         return
                     j, n = self._tasks[self._next]
                     self._next += 1
@@ -230,10 +236,16 @@ class InputPipeline:
 
     # ------------------------------------------------------------------ stage 2: host batches -> device batches, in order
     def _copier(self):
+        from .runtime import name_thread
+        name_thread("rpe-copy")
+        t_cpu = time.thread_time()
         try:
             if self.cuda:
                 torch.cuda.set_device(self.device)
-            for j in range(len(self.batches)):
+            for j in range(len(self.batches) + 1):
+                if j == len(self.batches):
+                    self._account("rpe-copy", t_cpu)
+                    break
                 with self._filled_cv:
                     while j not in self._filled:
                         if self._stop.is_set():
@@ -246,7 +258,16 @@ class InputPipeline:
                     continue
                 dev, released = _get(self._free_dev, self._stop)
                 if released is not None and self.sync_release == "host":
-                    released.synchronize()  # the consumer's last kernel that read this device batch (host-side wait: see __init__)
+                    # the consumer's last kernel that read this device batch (host-side wait: see __init__).  Polled, not
+                    # hipEventSynchronize: the host runs several replays ahead of the device, so this thread waits here most of
+                    # every batch, and the runtime's wait SPINS -- a whole core per rank (0.94 measured, blocking-sync events
+                    # included).  A batch is 15 ms; a 0.25 ms poll is nothing against the two batches of slack the ring holds.
+                    while not released.query():
+                        if self._stop.is_set():
+                            raise _Stop
+                        time.sleep(self.poll_s)
+                elif released is not None and self.sync_release == "spin":
+                    released.synchronize()
                 with torch.cuda.stream(self._copy_stream):
                     if released is not None and self.sync_release != "host":
                         self._copy_stream.wait_event(released)
@@ -300,6 +321,12 @@ class InputPipeline:
             pass
         except BaseException as e:  # noqa: BLE001
             self._fail(e)
+
+    def _account(self, name, since):
+        """CPU seconds a pipeline thread used (it ends with the pipeline: nobody can read /proc for it afterwards)."""
+        with self._account_lock:
+            used = self.stats.setdefault("thread_cpu_s", {})
+            used[name] = used.get(name, 0.0) + time.thread_time() - since
 
     def _fail(self, e):
         self._error = e

@@ -28,6 +28,49 @@ def usable_cores():
     return n
 
 
+def local_world_size():
+    """Ranks that share this node's cores: LOCAL_WORLD_SIZE (torchrun, bench.py's own launcher), else WORLD_SIZE, else 1."""
+    try:
+        return max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+    except ValueError:
+        return 1
+
+
+def cores_per_rank():
+    """This rank's share of the usable cores (>= 1): what its OpenMP team and its loader threads may count on."""
+    return max(1, usable_cores() // local_world_size())
+
+
+OMP_MARK = "RPE_OMP_NUM_THREADS_BY_CONFIGURE"  # set beside OMP_NUM_THREADS when configure() chose it: a launcher re-derives it per rank
+
+
+def name_thread(name):
+    """Name the calling thread for top -H / /proc/<pid>/task/*/comm (15 characters): the pipeline's threads can then be told
+    from the runtime's in a per-thread CPU account (tools/host_rehearsal.py)."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).prctl(15, name.encode()[:15], 0, 0, 0)  # PR_SET_NAME
+    except (OSError, AttributeError):
+        pass
+
+
+def thread_cpu_seconds():
+    """{(tid, name): user + system CPU seconds} of every thread of this process (/proc/self/task)."""
+    out, tick = {}, os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                stat = open("/proc/self/task/%s/stat" % tid).read()
+                name = stat[stat.index("(") + 1:stat.rindex(")")]
+                fields = stat[stat.rindex(")") + 2:].split()
+                out[(int(tid), name)] = (int(fields[11]) + int(fields[12])) / tick  # utime, stime
+            except (OSError, ValueError):
+                pass
+    except OSError:
+        pass
+    return out
+
+
 def configure():
     """Idempotent; an explicit setting in the environment wins.  Returns what is in effect (bench.py prints it in ``config``).
     The MIOpen convolution solvers are left at the library's defaults everywhere -- tests, bench and evaluation alike.  The
@@ -36,11 +79,14 @@ def configure():
     whatever MIOpen's timing-based search picks for the rest."""
     os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", GRAPH_QUEUES)
     # PyTorch sizes its OpenMP teams by the HOST's core count; inside a CPU quota that oversubscribes every host-side
-    # tensor op (collate, Tensor.copy_) and gets the whole process throttled.  Read when OpenMP initialises.
-    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
+    # tensor op (collate, Tensor.copy_) and gets the whole process throttled.  Read when OpenMP initialises.  The ranks of
+    # a node share the quota: each gets usable cores / LOCAL_WORLD_SIZE (eight ranks x 16 threads on 16 cores otherwise).
+    if "OMP_NUM_THREADS" not in os.environ or os.environ.get(OMP_MARK) == "1":
+        os.environ["OMP_NUM_THREADS"] = str(cores_per_rank())
+        os.environ[OMP_MARK] = "1"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # multi-process GPU work on this driver needs dmabuf IPC
     out = {"DEBUG_HIP_FORCE_GRAPH_QUEUES": os.environ["DEBUG_HIP_FORCE_GRAPH_QUEUES"], "OMP_NUM_THREADS": os.environ["OMP_NUM_THREADS"],
-           "miopen_solvers": "library defaults"}
+           "usable_cores": usable_cores(), "local_world_size": local_world_size(), "miopen_solvers": "library defaults"}
     import sys
     torch = sys.modules.get("torch")
     if torch is not None:  # imported before this call (python -m rpeflow_amd.evaluate, an embedder): libgomp has read the

@@ -39,6 +39,9 @@ sys.path.insert(0, ROOT)
 def child(args):
     from rpeflow_amd import runtime
     runtime.configure()
+    # a thread inherits the name of the thread that creates it: the main thread carries the name of the phase it is in, so the
+    # per-thread CPU account below says which phase a library's helper thread was born in ("at-import", "at-gloo", "at-hip", ...)
+    runtime.name_thread("at-import")
     import torch
     import torch.distributed as dist
     from rpeflow_amd import evaluate as E
@@ -46,7 +49,9 @@ def child(args):
     from rpeflow_amd.synthetic import SyntheticPairs
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.set_num_threads(max(1, runtime.usable_cores() // world))
+    runtime.name_thread("at-gloo")
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    runtime.name_thread("at-hip")
     real = args.real_rank is not None and rank == args.real_rank
     # host-only neighbours of a real rank may stay off the GPU altogether (--neighbours cpu): eight processes on ONE device share
     # its hardware queues, which a node with a GPU per rank does not
@@ -56,6 +61,7 @@ def child(args):
         torch.cuda.set_device(dev)
     if args.real_rank is not None:
         # the real rank's own world-size-1 nccl group (new_group is collective over the default group: every rank calls it)
+        runtime.name_thread("at-nccl")
         solo = dist.new_group(ranks=[args.real_rank], backend="nccl") if args.device == "cuda" else None
     if real:
         return real_child(args, rank, world, dev, solo, dist)
@@ -107,6 +113,7 @@ def real_child(args, rank, world, dev, solo, dist):
     from rpeflow_amd import runtime
     from rpeflow_amd.model import RPEFlow
     from rpeflow_amd.synthetic import SyntheticPairs, load_seeded_parameters
+    runtime.name_thread("at-model")
     model = load_seeded_parameters(RPEFlow()).to(dev).eval()
     forward = E.GraphedForward(model)
     n = args.batches * args.batch
@@ -115,20 +122,36 @@ def real_child(args, rank, world, dev, solo, dist):
     workers = E.default_workers() if args.workers is None else args.workers
     warm = SyntheticPairs(3 * args.batch, args.height, args.width, 8192, distinct=args.distinct, first_seed=1000 + rank * args.distinct)
     warm.cache = data.cache
+    runtime.name_thread("at-warm-up")
     E.evaluate(model, warm, args.batch, dev, 0, 1, group=solo, forward=forward, workers=workers)  # capture, MIOpen search, rings: untimed
     torch.cuda.synchronize()
     dist.barrier()  # everyone's set is generated, this rank's graph is captured: the host-only ranks warm their pipelines up now
     dist.barrier()  # the start line
     forward.host_times = []
     stats = {"timeline": True}  # device time per batch: forward, metric sums, and the gap before the next batch's first launch
+    runtime.name_thread("rpe-main")
+    threads0 = runtime.thread_cpu_seconds()
     t0, c0 = time.perf_counter(), time.process_time()
     metrics, _ = E.evaluate(model, data, args.batch, dev, 0, 1, group=solo, forward=forward, workers=workers, stats=stats)
     torch.cuda.synchronize()
     dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+    # where the cores go: CPU seconds per thread over the timed evaluation (threads that ended inside it -- the pipeline's own --
+    # are read by the pipeline when it closes: stats["thread_cpu_s"])
+    by_thread = {}
+    for (tid, name), sec in runtime.thread_cpu_seconds().items():
+        used = sec - threads0.get((tid, name), 0.0)
+        if used > 0:
+            by_thread[name] = by_thread.get(name, 0.0) + used
+    for name, sec in stats.get("thread_cpu_s", {}).items():
+        by_thread[name] = by_thread.get(name, 0.0) + sec
+    cores_by_thread = {k: round(v / dt, 3) for k, v in sorted(by_thread.items(), key=lambda kv: -kv[1]) if v / dt >= 0.005}
+    busiest = sorted(((sec - threads0.get(key, 0.0), key) for key, sec in runtime.thread_cpu_seconds().items()), reverse=True)[:6]
+    busiest = [{"tid": key[0], "born": key[1], "cores": round(used / dt, 3)} for used, key in busiest if used / dt >= 0.005]
     launch = sorted(forward.host_times)
     pct = lambda q: round(launch[min(len(launch) - 1, int(q * len(launch)))] * 1e3, 3) if launch else None
     out = {"rank": rank, "real": True, "batches_per_s": round(args.batches / dt, 2), "ms_per_batch": round(dt / args.batches * 1e3, 3),
-           "cpu_s_per_batch": round(cpu / args.batches, 5), "cores_in_use": round(cpu / dt, 2), "loader_threads": stats.get("workers", workers),
+           "cpu_s_per_batch": round(cpu / args.batches, 5), "cores_in_use": round(cpu / dt, 2), "cores_by_thread": cores_by_thread, "busiest_surviving_threads": busiest,
+           "loader_threads": stats.get("workers", workers),
            "h2d_MB_per_batch": round(stats["bytes"] / max(1, stats["batches"]) / 1e6, 1), "hipGraphLaunch_host_ms": {"p50": pct(0.5), "p99": pct(0.99), "max": pct(1.0)},
            "device_ms_per_batch": {k: stats.get("timeline_ms", {}).get(k) for k in ("forward", "accumulate", "gap", "host_loop")},
            "collective": "world-size-1 nccl group" if solo is not None else "none", "epe2d": metrics["EPE2D"], "generator_s_untimed": round(t_gen, 2)}
