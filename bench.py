@@ -87,7 +87,10 @@ def parse():
                         "all-reduce), a step = one batch per rank; selftest: the rank launcher and timing protocol alone, on CPU tensors")
     p.add_argument("--eval-batches", type=int, default=64, help="batches per rank of the 'eval' leg that the forward workload reports as well (0: skip)")
     p.add_argument("--eval-workers", type=int, default=None, help="loader threads per rank (default: rpeflow_amd.evaluate.default_workers())")
-    p.add_argument("--eval-pinned", action="store_true", help="hold the cached synthetic set in pinned memory (no staging pass)")
+    p.add_argument("--eval-pinned", action="store_true", help="(the default since round 6; kept for old command lines)")
+    p.add_argument("--eval-pageable", action="store_true", help="hold the evaluation's cached synthetic set in pageable memory: loader threads then "
+                   "stage every sample into the pinned ring (1.2 cores a rank at 60 batches/s; the default keeps the cached set pinned -- what "
+                   "a registered / memory-mapped set or a dataset with load_into() gives -- and the H2D copies start from where the samples lie)")
     p.add_argument("--eval-raw-events", type=int, default=0, help="the evaluation's samples carry up to this many RAW events each ([n,4] float32, "
                    "as the reference's dataset loads them without a pre-processed file) instead of voxel grids; the input pipeline voxelises them on the device")
     p.add_argument("--eval-distinct", type=int, default=None, help="distinct samples of the evaluation's synthetic set (default: 16 per rank)")
@@ -615,7 +618,7 @@ def main():
         n_eval = args.steps if args.workload == "eval" else args.eval_batches
         if forward is not None and n_eval > 0:
             dt_eval, eval_info = eval_leg(model, forward, dev, cfg, args.batch, n_eval, rank, world, dist, workers=args.eval_workers,
-                                          pinned=args.eval_pinned, backend=args.backend, distinct=args.eval_distinct, raw_events=args.eval_raw_events)
+                                          pinned=not args.eval_pageable, backend=args.backend, distinct=args.eval_distinct, raw_events=args.eval_raw_events)
             if args.workload == "eval":
                 dt = dt_eval
             else:

@@ -31,13 +31,16 @@
 extern "C" {
 #endif
 
-#define RPE_ABI_VERSION 8
+#define RPE_ABI_VERSION 9
 
 #define RPE_EINVAL (-1)       /* bad size / null pointer */
 #define RPE_EUNSUPPORTED (-2) /* valid request this build has no kernel for */
 
 typedef void *rpe_stream_t; /* a hipStream_t; NULL = the legacy default stream */
 
+/* RPE_ABI_VERSION in the lower 16 bits.  The upper 16 are 0 in every library that computes right results; a diagnostic build
+ * whose kernels drop work on purpose (energy probes, tools/corr_energy_probes.sh) reports its variant there, and
+ * rpeflow_amd/_lib.py refuses to load it unless RPE_ALLOW_DIAGNOSTIC_LIB=1 says the caller expects one. */
 int rpe_abi_version(void);
 const char *rpe_error_string(int code);
 
@@ -204,6 +207,9 @@ int rpe_knn_interpolate(const float *in_xyz, int64_t x_sb, int64_t x_sd, int64_t
  * around its two grid_sample_wrapper calls (RPEFlow_core.py:105-111) rides in the launch:
  *   scale_even / scale_odd  every tap of an even / odd channel of the source is multiplied as it is read, fl(tap * s): sampling
  *                           "flow_2d * (sx, sy)" (:103-104) without that tensor; 1, 1 for a plain source;
+ *   div_even / div_odd      (ABI 9) != 1: the product is then DIVIDED, fl(fl(tap * s) / d) -- the reference writes
+ *                           "flow * (sensor_w - 1) / (image_w - 1)", a multiply and a divide, two roundings; with s = the numerator
+ *                           and d = the denominator the taps carry the reference's bits (a single multiply by s / d can be an ulp off);
  *   subtract                NULL, or [B, channels, P] through strides: taken off the source's samples (":110  -= flow_3d[:, :2]").
  * Coordinates xy[b][d][p] = xy[b*xy_sb + d*xy_sd + p*xy_sp], d=0:x, 1:y.
  * add_pixel_grid=1, border=1, P=H*W: backwarp_2d(map, flow=xy, 'border').
@@ -215,6 +221,7 @@ typedef struct {
     int64_t sb, sc;
     int channels;
     float scale_even, scale_odd;
+    float div_even, div_odd;
     const float *subtract;
     int64_t sub_sb, sub_sc, sub_sp;
 } rpe_sample_source;
@@ -280,13 +287,14 @@ int rpe_ids_flow_inverse(const float *xyz, int64_t x_sb, int64_t x_sc, int64_t x
  *   2-D flow") and `append` [B, n_append, H*W] is copied behind the C3 + 3 channels (the cat with the event features):
  *   out [B, C3 + 3 + n_append, H, W].  Either may be NULL with a count of 0.
  * feat_3d as two tensors, C3 = C3a + C3b: channels [0, C3a) from feat_3d, [C3a, C3) from feat_3d_b (NULL with C3b = 0), whose
- *   even / odd channels are multiplied by scale_even / scale_odd as they are read -- the 2-D correlation fuser projects
- *   [3-D cost volume | xy of the 3-D flow in feature-map units] (RPEFlow_core.py:371-373: two in-place muls and a cat there).  */
+ *   even / odd channels are multiplied by scale_even / scale_odd and, where div_even / div_odd != 1, then divided by them as they
+ *   are read, fl(fl(v * s) / d) -- the 2-D correlation fuser projects [3-D cost volume | xy of the 3-D flow in feature-map units]
+ *   (RPEFlow_core.py:363-366, 371-373: "flow * (image_w - 1) / (sensor_w - 1)", a multiply, a divide and a cat there).  */
 int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_sd, int64_t xy_sn, const float *feat_2d, int C2,
                              int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
                              const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3a,
                              const float *feat_3d_b, int64_t g3_sb, int64_t g3_sc, int64_t g3_sn, int C3b,
-                             float scale_even, float scale_odd,
+                             float scale_even, float scale_odd, float div_even, float div_odd,
                              const int64_t *nn_idx, const float *subtract, int n_subtract, const float *append, int n_append,
                              int B, int N, float *workspace, float *out, rpe_stream_t stream);
 
@@ -457,8 +465,8 @@ int rpe_eval_accumulate(const float *flow2d, const float *target2d, int target2d
  *   tools/stamp_timeline.py), the kernel is the marker tools/trace_window.py looks for.  The cycle counters of two stamps must
  *   NOT be subtracted: they may come from different XCDs / shader engines, whose counters are not one clock.
  * rpe_clock_stamp_all: the same pair of counters stored per COMPUTE UNIT -- slots[2 key], slots[2 key + 1], key = XCC_ID << 8 |
- *   HW_ID[15:8] (shader engine, array, CU), 2048 keys: `slots` is 4096 values, zeroed by the caller; 8192 one-wave workgroups
- *   cover the chip.  Two of these bracket a stretch of the stream; for every key both reached, d(cycles) / d(ticks) x the
+ *   HW_ID[15:8] (shader engine, array, CU), 2048 keys: `slots` is 4096 values, 16-byte aligned, zeroed by the caller (a pair is ONE
+ *   16-byte store: both counters of a slot come from one wave); 8192 one-wave workgroups cover the chip.  Two of these bracket a stretch of the stream; for every key both reached, d(cycles) / d(ticks) x the
  *   constant rate = the clock that compute unit ran at (rpeflow_amd.runtime.ShaderClock takes the median; bench.py's
  *   roofline_corr carries it).  wall_khz (host pointer, may be NULL): that rate on the current device
  *   (hipDeviceAttributeWallClockRate).                                                                              */

@@ -67,7 +67,7 @@ _PROTOTYPES = {
                            _c_float, _c_float, _c_float, _c_float, _c_ptr, _c_ptr],
     "rpe_project_feat_nn_corr": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64,
                                  _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_ptr, _c_i64, _c_i64, _c_i64, _c_int, _c_float, _c_float,
-                                 _c_ptr, _c_ptr, _c_int, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
+                                 _c_float, _c_float, _c_ptr, _c_ptr, _c_int, _c_ptr, _c_int, _c_int, _c_int, _c_ptr, _c_ptr, _c_ptr],
     "rpe_pointconv_pack_rows": [_c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_int, _c_int, _c_int, _c_int, _c_ptr, _c_ptr],
     "rpe_pointconv_fused": [_c_ptr, _c_int, _c_int, _c_ptr, _c_i64, _c_ptr, _c_i64, _c_i64, _c_i64, _c_ptr, _c_ptr, _c_ptr, _c_ptr,
                             _c_float, _c_ptr, _c_int, _c_ptr, _c_ptr, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -83,7 +83,7 @@ _PROTOTYPES = {
 }
 
 _lib = None
-ABI_VERSION = 8  # RPE_ABI_VERSION of include/rpeflow_hip.h
+ABI_VERSION = 9  # RPE_ABI_VERSION of include/rpeflow_hip.h
 KNN_TIES = {"torch": 3, "set": 1, "index": 0}  # RPE_KNN_TIES_* (how equal distances are resolved)
 KNN_ALGO = {"auto": 0, "sweep": 0x100, "binned": 0x200, "matrix": 0x400, "insert": 0x800}  # RPE_KNN_ALGO_* (OR-ed into the mode)
 # entry points only a library built with -DRPE_EXPERIMENTAL has (python -m rpeflow_amd.build --experimental)
@@ -93,7 +93,8 @@ _EXPERIMENTAL = {"rpe_probe_mfma4x4": [_c_ptr, _c_ptr]}
 class SampleSource(ctypes.Structure):
     """rpe_sample_source of include/rpeflow_hip.h."""
     _fields_ = [("data", ctypes.c_void_p), ("sb", ctypes.c_int64), ("sc", ctypes.c_int64), ("channels", ctypes.c_int),
-                ("scale_even", ctypes.c_float), ("scale_odd", ctypes.c_float), ("subtract", ctypes.c_void_p),
+                ("scale_even", ctypes.c_float), ("scale_odd", ctypes.c_float), ("div_even", ctypes.c_float), ("div_odd", ctypes.c_float),
+                ("subtract", ctypes.c_void_p),
                 ("sub_sb", ctypes.c_int64), ("sub_sc", ctypes.c_int64), ("sub_sp", ctypes.c_int64)]
 
 
@@ -127,8 +128,12 @@ def lib():
                 getattr(handle, name).argtypes, getattr(handle, name).restype = argtypes, _c_int
         handle.rpe_error_string.argtypes = [_c_int]
         handle.rpe_error_string.restype = ctypes.c_char_p
-        if handle.rpe_abi_version() != ABI_VERSION:
-            raise RuntimeError("librpeflow_hip.so: ABI version mismatch")
+        version = handle.rpe_abi_version()
+        if version >> 16 and os.environ.get("RPE_ALLOW_DIAGNOSTIC_LIB") != "1":
+            raise RuntimeError(f"{LIB_PATH} is a DIAGNOSTIC build (variant {version >> 16}): its kernels compute wrong results on purpose "
+                               "(tools/corr_energy_probes.sh).  Unset RPE_HIP_LIB, or set RPE_ALLOW_DIAGNOSTIC_LIB=1 for a timing run")
+        if version & 0xffff != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH}: ABI version {version & 0xffff}, this package binds version {ABI_VERSION}")
         _lib = handle
     return _lib
 

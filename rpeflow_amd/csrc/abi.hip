@@ -1,7 +1,8 @@
 // ABI bookkeeping for librpeflow_hip.so.
 #include "common.h"
 
-RPE_API int rpe_abi_version(void) { return RPE_ABI_VERSION; }
+// lower 16 bits: RPE_ABI_VERSION; upper 16: non-zero only in a diagnostic build that computes wrong results on purpose
+RPE_API int rpe_abi_version(void) { return RPE_ABI_VERSION | (rpe_diagnostic_flavour() << 16); }
 
 RPE_API const char *rpe_error_string(int code) {
     if (code == 0) return "success";
@@ -31,8 +32,12 @@ __global__ __launch_bounds__(64) void clock_stamp_all_kernel(unsigned long long 
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     const unsigned key = ((xcc & 7u) << 8) | ((hw >> 8) & 0xffu);  // HW_ID[15:8]: CU_ID, SH_ID, SE_ID
-    slots[2 * key] = clock64();
-    slots[2 * key + 1] = wall_clock64();
+    // many of the 8192 workgroups land on one compute unit: the pair goes out as ONE 16-byte store, so a slot always holds
+    // the two counters of one wave (two 8-byte stores of different waves could interleave)
+    ulonglong2 pair;
+    pair.x = clock64();
+    pair.y = wall_clock64();
+    *reinterpret_cast<ulonglong2 *>(slots + 2 * key) = pair;
 }
 }  // namespace
 
@@ -43,7 +48,7 @@ RPE_API int rpe_clock_stamp(unsigned long long *slot2, rpe_stream_t stream) {
 }
 
 RPE_API int rpe_clock_stamp_all(unsigned long long *slots, int *wall_khz, rpe_stream_t stream) {
-    if (!slots) return RPE_EINVAL;
+    if (!slots || (reinterpret_cast<uintptr_t>(slots) & 15)) return RPE_EINVAL;  // (16-byte stores)
     if (wall_khz) {
         int device = 0;
         hipError_t e = hipGetDevice(&device);

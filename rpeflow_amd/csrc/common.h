@@ -18,6 +18,18 @@ static inline int rpe_launch_status() {
 // fmaxf(x, 0) returns 0 for both; the reference's evaluation masks NaN predictions (eval_withocc.py:86-87), so a NaN has to
 // reach the output as one.
 __device__ __forceinline__ float rpe_relu(float x) { return x < 0.f ? 0.f : x; }
+// 0 in the library that ships; the number of the diagnostic variant in a build that computes WRONG results on purpose
+// (correlation.hip under -DRPE_CORR_PROBE=1|2, tools/corr_energy_probes.sh).  rpe_abi_version() carries it in its upper half,
+// and the loader refuses such a library unless told to expect one (rpeflow_amd/_lib.py).
+int rpe_diagnostic_flavour();
+
+// fl(fl(x * s) / d): "x * num / den" as the reference's tensor expression rounds it (a multiply, then a true division:
+// -fhip-fp32-correctly-rounded-divide-sqrt is hipcc's default and the build adds no fast-math flag); d == 1 skips the division,
+// whose result would be the product itself.
+__device__ __forceinline__ float rpe_scaled(float x, float s, float d) {
+    const float p = x * s;
+    return d == 1.f ? p : p / d;
+}
 __device__ __forceinline__ int rpe_lane() { return (int)(threadIdx.x & (RPE_WAVE - 1)); }
 
 // wave-uniform value -> scalar register

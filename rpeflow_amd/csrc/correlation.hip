@@ -28,13 +28,16 @@
 
 #include "common.h"
 
-namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 #ifndef RPE_CORR_PROBE
 #define RPE_CORR_PROBE 0  // 1, 2: diagnostic builds that drop part of corr_mfma_dma_kernel's work (tools/corr_energy_probes.sh), never shipped
 #endif
+// (not exported: rpe_abi_version() reports it, so that a library whose correlation kernel computes wrong results on purpose
+// cannot be loaded by accident through a leaked RPE_HIP_LIB; the ring-depth probes 3-5 compute right results and report 0)
+int rpe_diagnostic_flavour() { return (RPE_CORR_PROBE == 1 || RPE_CORR_PROBE == 2) ? RPE_CORR_PROBE : 0; }
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void corr_direct_kernel(const float *__restrict__ in1, const float *__restrict__ in2,
                                                           int C, int H, int W, int md, float slope,

@@ -129,10 +129,11 @@ struct Bilinear {
         acc = acc + v_se * w_se;
         return acc;
     }
-    // the same on the map (plane * scale): every tap rounded once more, as reading the caller's scaled tensor would
-    __device__ __forceinline__ float sample_scaled(const float *plane, float scale) const {
-        const float v_nw = o_nw >= 0 ? plane[o_nw] * scale : 0.f, v_ne = o_ne >= 0 ? plane[o_ne] * scale : 0.f;
-        const float v_sw = o_sw >= 0 ? plane[o_sw] * scale : 0.f, v_se = o_se >= 0 ? plane[o_se] * scale : 0.f;
+    // the same on the map (plane * scale / div): every tap rounded once (twice with a divisor) more, as reading the caller's
+    // "x * num / den" tensor would (RPEFlow_core.py:367-370)
+    __device__ __forceinline__ float sample_scaled(const float *plane, float scale, float div) const {
+        const float v_nw = o_nw >= 0 ? rpe_scaled(plane[o_nw], scale, div) : 0.f, v_ne = o_ne >= 0 ? rpe_scaled(plane[o_ne], scale, div) : 0.f;
+        const float v_sw = o_sw >= 0 ? rpe_scaled(plane[o_sw], scale, div) : 0.f, v_se = o_se >= 0 ? rpe_scaled(plane[o_se], scale, div) : 0.f;
         float acc = v_nw * w_nw + v_ne * w_ne;
         acc = acc + v_sw * w_sw;
         acc = acc + v_se * w_se;
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(SampleSources S, int C, i
         const rpe_sample_source &src = S.src[si];
         const int ce = min(c1, S.first[si + 1]);
         const float *base = src.data + (int64_t)b * src.sb + (int64_t)(c - S.first[si]) * src.sc;
-        const bool plain = src.scale_even == 1.0f && src.scale_odd == 1.0f && !src.subtract;
+        const bool plain = src.scale_even == 1.0f && src.scale_odd == 1.0f && src.div_even == 1.0f && src.div_odd == 1.0f && !src.subtract;
         if (plain) {
             // four channels per trip: 16 independent gathered loads in flight instead of 4
             for (; c + 4 <= ce; c += 4, base += 4 * src.sc) {
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(SampleSources S, int C, i
         } else {
             for (; c < ce; ++c, base += src.sc) {
                 const int lc = c - S.first[si];
-                float v = bl.sample_scaled(base, (lc & 1) ? src.scale_odd : src.scale_even);
+                float v = bl.sample_scaled(base, (lc & 1) ? src.scale_odd : src.scale_even, (lc & 1) ? src.div_odd : src.div_even);
                 if (src.subtract) v = v - src.subtract[(int64_t)b * src.sub_sb + (int64_t)lc * src.sub_sc + (int64_t)p * src.sub_sp];
                 out[((int64_t)b * C + c) * P + p] = v;
             }
@@ -296,11 +297,11 @@ struct Feat3 {
     int Ca;
     const float *b;
     int64_t b_sb, b_sc, b_sn;
-    float s_even, s_odd;
+    float s_even, s_odd, d_even, d_odd;
     __device__ __forceinline__ float at(int batch, int c, int i) const {
         if (c < Ca) return a[(int64_t)batch * a_sb + (int64_t)c * a_sc + (int64_t)i * a_sn];
         const int lc = c - Ca;
-        return b[(int64_t)batch * b_sb + (int64_t)lc * b_sc + (int64_t)i * b_sn] * ((lc & 1) ? s_odd : s_even);
+        return rpe_scaled(b[(int64_t)batch * b_sb + (int64_t)lc * b_sc + (int64_t)i * b_sn], (lc & 1) ? s_odd : s_even, (lc & 1) ? d_odd : d_even);
     }
 };
 
@@ -810,13 +811,13 @@ RPE_API int rpe_project_feat_nn_corr(const float *xy, int64_t xy_sb, int64_t xy_
                                            int H, int W, const float *sampled_2d, int64_t sm_sb, int64_t sm_sc, int64_t sm_sn,
                                            const float *feat_3d, int64_t f3_sb, int64_t f3_sc, int64_t f3_sn, int C3a,
                                            const float *feat_3d_b, int64_t g3_sb, int64_t g3_sc, int64_t g3_sn, int C3b, float scale_even,
-                                           float scale_odd, const int64_t *nn_idx, const float *subtract, int n_subtract, const float *append,
+                                           float scale_odd, float div_even, float div_odd, const int64_t *nn_idx, const float *subtract, int n_subtract, const float *append,
                                            int n_append, int B, int N, float *workspace, float *out, rpe_stream_t stream) {
     const int C3 = C3a + C3b;
     if (!xy || !feat_2d || !nn_idx || !out || !workspace || B < 0 || C2 < 1 || C3a < 0 || C3b < 0 || H < 1 || W < 1 || N < 1 ||
         (C3a > 0 && !feat_3d) || (C3b > 0 && !feat_3d_b))
         return RPE_EINVAL;
-    const Feat3 F3{feat_3d, f3_sb, f3_sc, f3_sn, C3a, feat_3d_b, g3_sb, g3_sc, g3_sn, scale_even, scale_odd};
+    const Feat3 F3{feat_3d, f3_sb, f3_sc, f3_sn, C3a, feat_3d_b, g3_sb, g3_sc, g3_sn, scale_even, scale_odd, div_even, div_odd};
     if (n_subtract < 0 || n_subtract > C3 || n_append < 0 || (n_subtract > 0 && !subtract) || (n_append > 0 && !append)) return RPE_EINVAL;
     if (reinterpret_cast<uintptr_t>(workspace) & 15) return RPE_EINVAL;
     if (B == 0) return 0;

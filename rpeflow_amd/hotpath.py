@@ -253,11 +253,11 @@ class HotPathWorkload(torch.nn.Module):
 
             if shares:
                 with t.span("grid_sample"):  # corr fuser 3D (:376; RPEFlow_core.py:103-111 in one launch)
-                    to_sensor = ((sw - 1) / (w - 1), (sh - 1) / (h - 1))  # the 2-D flow in sensor units (:103-104)
+                    to_sensor = ((sw - 1, w - 1), (sh - 1, h - 1))  # the 2-D flow in sensor units: "* (sensor_w - 1) / (image_w - 1)", two roundings (:367-370)
                     sampled = grid_sample_sources([(corr_2d, None, None), (self.flow_2d[level], to_sensor, last_flow_3d[:, :2]), (ef_2d, None, None)], xy1)
                 with t.span("project_feat"):  # corr fuser 2D (:371-373, :82-83)
                     project_feat_with_nn_corr(xy1, corr_2d, corr_3d, nn_proj1[..., 0], sampled_2d=sampled[:, :corr_2d.shape[1]],
-                                              feat_3d_tail=last_flow_3d[:, :2], tail_scale=self.scale_xy[level])
+                                              feat_3d_tail=last_flow_3d[:, :2], tail_scale=((w - 1, sw - 1), (h - 1, sh - 1)))
             else:
                 with t.span("grid_sample"):  # corr fuser 3D (:376; utils via RPEFlow_core.py:107-108)
                     sampled = grid_sample_wrapper(torch.cat([corr_2d, self.flow_2d[level]], 1), xy1)

@@ -186,18 +186,23 @@ class InputPipeline:
                             busy.synchronize()  # the H2D that last read this slot
                         self._open[j] = {"slot": slot, "left": len(self.batches[j]), "samples": [None] * len(self.batches[j])}
                     rec = self._open[j]
-                sample = self._sample(self.batches[j][n])
-                if "events" in sample:
-                    self._check_events(sample["events"])
-                if rec["slot"] is None:  # pinned samples: copied from where they lie
-                    rec["samples"][n] = sample
+                index = self.batches[j][n]
+                if rec["slot"] is not None and self._load_into is not None and not (self._first is not None and self._first[0] == index):
+                    # the dataset decodes / reads STRAIGHT into the pinned host batch: no sample tensor, no staging copy
+                    self._load_into(index, {k: v[n] for k, v in rec["slot"].items()})
                 else:
-                    for k, v in sample.items():
-                        if k == "events":  # ragged: the first count rows of the slot's [max_events, 4]
-                            _memcpy(rec["slot"][k][n][:v.shape[0]], v)
-                            rec["slot"]["event_count"][n] = v.shape[0]
-                        else:
-                            _memcpy(rec["slot"][k][n], v)
+                    sample = self._sample(index)
+                    if "events" in sample:
+                        self._check_events(sample["events"])
+                    if rec["slot"] is None:  # pinned samples: copied from where they lie
+                        rec["samples"][n] = sample
+                    else:
+                        for k, v in sample.items():
+                            if k == "events":  # ragged: the first count rows of the slot's [max_events, 4]
+                                _memcpy(rec["slot"][k][n][:v.shape[0]], v)
+                                rec["slot"]["event_count"][n] = v.shape[0]
+                            else:
+                                _memcpy(rec["slot"][k][n], v)
                 with self._filled_cv:
                     rec["left"] -= 1
                     if rec["left"] == 0:
@@ -342,6 +347,11 @@ class InputPipeline:
         first = self.dataset[self.batches[0][0]]  # defines keys, shapes and dtypes
         self._first = (self.batches[0][0], first)
         self._direct = self.cuda and not self.processes and all(v.is_pinned() for v in first.values())
+        # ``dataset.load_into(i, out)`` (optional): fill ``out`` -- {key: the sample's place in a host batch, pinned on a GPU run}
+        # -- with sample i.  A dataset that reads or decodes (np.load, h5py read_direct, an image decoder with an output
+        # buffer) does so straight into the batch the H2D copy starts from; __getitem__ + memcpy costs a rank a core at 60
+        # batches/s of 206 MB (tools/host_rehearsal.py --real-rank 0: 1.2 cores in the loader threads)
+        self._load_into = None if (self.processes or self._direct or "events" in first) else getattr(self.dataset, "load_into", None)
         no_host_ring = self._direct or (self.processes and not self.cuda)
         host_like = dev_like = first
         if "events" in first:

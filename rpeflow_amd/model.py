@@ -332,8 +332,9 @@ class CorrFeatureFuser2D(nn.Module):
         self.fuse = CrossTransformerBlock2D(dim=in_channels_2d, num_heads=num_heads)
 
     def forward(self, xy, feat_2d, feat_3d, efeat_2d, last_flow_2d, last_flow_3d_to_2d, nn_proj, flow_3d_scale=None):
-        """``flow_3d_scale`` (sx, sy): ``last_flow_3d_to_2d`` is the 3-D flow's xy still in sensor units and the product with
-        (sx, sy) (RPEFlow_core.py:371-372) as well as the cat with ``feat_3d`` (:373) happen as the projection kernel reads them."""
+        """``flow_3d_scale`` ((num_x, den_x), (num_y, den_y)): ``last_flow_3d_to_2d`` is the 3-D flow's xy still in sensor units; the
+        conversion "* (image_w - 1) / (sensor_w - 1)" (RPEFlow_core.py:363-366) with the reference's two roundings as well as the
+        cat with ``feat_3d`` (:373) happen as the projection kernel reads them."""
         project = self._ops.project_feat_with_nn_corr
         if feat_2d.is_cuda and project is native_project_feat_with_nn_corr:
             # also "-= last_flow_2d" on the projected flow (RPEFlow_core.py:82) and the cat with the event features (:83) inside the launch
@@ -341,7 +342,7 @@ class CorrFeatureFuser2D(nn.Module):
             both = project(xy, feat_2d, feat_3d, nn_proj[..., 0], subtract_last=last_flow_2d, append=efeat_2d, **tail)
         else:
             if flow_3d_scale is not None:
-                last_flow_3d_to_2d = last_flow_3d_to_2d * _pair_scale(flow_3d_scale[0], flow_3d_scale[1], last_flow_3d_to_2d)
+                last_flow_3d_to_2d = _scaled_pair(last_flow_3d_to_2d, flow_3d_scale)
             feat_3d = torch.cat([feat_3d, last_flow_3d_to_2d], dim=1)
             feat_3d_to_2d = project(xy, feat_2d, feat_3d, nn_proj[..., 0])
             feat_3d_to_2d[:, -2:] -= last_flow_2d  # RPEFlow_core.py:82
@@ -361,14 +362,14 @@ class CorrFeatureFuser3D(nn.Module):
         self.fuse = CrossTransformerBlock3D(dim=in_channels_3d, num_heads=num_heads)
 
     def forward(self, xy, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d, last_flow_2d_to_3d, flow_2d_scale=None):
-        """``flow_2d_scale`` (sx, sy): ``last_flow_2d_to_3d`` is the 2-D flow still in feature-map units; its product with (sx, sy)
-        (RPEFlow_core.py:103-104), both samplings, the subtraction (:110) and both concatenations (:105, :111) are ONE launch."""
+        """``flow_2d_scale`` ((num_x, den_x), (num_y, den_y)): ``last_flow_2d_to_3d`` is the 2-D flow still in feature-map units; its
+        conversion "* (sensor_w - 1) / (image_w - 1)" (RPEFlow_core.py:367-370, two roundings), both samplings, the subtraction (:110) and both concatenations (:105, :111) are ONE launch."""
         if feat_corr_2d.is_cuda and self._ops.grid_sample_wrapper is native_grid_sample_wrapper:
             both = grid_sample_sources([(feat_corr_2d, None, None), (last_flow_2d_to_3d, flow_2d_scale, last_flow_3d[:, :2]),
                                         (efeat_2d, None, None)], xy)
             return self.fuse(feat_corr_3d, run_chain(self.mlps, both))
         if flow_2d_scale is not None:
-            last_flow_2d_to_3d = last_flow_2d_to_3d * _pair_scale(flow_2d_scale[0], flow_2d_scale[1], last_flow_2d_to_3d)
+            last_flow_2d_to_3d = _scaled_pair(last_flow_2d_to_3d, flow_2d_scale)
         feat_2d_to_3d = self._ops.grid_sample_wrapper(torch.cat([feat_corr_2d, last_flow_2d_to_3d], dim=1), xy)
         efeat_2d_to_3d = self._ops.grid_sample_wrapper(efeat_2d, xy)
         feat_2d_to_3d[:, -2:] -= last_flow_3d[:, :2]  # RPEFlow_core.py:110
@@ -468,6 +469,14 @@ def convex_upsample(flow, mask, scale_factor=8):
 _pair_scale_cache = {}
 
 
+def _scaled_pair(x, scale):
+    """x[:, 0] * num_x / den_x, x[:, 1] * num_y / den_y for ``scale`` = ((num_x, den_x), (num_y, den_y)) -- the reference's
+    "flow * (image_w - 1) / (sensor_w - 1)" (RPEFlow_core.py:363-370): a multiply, then a divide, each rounded; what the native
+    kernels do as they read the flow (rpe_scaled)."""
+    (nx, dx), (ny, dy) = scale
+    return x * _pair_scale(nx, ny, x) / _pair_scale(dx, dy, x)
+
+
 def _pair_scale(a, b, like):
     """[1,2,1(,1)] tensor (a, b) on like's device, cached: x[:, :2] * _pair_scale(...) scales the two flow channels by
     different factors in one launch.  (Created on the first, eager forward; graph capture then finds it resident.)"""
@@ -547,11 +556,24 @@ class _Branches:
 
 
 class RPEFlow_core(nn.Module):
+    def constants_intact(self):
+        """True while every cached constant of decode() and of the point-cloud pyramid still holds the value it was made with
+        (nobody wrote through a shared tensor).  Cheap enough for a test or a debugging assertion, one sync."""
+        from . import pwc3d_core
+        return all(int(z.count_nonzero()) == 0 for z in self._zeros.values()) and pwc3d_core.constants_intact()
+
+    def clear_constants(self):
+        """Drop the cached constants (they are rebuilt on the next forward).  Graphs captured before still hold theirs."""
+        from . import pwc3d_core
+        self._zeros.clear()
+        pwc3d_core.clear_constants()
+
     def __init__(self, cfgs2d, cfgs3d, cfgsattention=None, ops=None):
         super().__init__()
         self.cfgs2d, self.cfgs3d = cfgs2d, cfgs3d
+        self._native_ops = ops is None  # (a caller's own operators get fresh tensors where the native ones share constants)
         self.ops = ops = ops or native_ops()
-        self._zeros = {}  # constant zero tensors of decode(), by shape
+        self._zeros = {}  # constant zero tensors of decode(), by (shape, dtype, device, inference mode)
         FeaturePyramid3D, Correlation3D, FlowEstimator3D = ops.FeaturePyramid3D, ops.Correlation3D, ops.FlowEstimator3D
         corr_ch = (2 * cfgs2d.max_displacement + 1) ** 2
         event_bins = cfgs2d.event_bins * 2 if cfgs2d.event_polarity else cfgs2d.event_bins
@@ -695,9 +717,12 @@ class RPEFlow_core(nn.Module):
 
         def zeros(*shape):
             """The coarsest level's "previous" flows (RPEFlow_core.py:341-344): constant tensors, made once per shape -- every
-            consumer reads them (residual / subtrahend / gather source), none writes."""
+            NATIVE consumer reads them (residual / subtrahend / gather source), none writes; ``constants_intact()`` checks it.
+            Operators passed in by the caller (``ops=``) get a fresh tensor every time: nothing is known about what they write."""
             like = feats_2d_both[1]
-            key = (shape, like.dtype, like.device)
+            if not self._native_ops:
+                return torch.zeros(shape, dtype=like.dtype, device=like.device)
+            key = (shape, like.dtype, like.device, torch.is_inference_mode_enabled())  # (an inference tensor cannot serve a later autograd pass)
             if key not in self._zeros:
                 z = torch.zeros(shape, dtype=like.dtype, device=like.device)
                 if like.is_cuda and torch.cuda.is_current_stream_capturing():
@@ -782,7 +807,7 @@ class RPEFlow_core(nn.Module):
             def chain_3d():
                 # (the 2-D flow in sensor units, :103-104, exists only as the sampling kernel reads it)
                 corr_3d_fused = self.corr_feat_fusers_3d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_3d, last_flow_2d,
-                                                                flow_2d_scale=((sensor_w - 1) / (image_w - 1), (sensor_h - 1) / (image_h - 1)))
+                                                                flow_2d_scale=((sensor_w - 1, image_w - 1), (sensor_h - 1, image_h - 1)))
                 x_3d = [self.correlation_aligners_3d[level](corr_3d_fused), aligned_3d, last_flow_3d, last_flow_feat_3d]
                 if not isinstance(self.flow_estimator_3d, NativeFlowEstimator3D):  # (the native one concatenates while packing)
                     x_3d = torch.cat(x_3d, dim=1)
@@ -792,7 +817,7 @@ class RPEFlow_core(nn.Module):
 
             out_3d = br.fork(chain_3d, [feat_corr_2d, efeat_2d, last_flow_2d])
             corr_2d_fused = self.corr_feat_fusers_2d[level](xy1, feat_corr_2d, feat_corr_3d, efeat_2d, last_flow_2d, last_flow_3d[:, :2], nn_proj1,
-                                                            flow_3d_scale=(sx, sy))
+                                                            flow_3d_scale=((image_w - 1, sensor_w - 1), (image_h - 1, sensor_h - 1)))
             x_2d = torch.cat([corr_2d_fused, aligned_2d, aligned_e2d, last_flow_2d, last_flow_feat_2d], dim=1)
             flow_feat_2d_raw = self.flow_estimator_2d(x_2d)
             _stamp("main L%d stage2 done" % level)

@@ -30,7 +30,7 @@ def build_pc_pyramid(pc1, pc2, n_samples_list, sample_index_both=None, return_bo
         sample_index_both = furthest_point_sampling(pc_both.transpose(1, 2), max(n_samples_list))
     sample_index1, sample_index2 = sample_index_both[:batch_size], sample_index_both[batch_size:]
 
-    key = (batch_size, n_points, pc1.device)
+    key = (batch_size, n_points, pc1.device, torch.is_inference_mode_enabled())
     lv0_index = _LEVEL0_INDEX.get(key)
     if lv0_index is None:  # a constant: made once (kept only when made outside a stream capture, whose memory belongs to the graph)
         lv0_index = torch.arange(n_points, device=pc1.device)[None, :].expand(batch_size, n_points)
@@ -49,6 +49,23 @@ def build_pc_pyramid(pc1, pc2, n_samples_list, sample_index_both=None, return_bo
     if return_both:
         return xyzs1, xyzs2, sample_indices1, sample_indices2, both
     return xyzs1, xyzs2, sample_indices1, sample_indices2
+
+
+def constants_intact():
+    """The cached pyramid constants still hold their values: the level-0 index is 0 .. N-1 in every row (an expanded view --
+    PyTorch refuses in-place writes through it -- handed out in ``sample_indices`` as the reference hands out its own,
+    pwc3d_core.py:17-19), the zero point is zero."""
+    for key, t in _LEVEL0_INDEX.items():
+        if key[0] == "zero point":
+            if int(t.count_nonzero()) != 0:
+                return False
+        elif not torch.equal(t[0], torch.arange(t.shape[1], device=t.device)):
+            return False
+    return True
+
+
+def clear_constants():
+    _LEVEL0_INDEX.clear()
 
 
 def _stacked(a, b):
@@ -80,11 +97,12 @@ class FeaturePyramid3D(nn.Module):
         # level 0: the MLP of an all-zero input (pwc3d_core.py:51-52), i.e. ONE vector for every point (eval-mode BatchNorm
         # is per point): computed on a single point and broadcast -- a stride-0 view the next layer's kernel reads as it is
         if xyzs[0].is_cuda and not self.training and not torch.is_grad_enabled():
-            zero = _LEVEL0_INDEX.get(("zero point", xyzs[0].device))
+            zero_key = ("zero point", xyzs[0].device, xyzs[0].dtype, torch.is_inference_mode_enabled())
+            zero = _LEVEL0_INDEX.get(zero_key)
             if zero is None:  # (a constant, like the level-0 index: kept unless made inside a stream capture)
                 zero = xyzs[0].new_zeros((1, 3, 1))
                 if not torch.cuda.is_current_stream_capturing():
-                    _LEVEL0_INDEX[("zero point", xyzs[0].device)] = zero
+                    _LEVEL0_INDEX[zero_key] = zero
             feats = [self.level0_mlp(zero).expand(xyzs[0].shape[0], -1, xyzs[0].shape[2])]
         else:
             feats = [self.level0_mlp(torch.zeros_like(xyzs[0]))]

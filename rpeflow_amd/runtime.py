@@ -135,6 +135,7 @@ class ShaderClock:
             _lib.check(_lib.lib().rpe_clock_stamp_all(self.slots[i].data_ptr(), ctypes.byref(self.khz), _lib.stream_of(self.slots)), "clock_stamp_all")
 
     def __enter__(self):
+        self.slots.zero_()  # a reused object must not keep a first stamp for a compute unit this use does not reach
         self._stamp(0)
         return self
 

@@ -109,8 +109,11 @@ def pointwise_conv(x, weight, bias=None, stride=1, residual=None, inplace=False,
     if bias is not None:  # (an epilogue's shift already contains the block's bias: callers pass one or the other)
         shift = bias if shift is None else shift + (bias if scale is None else bias * scale)
     if x.is_cuda and 2.0 * B * P * C * cout <= _PW_MAX_FLOPS:
-        # a channel slice of a wider tensor (samples dense, batch stride larger) is read / added where it lies
-        dense = lambda t, c: t.stride(2) == 1 and t.stride(1) == P and t.stride(0) >= c * P
+        # a channel slice of a wider tensor (samples dense, batch stride larger) is read / added where it lies.  PyTorch's
+        # stride of a size-1 dimension is arbitrary (B == 1, one channel, one position): such a dimension is not looked at,
+        # and the batch stride handed to the kernel is the dense one then
+        dense = lambda t, c: (P == 1 or t.stride(2) == 1) and (c == 1 or t.stride(1) == P) and (B == 1 or t.stride(0) >= c * P)
+        batch_stride = lambda t, c: t.stride(0) if B > 1 else c * P
         xf = _f32(xf)
         if not dense(xf, C):
             xf = xf.contiguous()
@@ -121,9 +124,9 @@ def pointwise_conv(x, weight, bias=None, stride=1, residual=None, inplace=False,
                 res = res.contiguous()
         reuse = inplace and res is not None and res.is_contiguous() and res.data_ptr() == residual.data_ptr()
         out = res if reuse else torch.empty((B, cout, P), dtype=torch.float32, device=x.device)
-        _launch(xf, "pointwise_conv", _lib.lib().rpe_pointwise_conv, _ptr(xf), xf.stride(0), B, C, P, _ptr(_pw_packed_weight(weight)), 0, cout,
+        _launch(xf, "pointwise_conv", _lib.lib().rpe_pointwise_conv, _ptr(xf), batch_stride(xf, C), B, C, P, _ptr(_pw_packed_weight(weight)), 0, cout,
                 _ptr(scale) if scale is not None else _NULL, _ptr(shift.contiguous()) if shift is not None else _NULL,
-                _ACT_CODE[kind], 0.1, _ptr(res) if res is not None else _NULL, res.stride(0) if res is not None else 0, _ptr(out))
+                _ACT_CODE[kind], 0.1, _ptr(res) if res is not None else _NULL, batch_stride(res, cout) if res is not None else 0, _ptr(out))
         return out.reshape((B, cout) + tuple(spatial))
     w = weight.reshape(cout, -1)
     wb = w.unsqueeze(0).expand(B, -1, -1)  # batch stride 0: one strided-batched GEMM, the weight read once per sample from L2
@@ -548,8 +551,18 @@ def mesh_grid(n, h, w, device, channel_first=True):
     return mesh_grid_cache[key]
 
 
+def _num_den(factor):
+    """A scale factor as (multiplier, divisor): a number s -> (s, 1); a pair (num, den) stays -- fl(fl(x * num) / den), the two
+    roundings of the reference's "x * num / den" (RPEFlow_core.py:363-370)."""
+    if isinstance(factor, (tuple, list)):
+        num, den = factor
+        return float(num), float(den)
+    return float(factor), 1.0
+
+
 def _sample(sources, B, H, W, xy_ptr, xy_strides, P, add_grid, border, like):
-    """rpe_bilinear_sample over ``sources`` = [(map [B,C,H,W], (scale_even, scale_odd) or None, subtract [B,C,P] or None), ...]."""
+    """rpe_bilinear_sample over ``sources`` = [(map [B,C,H,W], (scale_even, scale_odd) or None, subtract [B,C,P] or None), ...];
+    a scale is a number or a (numerator, denominator) pair (``_num_den``)."""
     assert 1 <= len(sources) <= 4
     table, keep, C = (_lib.SampleSource * len(sources))(), [], 0
     for i, (m, scale, sub) in enumerate(sources):
@@ -557,13 +570,13 @@ def _sample(sources, B, H, W, xy_ptr, xy_strides, P, add_grid, border, like):
         assert m.dim() == 4 and m.shape[0] == B and tuple(m.shape[2:]) == (H, W)
         if m.stride(3) != 1 or m.stride(2) != W:
             m = m.contiguous()
-        se, so = (1.0, 1.0) if scale is None else (float(scale[0]), float(scale[1]))
+        (se, de), (so, do) = ((1.0, 1.0), (1.0, 1.0)) if scale is None else (_num_den(scale[0]), _num_den(scale[1]))
         sub_args = (None, 0, 0, 0)
         if sub is not None:
             sub = _f32(sub)
             assert sub.shape == (B, m.shape[1], P)
             sub_args = (sub.data_ptr(), *sub.stride())
-        table[i] = _lib.SampleSource(m.data_ptr(), m.stride(0), m.stride(1), m.shape[1], se, so, *sub_args)
+        table[i] = _lib.SampleSource(m.data_ptr(), m.stride(0), m.stride(1), m.shape[1], se, so, de, do, *sub_args)
         keep += [m, sub]
         C += m.shape[1]
     out = torch.empty((B, C, P), dtype=torch.float32, device=like.device)
@@ -638,7 +651,8 @@ def grid_sample_wrapper(feat_2d, xy):
 def grid_sample_sources(sources, xy):
     """grid_sample_wrapper(torch.cat([m * scale ...], dim=1), xy) - torch.cat([subtract ...], dim=1) in ONE launch, without the
     concatenated map: ``sources`` = [(map [B,C_i,H,W], scale, subtract), ...] (at most four maps of one size); ``scale`` None or
-    (even-channel factor, odd-channel factor) applied to the map's values as they are read; ``subtract`` None or [B,C_i,N],
+    (even-channel factor, odd-channel factor) applied to the map's values as they are read, each factor a number or a
+    (numerator, denominator) pair -- "x * num / den" with the reference's two roundings; ``subtract`` None or [B,C_i,N],
     taken off that map's samples.  What the 3-D correlation fuser does around its two calls (RPEFlow_core.py:103-111)."""
     first = sources[0][0]
     _lib.require_gpu(first, xy, op="grid_sample_wrapper")
@@ -681,7 +695,8 @@ def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=
     fuser of the same (map, points) pair computes it anyway; the per-point bilinear taps are then not repeated.
     ``subtract_last`` [B,n,H,W]: subtracted from the last n projected channels; ``append`` [B,m,H,W]: concatenated behind the
     result (-> [B,C3+3+m,H,W]) -- the two steps the 2-D correlation fuser puts behind this call (RPEFlow_core.py:82-83), inside
-    the second launch.  ``feat_3d_tail`` [B,Ct,N] with ``tail_scale`` = (even-channel factor, odd-channel factor): feat_3d is
+    the second launch.  ``feat_3d_tail`` [B,Ct,N] with ``tail_scale`` = (even-channel factor, odd-channel factor; each a number or a
+    (numerator, denominator) pair: fl(fl(x * num) / den), the reference's "x * (image_w - 1) / (sensor_w - 1)"): feat_3d is
     torch.cat([feat_3d, feat_3d_tail * scale], dim=1) without that tensor (the fuser's [cost volume | flow_3d xy in map units],
     :371-373)."""
     _lib.require_gpu(xy, feat_2d, feat_3d, op="project_feat_with_nn_corr")
@@ -718,7 +733,7 @@ def project_feat_with_nn_corr(xy, feat_2d, feat_3d, nn_indices=None, sampled_2d=
         sm_strides = sampled_2d.stride()
     _launch(feat_2d, "project_feat_with_nn_corr", _lib.lib().rpe_project_feat_nn_corr,
             _ptr(xy), *xy.stride(), _ptr(feat_2d), C2, H, W, _ptr(sampled_2d), *sm_strides, _ptr(feat_3d), *feat_3d.stride(), C3a,
-            *tail_args, C3b, float(tail_scale[0]), float(tail_scale[1]),
+            *tail_args, C3b, _num_den(tail_scale[0])[0], _num_den(tail_scale[1])[0], _num_den(tail_scale[0])[1], _num_den(tail_scale[1])[1],
             _ptr(nn_indices), _ptr(subtract_last), n_sub, _ptr(append), n_app, B, N, _ptr(rows), _ptr(out))
     return out
 

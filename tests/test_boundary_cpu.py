@@ -33,7 +33,7 @@ def exported_symbols():
 def test_library_builds_and_exports_header_symbols():
     """The default library exports EXACTLY what the header declares outside its RPE_EXPERIMENTAL blocks -- no kept experiments
     (round-3 review: ~50 entry points, a dozen dispatched nowhere) -- and a bounded number of entry points (42 since round 5:
-    rpe_project_points and rpe_clock_probe joined; every one is called by the package, next test)."""
+    rpe_project_points and rpe_clock_stamp_all joined; every one is called by the package, next test)."""
     assert not os.environ.get("RPE_EXPERIMENTAL"), "this test checks the default build"
     build.build()
     handle = ctypes.CDLL(_lib.LIB_PATH)
@@ -62,6 +62,27 @@ def test_ctypes_prototypes_cover_the_header():
     assert set(_lib._PROTOTYPES) | {"rpe_error_string"} == set(declared_symbols())
     assert _lib.lib().rpe_abi_version() == _lib.ABI_VERSION
     assert _lib.lib().rpe_error_string(-1).decode().startswith("rpeflow_hip")
+
+
+def test_a_diagnostic_build_cannot_be_loaded_by_accident(tmp_path):
+    """A library whose correlation kernel drops work on purpose (-DRPE_CORR_PROBE=1|2, tools/corr_energy_probes.sh) says so in the
+    upper half of rpe_abi_version(), and the loader refuses it unless RPE_ALLOW_DIAGNOSTIC_LIB=1: a leaked RPE_HIP_LIB cannot
+    put wrong results behind the operators silently.  The shipped library reports 0 there."""
+    import subprocess
+    import sys
+    assert _lib.lib().rpe_abi_version() >> 16 == 0
+    src = os.path.join(ROOT, "rpeflow_amd", "csrc")
+    obj, lib = str(tmp_path / "corr_probe.o"), str(tmp_path / "librpeflow_probe.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", *build.FLAGS, "-DRPE_CORR_PROBE=1", "-I", os.path.join(ROOT, "include"), "-I", src, "-c",
+                    os.path.join(src, "correlation.hip"), "-o", obj], check=True)
+    others = [os.path.join(src, "build", f) for f in os.listdir(os.path.join(src, "build")) if f.endswith(".o") and f != "correlation.o"]
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *others, obj], check=True)
+    code = "from rpeflow_amd import _lib; print(_lib.lib().rpe_abi_version() >> 16)"
+    refused = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RPE_HIP_LIB=lib), capture_output=True, text=True, cwd=ROOT)
+    assert refused.returncode != 0 and "DIAGNOSTIC build" in refused.stderr
+    allowed = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RPE_HIP_LIB=lib, RPE_ALLOW_DIAGNOSTIC_LIB="1"),
+                             capture_output=True, text=True, cwd=ROOT)
+    assert allowed.returncode == 0 and allowed.stdout.strip() == "1"
 
 
 def test_same_public_names_and_signatures_as_reference():

@@ -685,6 +685,40 @@ def test_project_feat_with_a_scaled_tail():
                                                        feat_3d_tail=flow[:, :2], tail_scale=(sx, sy)), ref)
 
 
+def test_flow_unit_conversions_round_as_the_reference_expression():
+    """RPEFlow_core.py:363-370 converts flows between feature-map and sensor units with "flow * (image_w - 1) / (sensor_w - 1)":
+    a multiply THEN a divide, two fp32 roundings.  The native operators take the conversion as (numerator, denominator) and apply
+    fl(fl(x * num) / den) as they read the flow (rpe_scaled): bit for bit the operator on the tensor PyTorch builds from the
+    reference's literal expression -- which one multiply by the precomputed ratio is not (counted below, so the test knows it
+    distinguishes the two)."""
+    g = torch.Generator().manual_seed(17)
+    differs = 0
+    for B, C, H, W, N, sh, sw in [(2, 81, 72, 120, 2048, 18, 30), (1, 7, 9, 15, 256, 18, 30), (3, 16, 64, 80, 1024, 16, 20)]:
+        corr, flow = torch.randn(B, C, H, W, generator=g).to(DEV), (3.0 * torch.randn(B, 2, H, W, generator=g)).to(DEV)
+        xy = (torch.rand(B, 2, N, generator=g) * torch.tensor([W - 1.0, H - 1.0])[None, :, None]).to(DEV)
+        flow_3d = torch.randn(B, 3, N, generator=g).to(DEV)
+        # the 3-D correlation fuser's front (:367-370, :103-111)
+        # (the reference's expression on the CPU, where the parity oracle runs: a true division.  PyTorch's GPU kernel for
+        # tensor / python-scalar multiplies by the reciprocal instead -- a third rounding pattern, not the reference's)
+        cpu = flow.cpu()
+        literal = torch.cat([cpu[:, 0:1] * (sw - 1) / (W - 1), cpu[:, 1:2] * (sh - 1) / (H - 1)], dim=1).to(DEV)
+        single = flow * torch.tensor([(sw - 1) / (W - 1), (sh - 1) / (H - 1)], device=DEV).view(1, 2, 1, 1)
+        differs += int((literal != single).sum())
+        ref = U.grid_sample_wrapper(torch.cat([corr, literal], 1), xy)
+        ref[:, -2:] -= flow_3d[:, :2]
+        got = U.grid_sample_sources([(corr, None, None), (flow, ((sw - 1, W - 1), (sh - 1, H - 1)), flow_3d[:, :2])], xy)
+        assert torch.equal(got, ref)
+        # the 2-D correlation fuser's projected tail (:363-366, :371-373)
+        f3 = torch.randn(B, 12, N, generator=g).to(DEV)
+        nn = torch.randint(0, N, (B, H * W), generator=g).to(DEV)
+        cpu = flow_3d.cpu()
+        tail = torch.cat([cpu[:, 0:1] * (W - 1) / (sw - 1), cpu[:, 1:2] * (H - 1) / (sh - 1)], dim=1).to(DEV)
+        ref = U.project_feat_with_nn_corr(xy, corr, torch.cat([f3, tail], 1), nn)
+        got = U.project_feat_with_nn_corr(xy, corr, f3, nn, feat_3d_tail=flow_3d[:, :2], tail_scale=((W - 1, sw - 1), (H - 1, sh - 1)))
+        assert torch.equal(got, ref)
+    assert differs > 0, "no value distinguishes x * num / den from x * (num / den): the test would prove nothing"
+
+
 def test_pointwise_conv_reads_channel_slices_where_they_lie():
     """conv_module(1x1, x, residual=r) with x and r channel slices of wider tensors (batch stride larger than C P) == the call on
     contiguous copies: the flow heads add the up-sampled flow, a slice of [flow | features] (RPEFlow_core.py:409-410)."""
@@ -698,6 +732,18 @@ def test_pointwise_conv_reads_channel_slices_where_they_lie():
         close(got, (r + conv(x)).cpu().numpy(), 1e-5)
         odd = U.conv_module(conv, wide_x[:, 3:67, :511], residual=wide_r[:, :3, :511])  # not dense per sample: copied, same values
         close(odd, (wide_r[:, :3, :511] + conv(wide_x[:, 3:67, :511])).cpu().numpy(), 1e-5)
+        # one sample: PyTorch's batch stride of a size-1 dimension is arbitrary (here (70 * 512, ...) sliced, then a view whose
+        # batch stride is 1) -- the kernel must get the dense stride, and a channel slice is written in place where it lies
+        one_x, one_r = wide_x[:1, 3:67], wide_r[:1, :3].clone()
+        weird = one_x.as_strided(one_x.shape, (1, 512, 1), one_x.storage_offset())
+        assert torch.equal(weird, one_x) and weird.stride(0) == 1
+        want = U.conv_module(conv, one_x.contiguous(), residual=one_r.contiguous())
+        assert torch.equal(U.conv_module(conv, weird, residual=one_r), want)
+        wide_one = torch.randn(1, 67, 512, device=DEV)
+        slice_r = wide_one[:, 5:8]                      # B == 1: is_contiguous() although it is a slice of a wider tensor
+        want = U.conv_module(conv, one_x, residual=slice_r.clone())
+        got = U.conv_module(conv, one_x, residual=slice_r, inplace=True)
+        assert torch.equal(got, want) and got.data_ptr() == slice_r.data_ptr() and torch.equal(wide_one[:, 5:8], want)
 
 
 @pytest.mark.parametrize("cin", [1, 64])  # one channel group: the plain kernel; 16 groups on a small map: the K-split form

@@ -47,6 +47,30 @@ def test_order_and_contents_do_not_depend_on_the_workers(workers, processes):
     assert pipe.stats["batches"] == 4
 
 
+def test_a_dataset_may_load_straight_into_the_host_batch():
+    """``load_into(i, out)``: the pipeline hands the dataset the sample's place in the (pinned) host batch and copies nothing
+    itself; batches equal the __getitem__ path's, whatever the number of workers."""
+    class Direct(Tiny):
+        def __init__(self, n):
+            super().__init__(n)
+            self.direct, self.lock = [], threading.Lock()
+
+        def load_into(self, i, out):
+            assert set(out) == {"a", "b", "c"} and out["a"].shape == (3, 5) and out["b"].dtype == torch.int64
+            out["a"].fill_(float(i))
+            out["b"].copy_(torch.tensor([i, 2 * i]))
+            out["c"].fill_(i % 251)
+            with self.lock:
+                self.direct.append(i)
+
+    indices = list(range(2, 50, 3))
+    for workers in (1, 3):
+        data = Direct(64)
+        got = [{k: v.clone() for k, v in b.items()} for b in InputPipeline(data, indices, 4, "cpu", workers=workers)]
+        check(got, indices, 4)
+        assert sorted(data.direct) == indices[1:]  # (the first sample was read through __getitem__ to learn keys and shapes)
+
+
 def test_pairs_hands_out_the_next_batch_early_and_recycles_slots():
     indices = list(range(30))
     pipe = InputPipeline(Tiny(30), indices, 4, "cpu", workers=3)

@@ -156,6 +156,32 @@ def test_model_graph_replay_and_single_stream_agree(golden_dir):
         # on the host and therefore cannot be captured; here a loose bound guards against gross errors only)
         assert abs(epe(f2, s["flow_2d"][None, :2]) - epe(g["flow_2d"], s["flow_2d"][None, :2])) < 5e-3
         assert abs(epe(f3, s["flow_3d"][None]) - epe(g["flow_3d"], s["flow_3d"][None])) < 5e-3
+    # the constants the forwards above shared (the coarsest level's zero flows, the level-0 index, the pyramid's zero point)
+    # still hold their values after eager runs on one and two streams, a capture and three replays: nobody wrote through them
+    core = model.pwc_fusion_core
+    assert len(core._zeros) > 0 and core.constants_intact()
+    first = dict(core._zeros)
+    with torch.inference_mode():  # inference tensors are keyed apart: an inference-mode forward must not hand its constants to autograd later
+        model(batch)
+    assert len(core._zeros) > len(first) and all(core._zeros[k] is v for k, v in first.items())
+    core.clear_constants()
+    assert not core._zeros and core.constants_intact()
+    again = model(batch)
+    assert torch.equal(again["flow_3d"], eager["flow_3d"])
+
+
+@pytest.mark.gpu
+@torch.no_grad()
+def test_callers_own_operators_never_see_a_shared_constant():
+    """RPEFlow(ops=...) with a caller's operators: the coarsest level's zero flows are fresh tensors every forward (a port may
+    write into what it is given), so nothing is cached for them."""
+    from rpeflow_amd.hotpath import native_ops
+    from rpeflow_amd.model import RPEFlow
+    model = RPEFlow(ops=native_ops()).eval()   # the same callables, but handed in: treated as a caller's own
+    model.load_state_dict(seeded_state(model), strict=True)
+    model = model.to("cuda:0")
+    out = model(sample_batch("cuda:0"))
+    assert torch.isfinite(out["flow_3d"]).all() and not model.pwc_fusion_core._zeros
 
 
 @pytest.mark.gpu

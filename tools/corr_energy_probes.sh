@@ -25,6 +25,6 @@ for v in "$@"; do
   if [ $v -ge 3 ]; then
     RPE_HIP_LIB=$E/librpeflow_corrp$v.so timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -k "correlation" 2>&1 | tail -2 > $OUT/corr_probe${v}_parity.txt
   fi
-  RPE_HIP_LIB=$E/librpeflow_corrp$v.so timeout 300 python3 tools/corr_clock.py --out $OUT/corr_clock_probe$v.json > $OUT/corr_clock_probe$v.log 2>&1
+  RPE_ALLOW_DIAGNOSTIC_LIB=1 RPE_HIP_LIB=$E/librpeflow_corrp$v.so timeout 300 python3 tools/corr_clock.py --out $OUT/corr_clock_probe$v.json > $OUT/corr_clock_probe$v.log 2>&1
 done
 timeout 300 python3 tools/corr_clock.py --out $OUT/corr_clock_shipped.json > $OUT/corr_clock_shipped.log 2>&1

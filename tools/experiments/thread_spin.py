@@ -47,7 +47,7 @@ def account(label, seconds, body):
 
 
 def main():
-    which = sys.argv[1:] or ["idle", "replay", "replay_paced", "eager", "copies", "replay+copies"]
+    which = sys.argv[1:] or ["idle", "replay", "replay_paced", "replay_ring", "eager", "copies", "replay+copies"]
     torch.set_grad_enabled(False)
     dev = torch.device("cuda", 0)
     runtime.name_thread("ph-hip-init")
@@ -89,12 +89,24 @@ def main():
             dst.copy_(src, non_blocking=True)
         time.sleep(0.004)
 
+    ring = []
+
+    def replay_ring():  # what a rank of the evaluation does: at most three replays in flight, the host waits by POLLING an old event
+        graph.replay()
+        ev = torch.cuda.Event()
+        ev.record()
+        ring.append(ev)
+        if len(ring) > 3:
+            old = ring.pop(0)
+            while not old.query():
+                time.sleep(0.00025)
+
     def both():
         graph.replay()
         with torch.cuda.stream(side):
             dst.copy_(src, non_blocking=True)
 
-    loops = {"idle": lambda: time.sleep(0.01), "replay": replay, "replay_paced": replay_paced, "eager": eager, "copies": copies, "replay+copies": both}
+    loops = {"idle": lambda: time.sleep(0.01), "replay": replay, "replay_paced": replay_paced, "replay_ring": replay_ring, "eager": eager, "copies": copies, "replay+copies": both}
     for name in which:
         account(name, 4.0, loops[name])
 
