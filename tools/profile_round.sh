@@ -4,12 +4,13 @@
 #
 #   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r05 [step ...]'
 #
-# Steps (default: all, in this order): bench stats forward timeline pmc fps knn2d hotpath rehearsal corrclock knngate
+# Steps (default: all, in this order): ranks8 bench stats forward timeline pmc fps knn2d hotpath rehearsal corrclock knngate
+# (ranks8 first: eight ranks of the default bench on this box's ONE GPU, on the fresh box's cold MIOpen database -- start-up account)
 # Output: gpurun_out/<round>/prof/ ; copy what is to be judged into profiles/<round>_*.
 # PMC passes are separate runs, counters only with --kernel-trace, the program itself behind "--" (no env / bash -c hops).
 set -x
 R=${1:-r05}; shift
-STEPS=${*:-bench stats forward timeline pmc fps knn2d hotpath rehearsal corrclock knngate}
+STEPS=${*:-ranks8 bench stats forward timeline pmc fps knn2d hotpath rehearsal corrclock knngate}
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R/prof
 mkdir -p $OUT
@@ -36,6 +37,9 @@ pmc() {  # tag passes... -- command...   (passes: a b c d e, see below)
   done
 }
 
+if has ranks8; then  # functional 8-rank run (all ranks on the one GPU, collective on gloo): time to the first step per rank, cold database
+  ( time timeout 900 python3 bench.py --gpus 8 --share-gpu --backend gloo --steps 2 --warmup 1 --no-cpu-baseline --no-corr-microbench --eval-batches 8 > $OUT/bench_8rank_shared_gpu.json 2> $OUT/bench_8rank_shared_gpu.err ) 2> $OUT/bench_8rank_shared_gpu_time.txt
+fi
 if has bench; then  # the bench lines themselves, un-profiled (first process on this box)
   python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
   python3 bench.py --workload eval --steps 128 --no-cpu-baseline --no-corr-microbench > $OUT/bench_eval.json 2> $OUT/bench_eval.err
@@ -84,11 +88,13 @@ if has hotpath; then  # the hot-path sequence alone, eager, kernel stats; and wh
   python3 tools/aten_gpu_census.py hotpath > $OUT/aten_census_hotpath.txt 2>/dev/null
   python3 tools/aten_gpu_census.py forward > $OUT/aten_census_forward.txt 2>/dev/null
 fi
-if has rehearsal; then  # the 8-rank host side: host-only ranks; then with a real rank among them, and that rank alone
+if has rehearsal; then  # the 8-rank host side: host-only ranks; a real rank alone and among seven paced host-side neighbours, cached set pinned (the default of bench.py's eval leg) and pageable (staged by loader threads)
   timeout -k 5 300 python3 tools/host_rehearsal.py --ranks 8 --batches 384 2>/dev/null | grep "^{" > $OUT/host_rehearsal_default.json
-  timeout -k 5 600 python3 tools/host_rehearsal.py --ranks 1 --batches 256 --real-rank 0 2>/dev/null | grep "^{" > $OUT/host_rehearsal_real_alone.json
-  timeout -k 5 600 python3 tools/host_rehearsal.py --ranks 8 --batches 256 --real-rank 0 2>/dev/null | grep "^{" > $OUT/host_rehearsal_real_rank0_unpaced.json
-  timeout -k 5 600 python3 tools/host_rehearsal.py --ranks 8 --batches 256 --real-rank 0 --pace 66 2>/dev/null | grep "^{" > $OUT/host_rehearsal_real_rank0.json
+  for mode in pinned pageable; do
+    flag=""; [ $mode = pinned ] && flag="--pinned"
+    timeout -k 5 600 python3 tools/host_rehearsal.py --ranks 1 --batches 256 --real-rank 0 $flag 2>/dev/null | grep "^{" > $OUT/host_rehearsal_real_alone_$mode.json
+    timeout -k 5 600 python3 tools/host_rehearsal.py --ranks 8 --batches 256 --real-rank 0 --neighbours cpu --pace 66 $flag 2>/dev/null | grep "^{" > $OUT/host_rehearsal_real_cpu_neighbours_$mode.json
+  done
 fi
 if has corrclock; then  # engine clock over the very launches of the correlation microbench, per operand kind
   python3 tools/corr_clock.py --out $OUT/corr_clock.json > $OUT/corr_clock.log 2>&1
