@@ -108,13 +108,19 @@ NOMINAL_SCLK_MHZ = 2400.0   # MI355X_MICROARCH.md: peak engine clock
 HBM_COPY_GBS = 6290.0       # MI355X_MICROARCH.md: what a device-to-device copy reaches of the 8 TB/s (the guide's figure; the run measures its own beside it)
 
 
-def pmc_traffic(suffix):
-    """(HBM bytes per launch, file) from the newest PMC summary committed under profiles/ (rocprofv3 cannot run inside this
-    process; the passes are `tools/profile_round*.sh`'s, collected as MI355X_MICROARCH.md prescribes)."""
+def pmc_summary(suffix):
+    """The newest PMC summary committed under profiles/ whose name ends in ``suffix`` (rocprofv3 cannot run inside this process;
+    the passes are `tools/profile_round.sh`'s, collected as MI355X_MICROARCH.md prescribes), and its path; (None, None) without."""
     for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
         if name.endswith(suffix):
-            return int(json.load(open(os.path.join(ROOT, "profiles", name)))["derived"]["hbm_traffic_bytes"]), "profiles/" + name
+            return json.load(open(os.path.join(ROOT, "profiles", name))), "profiles/" + name
     return None, None
+
+
+def pmc_traffic(suffix):
+    """(HBM bytes per launch, file): FETCH_SIZE with the guide's gfx950 correction + WRITE_SIZE."""
+    summary, source = pmc_summary(suffix)
+    return (int(summary["derived"]["hbm_traffic_bytes"]), source) if summary else (None, None)
 
 
 def clocked(frac, clock, dev, launches=0):
@@ -245,9 +251,13 @@ def pointconv_microbench(dev, iters=40):
     alg = roofline.pointconv(B, N, N, C, Cout, False)
     tflops = flops / us / 1e6
     traffic, source = pmc_traffic("pointconv_pmc.json")
+    summary, _ = pmc_summary("pointconv_pmc.json")
+    # FETCH_SIZE's doubling on gfx950 is calibrated for 16-byte-per-lane streams; this kernel's reads are 64-byte gathered row
+    # pieces and 1-KiB weight fragments from L2: the corrected figure is an upper bound, the counter as read a lower one
+    as_counted = int(summary["counters_mean_per_launch"]["FETCH_SIZE"] * 1024 + summary["derived"]["write_bytes"]) if summary else None
     return {"kernel": "pointconv_fused_kernel<1,2,4,2,1> (PointConvNoSampling 195 -> 128 over 4 x 4096 points, k = 16: FlowEstimator3D.point_conv1 at pyramid level 1)",
             "bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4),
-            "traffic": traffic, "traffic_source": source, "us_per_launch": round(us, 1), "launches_per_step": 1,
+            "traffic": traffic, "traffic_as_counted": as_counted, "traffic_source": source, "us_per_launch": round(us, 1), "launches_per_step": 1,
             "algorithmic_flops": flops, "algorithmic_bytes": alg, "hbm_GBs": round(alg / us / 1e3, 1),
             "note": "the largest in-scope throughput kernel of the step (rocprof: 180 us a launch, two launches a step with its 128 -> 128 twin), "
                     "timed here by HIP events over %d back-to-back launches of that kernel alone.  fp32 MFMA (v_mfma_f32_16x16x4_f32) against the "

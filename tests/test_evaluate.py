@@ -101,6 +101,16 @@ print("RESULT", rank, json.dumps(acc.tolist()))
 if rank == 0:  # an unsharded call inside the job (rank 0 validating on its own): no collective, nothing multiplied, no waiting for rank 1
     _, alone = E.evaluate(fake_model, data, batch_size=2, device="cpu")
     print("ALONE", rank, json.dumps(alone.tolist()))
+# the first forward in turn (MIOpen's solver search on a GPU run): rank 0's step ends before any other rank's begins
+import time
+from rpeflow_amd.evaluate import first_forward_in_turn
+def step():
+    t0 = time.time()
+    time.sleep(0.3)
+    return t0, time.time()
+span = first_forward_in_turn(step, rank, dist.group.WORLD)
+print("TURN", rank, json.dumps(span))
+assert first_forward_in_turn(lambda: 7, rank, None) == 7   # no group: just the call
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -128,6 +138,8 @@ def test_two_process_gloo_all_reduce_equals_single_process(tmp_path):
     assert accs[0][0] == single[0].item() and accs[0][4] == single[4].item()
     alone = json.loads(next(l for l in outs[0][0].splitlines() if l.startswith("ALONE")).split(" ", 2)[2])
     assert alone == single.tolist()  # world_size=1, group=None inside an initialised 2-rank group: the plain single-process sums
+    turns = [json.loads(next(l for l in o[0].splitlines() if l.startswith("TURN")).split(" ", 2)[2]) for o in outs]
+    assert turns[0][1] <= turns[1][0]  # first_forward_in_turn: rank 0 had finished its step when rank 1 began its own
 
 
 @pytest.mark.parametrize("device", ["cpu", pytest.param("cuda:0", marks=pytest.mark.gpu)])
