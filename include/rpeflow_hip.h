@@ -137,8 +137,9 @@ int rpe_fps_algo(const float *xyz, int64_t sb, int64_t sn, int64_t sd,
  * leaky_slope != 0 fuses the caller's leaky_relu (RPEFlow_core.py:362); pass 0
  * for the plain operator.  algo: 0 = pick; 1 = direct (any md); 3 = small maps (md <= 4: 64 flattened pixels x one displacement
  * row a workgroup, channels split over its waves); 2 = MFMA tiles, register-staged (md == 4);
- * 4 / 7 = MFMA tiles behind an LDS-DMA ring, 4 / 8 waves a workgroup (md == 4, W % 4 == 0, C % 4 / C % 2 == 0, 16-byte
- * aligned inputs).  All give the same values to fp32 re-association; tests cross-check them.                        */
+ * 7 / 8 = MFMA tiles behind an LDS-DMA ring, eight waves a workgroup with two rows / one row a wave (md == 4, W % 4 == 0,
+ * C % 2 / C % 4 == 0, 16-byte aligned inputs; 8: the mid-size maps, where two rows a wave leave SIMDs empty).  All give the
+ * same values to fp32 re-association; tests cross-check them.                                                        */
 int rpe_correlation2d_forward(const float *in1, const float *in2, int B, int C, int H, int W, int md,
                               float leaky_slope, int algo, float *out, rpe_stream_t stream);
 

@@ -542,15 +542,18 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
     hipStream_t st = (hipStream_t)stream;
     const int n = 2 * md + 1;
     const bool aligned = ((reinterpret_cast<uintptr_t>(in1) | reinterpret_cast<uintptr_t>(in2)) & 15) == 0;
-    // pick (measured on MI355X, B=4, see profiles/): the LDS-DMA ring kernels where their alignment
-    // conditions hold -- 8 waves x 2 rows from 144x240 maps up, 4 waves x 2 rows down to 72x120 --
-    // the register-staged MFMA kernel for other large maps, one thread per output for the rest: on maps of a few
-    // thousand pixels the tiled kernels are launch- and latency-bound (36x60, C = 96: 68 us against 32).
+    // pick (measured on MI355X, tools/corr_gate_table.py -> profiles/r06_corr_gate_table*.txt): the LDS-DMA ring kernels where their
+    // alignment conditions hold, from 72x120 maps up -- TWO rows a wave (216 accumulators, two waves a SIMD: the operand reuse
+    // that carries the big maps) once that tiling puts a wave on every SIMD, ONE row a wave (108 accumulators, twice the waves)
+    // below, where the launch is latency-bound: 4 x 64 x 72 x 120 51 -> 33 us, 3 x 32 x 128 x 160 36 -> 24 us, and 39 against 44 us
+    // the other way at 4 x 32 x 144 x 240 (1152 waves) -- the register-staged MFMA kernel for other large maps, the small-map
+    // kernel up to 8 x 36 x 60 pixels (36x60, C = 96: 15 us against 42-72 for the tiled kernels), one thread per output for the rest.
     if (algo == 0) {
         const bool dma_ok = md == MD && W % 4 == 0 && aligned && B <= 65535 && (int64_t)H * W * 4 < (1ll << 31);
         const int64_t px = (int64_t)H * W;
-        if (dma_ok && C % 2 == 0 && px >= 144 * 240) algo = 7;
-        else if (dma_ok && C % 4 == 0 && px >= 72 * 120) algo = 4;
+        const int64_t waves2 = (int64_t)B * ((H + 1) / 2) * ((W + TX - 1) / TX);  // waves of the two-rows-a-wave tiling; the chip has 1024 SIMDs
+        if (dma_ok && C % 4 == 0 && px >= 72 * 120 && waves2 < 1024) algo = 8;
+        else if (dma_ok && C % 2 == 0 && px >= 72 * 120) algo = 7;
         else if (md == MD && px >= 72 * 120) algo = 2;
         else if (md <= 4 && B <= 65535 && (int64_t)B * px <= 8 * 36 * 60) algo = 3;  // the maps it was written and measured on (<= 36x60, 2B = 8)
         else algo = 1;
@@ -559,9 +562,9 @@ RPE_API int rpe_correlation2d_forward(const float *in1, const float *in2, int B,
         if (md != MD) return RPE_EUNSUPPORTED;
         if (B > 65535) return RPE_EUNSUPPORTED;
         launch_mfma<2, 4, 4>(in1, in2, B, C, H, W, leaky_slope, out, st);
-    } else if (algo == 4 || algo == 7) {
+    } else if (algo == 7 || algo == 8) {
         if (md != MD || B > 65535 || W % 4 != 0 || !aligned) return RPE_EUNSUPPORTED;
-        int rc = algo == 4 ? launch_mfma_dma<2, 4, 4, 3, 4, true>(in1, in2, B, C, H, W, leaky_slope, out, st)
+        int rc = algo == 8 ? launch_mfma_dma<1, 8, 4, 3, 3, true>(in1, in2, B, C, H, W, leaky_slope, out, st)  // one row a wave
 #if RPE_CORR_PROBE >= 3 && RPE_CORR_PROBE <= 5  // ring depth probes: 4 / 5 / 6 slots instead of 3 (tools/corr_energy_probes.sh)
                            : launch_mfma_dma<2, 8, 2, RPE_CORR_PROBE + 1, 3, true>(in1, in2, B, C, H, W, leaky_slope, out, st);
 #else

@@ -301,7 +301,7 @@ def test_fps_transposed_view_as_the_model_passes_it():
 
 
 # ---------------------------------------------------------------- correlation2d
-DMA_ALGOS = (4, 7)  # LDS-DMA ring variants of the MFMA kernel (4 / 8 waves): need W % 4 == 0 and C % 4 / C % 2 == 0
+DMA_ALGOS = (7, 8)  # LDS-DMA ring variants of the MFMA kernel (eight waves, two rows / one row a wave): need W % 4 == 0 and C % 2 / C % 4 == 0
 
 
 def corr_algos(C, Wd, md):
@@ -311,7 +311,7 @@ def corr_algos(C, Wd, md):
     if md == 4:
         algos.append(2)
         if Wd % 4 == 0:
-            algos += [a for a in DMA_ALGOS if C % (4 if a == 4 else 2) == 0]
+            algos += [a for a in DMA_ALGOS if C % (2 if a == 7 else 4) == 0]
     return algos
 
 

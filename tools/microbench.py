@@ -31,7 +31,7 @@ def main():
         a = torch.randn(1, 256, 544, 960, device=dev)
         b = torch.randn(1, 256, 544, 960, device=dev)
         alg_bytes = 2 * a.numel() * 4 + 81 * 544 * 960 * 4
-        for algo in (7, 2, 4, 7):
+        for algo in (7, 2, 8, 7):
             us = timeit(lambda: W._correlation2d_algo(a, b, 4, algo))
             print(f"corr algo={algo} 1x256x544x960: {us:9.1f} us  {alg_bytes / us / 1e6:7.3f} TB/s algorithmic  ({alg_bytes / us / 1e6 / 8.0:.3f} of 8 TB/s)")
         for (B, C, H, Wd) in [(4, 32, 144, 240), (4, 64, 72, 120), (4, 96, 36, 60), (4, 128, 18, 30), (4, 192, 9, 15)]:
@@ -39,7 +39,7 @@ def main():
             us = timeit(lambda: ops.correlation2d(x, y, 4))
             us1 = timeit(lambda: W._correlation2d_algo(x, y, 4, 1))
             us2 = timeit(lambda: W._correlation2d_algo(x, y, 4, 2))
-            dma = [timeit(lambda: W._correlation2d_algo(x, y, 4, al)) if Wd % 4 == 0 else float("nan") for al in (4, 7)]
+            dma = [timeit(lambda: W._correlation2d_algo(x, y, 4, al)) if Wd % 4 == 0 else float("nan") for al in (8, 7)]
             print(f"corr model {B}x{C}x{H}x{Wd}: picked {us:9.1f} us   direct {us1:9.1f} us  mfma {us2:9.1f} us  dma4/7 {dma[0]:7.1f} {dma[1]:7.1f}")
     if "knn" in which:
         for (B, M, Q, D, k) in [(4, 8192, 4096, 3, 16), (4, 4096, 4096, 3, 16), (4, 4096, 34560, 2, 1), (4, 2048, 8640, 2, 1),
