@@ -84,8 +84,9 @@ class SyntheticPairs(torch.utils.data.Dataset):
         t0 = time.perf_counter()
         wanted = range(self.distinct) if indices is None else sorted({i % self.distinct for i in indices})
         missing = [s for s in wanted if s not in self.cache]
-        if threads is None:
-            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        if threads is None:  # this rank's share of the cores the process may use (eight ranks x 16 generator threads on a 16-core quota otherwise)
+            from .runtime import cores_per_rank
+            threads = cores_per_rank()
         with ThreadPoolExecutor(max(1, min(threads, 16, len(missing) or 1))) as pool:
             for slot, sample in zip(missing, pool.map(self._make, missing)):
                 self.cache[slot] = sample
