@@ -305,11 +305,13 @@ def first_forward_in_turn(step, rank, group=None):
     together = group is not None and dist.get_world_size(group) > 1
     if together and rank != 0:
         dist.barrier(group)
-    out = step()
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-    if together and rank == 0:
-        dist.barrier(group)
+    try:
+        out = step()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    finally:
+        if together and rank == 0:  # (also when the step raised: the others must not wait for ever)
+            dist.barrier(group)
     return out
 
 
