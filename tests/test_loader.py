@@ -145,6 +145,31 @@ def test_device_ring_delivers_the_samples(pin):
     assert n == 12 and pipe.stats["batches"] == 12 and (pipe.stats["direct"] == 12) == pin
 
 
+@pytest.mark.gpu
+def test_load_into_fills_the_pinned_ring_on_a_gpu_run():
+    """``load_into`` on a CUDA run: the places handed to the dataset are PINNED host memory (the H2D copy starts from them),
+    every batch arrives on the device with the __getitem__ path's contents, through more batches than the ring has slots."""
+    class Direct(SyntheticPairs):
+        pinned_places = 0
+
+        def load_into(self, i, out):
+            sample = self[i]
+            assert set(out) == set(sample)
+            Direct.pinned_places += all(v.is_pinned() for v in out.values())
+            for k, v in sample.items():
+                out[k].copy_(v)
+
+    data = Direct(23, H=64, W=96, N=1024, distinct=5, cache=True)
+    pipe = InputPipeline(data, list(range(23)), 2, "cuda:0", workers=3)
+    n = 0
+    for batch, _ in pipe.pairs():
+        ids = list(range(2 * n, min(2 * n + 2, 23)))
+        for k in ("images", "event_voxel", "pcs", "flow_2d"):
+            assert batch[k].device.type == "cuda" and torch.equal(batch[k].cpu(), torch.stack([data[i][k] for i in ids])), (n, k)
+        n += 1
+    assert n == 12 and Direct.pinned_places == 22  # every sample but the first, which defined keys and shapes through __getitem__
+
+
 def test_raw_events_need_the_device_stage():
     """A dataset that returns raw events (flyingthings3d.py:206-208 without a pre-processed file) is voxelised by the pipeline's
     copy stage on the GPU; there is no CPU voxelisation in the product, so a CPU consumer is refused -- loudly."""
