@@ -16,7 +16,10 @@ from pageable memory on the compute stream feeds 4 frame pairs a second.  Here t
            compute stream, and the copy stream waits on that before overwriting it.
 
 Samples that already lie in pinned memory (``SyntheticPairs(pin=True)``, a registered memory-mapped set) skip stage 1:
-they are copied to the device from where they are.
+they are copied to the device from where they are.  A dataset that implements ``load_into(i, out)`` is handed the sample's
+place in the pinned host batch and reads / decodes straight into it: stage 1 then copies nothing (the staging memcpy of
+``__getitem__`` samples is 1.2-1.4 cores a rank at 60 batches/s of 206 MB).  The pipeline's threads are
+named ``rpe-load`` / ``rpe-copy`` (top -H) and report their CPU seconds in ``stats["thread_cpu_s"]``.
 
 Raw events.  The reference's dataset voxelises a sample's events on the CPU when no pre-processed file exists
 (flyingthings3d.py:206-208: load_events_h5 -> eventsToVoxel, ~50 ms a sample in numpy/torch against a 15 ms batch).  A
@@ -122,8 +125,9 @@ class InputPipeline:
         self.sync_ready = os.environ.get("RPE_PIPE_SYNC_READY", "dev")      # how the consumer waits for a batch's H2D copy
         # how the copy stream waits for the consumer to be done with a device batch: on the HOST (the copy thread waits for the
         # event, then issues the copy).  With a device-side wait (copy stream waiting on an event of the compute stream while the
-        # compute stream waits on the copy stream's), hipGraphLaunch on the compute stream blocks its caller for 20-30 ms two
-        # launches out of three (ROCm 7.2, measured); the host-side wait costs nothing: the event is three batches old.
+        # compute stream waits on the copy stream's: "dev"), hipGraphLaunch on the compute stream blocks its caller for 20-30 ms
+        # two launches out of three (ROCm 7.2, measured).  "host" polls the event (Event.query + a short sleep); "spin" is the
+        # plain Event.synchronize of rounds 3-5, which busy-waits a core away (tools/host_rehearsal.py: 0.94 against 0.02 cores).
         self.sync_release = os.environ.get("RPE_PIPE_SYNC_RELEASE", "host")
         self.poll_s = float(os.environ.get("RPE_PIPE_POLL_MS", "0.25")) * 1e-3
         self.depth = max(self.depth, int(os.environ.get("RPE_PIPE_DEPTH", self.depth)))
