@@ -149,13 +149,13 @@ def test_device_ring_delivers_the_samples(pin):
 def test_load_into_fills_the_pinned_ring_on_a_gpu_run():
     """``load_into`` on a CUDA run: the places handed to the dataset are PINNED host memory (the H2D copy starts from them),
     every batch arrives on the device with the __getitem__ path's contents, through more batches than the ring has slots."""
-    class Direct(SyntheticPairs):
-        pinned_places = 0
+    pinned_places = []  # (list.append is atomic: three loader threads call load_into)
 
+    class Direct(SyntheticPairs):
         def load_into(self, i, out):
             sample = self[i]
             assert set(out) == set(sample)
-            Direct.pinned_places += all(v.is_pinned() for v in out.values())
+            pinned_places.append(all(v.is_pinned() for v in out.values()))
             for k, v in sample.items():
                 out[k].copy_(v)
 
@@ -167,7 +167,7 @@ def test_load_into_fills_the_pinned_ring_on_a_gpu_run():
         for k in ("images", "event_voxel", "pcs", "flow_2d"):
             assert batch[k].device.type == "cuda" and torch.equal(batch[k].cpu(), torch.stack([data[i][k] for i in ids])), (n, k)
         n += 1
-    assert n == 12 and Direct.pinned_places == 22  # every sample but the first, which defined keys and shapes through __getitem__
+    assert n == 12 and len(pinned_places) == 22 and all(pinned_places)  # every sample but the first, which defined keys and shapes through __getitem__
 
 
 def test_raw_events_need_the_device_stage():
