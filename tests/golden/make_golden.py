@@ -484,7 +484,14 @@ def gen_eval():
 
 
 # ------------------------------------------------------------------ the reference model's own calls
-TRACE_CASE = dict(B=2, H=128, W=192, N=8192, first_seed=1000)
+TRACE_CASES = {
+    # the model goldens' regime: standard parameter fill, pc2 = pc1 + small noise, every point inside the frame
+    "call_trace": dict(B=2, H=128, W=192, N=8192, first_seed=1000, stress=False, model_seed=None),
+    # off the easy regime (tests/inputs.py frame_pair_stress): the second parameter fill, a rigid motion + N(0, 0.5^2), ~5 % of the
+    # points projecting outside the frame -- the cross-cloud searches are no longer near-self searches, grid_sample_wrapper's
+    # zero padding and the nearest-pixel search off the raster take part
+    "call_trace_stress": dict(B=1, H=128, W=192, N=8192, first_seed=5000, stress=True, model_seed="stress"),
+}
 # functions wrapped where the reference's modules bound them at import time (``from .csrc import ...``): (module, name) pairs
 TRACE_FUNCTIONS = {
     "k_nearest_neighbor": ["RPEFlow_core", "pwc3d_core", "pointconv", "utils"],
@@ -627,10 +634,15 @@ def _module_record(rec, mod):
     return dict(name=rec.module_names[id(mod)], cls=cls, ctor=ctor)
 
 
-@torch.no_grad()
 def gen_call_trace():
-    """Every call the reference MODEL makes into the hot path during one forward (128 x 192 frames, B = 2, 8192 points, seeded
-    parameters): the four names of models/csrc, the section-8(a) glue functions of models/utils.py, build_pc_pyramid and the
+    for name in TRACE_CASES:
+        _gen_call_trace(name)
+
+
+@torch.no_grad()
+def _gen_call_trace(trace_name):
+    """Every call the reference MODEL makes into the hot path during one forward (128 x 192 frames, 8192 points, seeded
+    parameters; TRACE_CASES): the four names of models/csrc, the section-8(a) glue functions of models/utils.py, build_pc_pyramid and the
     PointConv / Correlation3D / FlowEstimator3D / FeaturePyramid3D forwards -- how each was called (positional / keyword),
     shapes, dtypes, strides, storage offsets, values and outputs.  Format and storage policy: tests/trace_io.py."""
     import importlib
@@ -638,8 +650,11 @@ def gen_call_trace():
     import json
     from tests import trace_io as TIO
 
+    c = TRACE_CASES[trace_name]
     m = reference_model()
-    m.load_state_dict({k: T(v) for k, v in model_params(m).items()}, strict=True)
+    shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    seed_kw = {"seed": I.STRESS_MODEL_SEED} if c["model_seed"] == "stress" else {}
+    m.load_state_dict({k: T(v) for k, v in I.model_params(shapes, **seed_kw).items()}, strict=True)
     m.eval()
     rec = _Recorder()
     rec.module_names = {id(mod): name for name, mod in m.named_modules()}
@@ -687,8 +702,8 @@ def gen_call_trace():
         for cls_name in classes:
             wrap_forward(getattr(importlib.import_module("models." + mod_name), cls_name))
 
-    c = TRACE_CASE
-    samples = [I.frame_pair(c["first_seed"] + i, H=c["H"], W=c["W"], N=c["N"]) for i in range(c["B"])]
+    make = I.frame_pair_stress if c["stress"] else I.frame_pair
+    samples = [make(c["first_seed"] + i, H=c["H"], W=c["W"], N=c["N"]) for i in range(c["B"])]
     batch = {k: torch.stack([T(s[k]) for s in samples]) for k in samples[0]}
     rec.enabled = True
     try:
@@ -703,12 +718,13 @@ def gen_call_trace():
     for call in rec.calls:
         counts[call["fn"]] = counts.get(call["fn"], 0) + 1
     print("calls:", len(rec.calls), counts)
-    meta = dict(case=c, parameters="tests.inputs.model_params over tests/golden/state_dict_keys.json", full_bytes=TIO.FULL_BYTES,
+    meta = dict(case=c, parameters="tests.inputs.model_params over tests/golden/state_dict_keys.json" + (" with seed STRESS_MODEL_SEED" if seed_kw else ""),
+                full_bytes=TIO.FULL_BYTES,
                 sample_above=TIO.SAMPLE_ABOVE, n_samples=TIO.N_SAMPLES, counts=counts, calls=rec.calls)
-    with open(os.path.join(OUT, "call_trace.json"), "w") as f:
+    with open(os.path.join(OUT, trace_name + ".json"), "w") as f:
         json.dump(meta, f, separators=(",", ":"))
-    save("call_trace", **rec.arrays)
-    print("call_trace.json: %.0f KiB, %d arrays" % (os.path.getsize(os.path.join(OUT, "call_trace.json")) / 1024, len(rec.arrays)))
+    save(trace_name, **rec.arrays)
+    print("%s.json: %.0f KiB, %d arrays" % (trace_name, os.path.getsize(os.path.join(OUT, trace_name + ".json")) / 1024, len(rec.arrays)))
 
 
 if __name__ == "__main__":

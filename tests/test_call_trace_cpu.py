@@ -1,10 +1,10 @@
 """The call-trace fixture without a GPU: what it holds, how its arguments are rebuilt, and the CPU oracle against it.
 
-tests/golden/call_trace.{json,npz} records every hot-path call of one forward of the imported reference model
-(tests/golden/make_golden.py call_trace, tests/trace_io.py).  Here: the fixture's inventory and the argument patterns of the
+tests/golden/call_trace{,_stress}.{json,npz} record every hot-path call of one forward of the imported reference model, once per
+parameter fill (tests/golden/make_golden.py call_trace, tests/trace_io.py).  Here: the fixture's inventory and the argument patterns of the
 reference's call sites; ``strided_tensor`` (the rebuild with recorded strides / offsets); and every recorded FUNCTION call
 replayed through oracle/oracle.py -- 43 KNN and the FPS call index for index, 156 gathers bit for bit, samplers / warps /
-interpolation / correlation within the oracle's own golden bounds -- which pins the oracle to 300 more reference outputs,
+interpolation / correlation within the oracle's own golden bounds -- which pins the oracle to 2 x 301 more reference outputs,
 on the reference model's own arguments.  The GPU replay of the same trace is tests/test_gpu_call_trace.py.
 """
 import numpy as np
@@ -20,9 +20,11 @@ EXPECTED_COUNTS = {"k_nearest_neighbor": 43, "furthest_point_sampling": 1, "corr
                    "build_pc_pyramid": 1, "batch_indexing_channel_first": 136, "batch_indexing_channel_last": 20}
 
 
-@pytest.fixture(scope="module")
-def trace():
-    return TIO.Trace()
+@pytest.fixture(scope="module", params=TIO.TRACES)
+def trace(request):
+    """Both recorded forwards: the model goldens' regime (B = 2) and the stress one (second parameter fill, large motion, points
+    outside the frame, B = 1) -- tests/golden/make_golden.py TRACE_CASES."""
+    return TIO.Trace(request.param)
 
 
 def test_trace_holds_every_call_of_one_reference_forward(trace):
@@ -90,4 +92,4 @@ def test_oracle_reproduces_the_recorded_reference_calls(trace, fn):
             want, _ = trace.output(call["out"])
             scale = max(1.0, float(np.abs(want).max()))
             worst = max(worst, TIO.compare_output(got, call["out"], trace, exact=False, atol=bound * scale, what=what) / scale)
-    print("\n%s: oracle = reference on %d recorded calls%s" % (fn, len(calls), "" if bound is None else " (worst %.2e of the output scale)" % worst))
+    print("\n%s / %s: oracle = reference on %d recorded calls%s" % (trace.name, fn, len(calls), "" if bound is None else " (worst %.2e of the output scale)" % worst))

@@ -1,8 +1,9 @@
 """Replay of the calls the reference MODEL itself makes into the hot path, through rpeflow_amd on the GPU.
 
 north_star: "exposed through the same Python operator signatures so models/RPEFlow.py ... consume them unchanged".
-tests/golden/call_trace.{json,npz} (tests/golden/make_golden.py call_trace; format: tests/trace_io.py) holds all 324 calls one
-forward of the imported reference makes -- 43 k_nearest_neighbor (RPEFlow_core.py:329-331, pwc3d_core.py:81,
+tests/golden/call_trace{,_stress}.{json,npz} (tests/golden/make_golden.py call_trace; format: tests/trace_io.py) hold all 324
+calls one forward of the imported reference makes -- once in the model goldens' regime (B = 2), once off it (second parameter
+fill, large motion, points outside the frame, B = 1) -- 43 k_nearest_neighbor (RPEFlow_core.py:329-331, pwc3d_core.py:81,
 pointconv.py:46, utils.py:148), furthest_point_sampling (pwc3d_core.py:13), 5 correlation2d (RPEFlow_core.py:362), 156
 gathers, 13 knn_interpolation, 4 + 4 warps, 45 grid_sample_wrapper, 20 project_feat_with_nn_corr, build_pc_pyramid, 20
 PointConv, 5 Correlation3D, 5 FlowEstimator3D and 2 FeaturePyramid3D forwards -- with the argument patterns of the
@@ -12,16 +13,13 @@ build_pc_pyramid's transposed view and prefix slices of the sampling order, Poin
 slice backwarp_3d receives as flow, one tensor object passed twice.  Every argument is rebuilt WITH THE
 RECORDED STRIDES AND STORAGE OFFSET, the rpeflow_amd counterpart is called the way the reference called its own function, and
 the result is held against the reference's output: indices and gathers bit for bit, floating point within the bound of the
-operator's golden test.
+operator's golden test.  (What the fixtures hold -- counts, call forms, strided arguments -- is asserted without a GPU in
+tests/test_call_trace_cpu.py.)
 """
-import json
-import os
-
 import numpy as np
 import pytest
 import torch
 
-from tests import inputs as I
 from tests import trace_io as TIO
 
 pytestmark = pytest.mark.gpu
@@ -57,16 +55,17 @@ EXPECTED_COUNTS = {"k_nearest_neighbor": 43, "furthest_point_sampling": 1, "corr
                    "build_pc_pyramid": 1, "batch_indexing_channel_first": 136, "batch_indexing_channel_last": 20}
 
 
-@pytest.fixture(scope="module")
-def trace():
-    return TIO.Trace()
+@pytest.fixture(scope="module", params=TIO.TRACES)
+def trace(request):
+    """Both recorded forwards: the model goldens' regime (B = 2) and the stress one (second parameter fill, large motion, ~5 % of
+    the points projecting outside the frame, B = 1) -- tests/golden/make_golden.py TRACE_CASES."""
+    return TIO.Trace(request.param)
 
 
 @pytest.fixture(scope="module")
-def parameters(golden_dir):
+def parameters(trace):
     """The seeded parameter fill the trace was recorded with, by state-dict key."""
-    keys = json.load(open(os.path.join(golden_dir, "state_dict_keys.json")))
-    return I.model_params([(k, tuple(shape)) for k, shape, _ in keys])
+    return trace.parameters()
 
 
 def check_output(got, o, trace, bound, what):
@@ -100,25 +99,6 @@ def replay(trace, call, parameters):
     return check_output(got, call["out"], trace, BOUNDS[call["fn"]], what)
 
 
-def test_trace_holds_every_call_of_one_reference_forward(trace):
-    counts = {}
-    for call in trace.calls:
-        counts[call["fn"]] = counts.get(call["fn"], 0) + 1
-    assert counts == EXPECTED_COUNTS
-    # the patterns the review named are really in there
-    knn = [c for c in trace.calls if c["fn"] == "k_nearest_neighbor"]
-    grid_calls = [c for c in knn if c["site"].startswith("models/RPEFlow_core.py:3") and c["args"][2]["passed"] == "kw" and c["args"][2]["value"] == 1]
-    assert len(grid_calls) == 10 and all(c["args"][1]["t"]["shape"][1] == 2 and c["args"][0]["t"]["shape"][1] == 2 for c in grid_calls)  # [B,2,HW] mesh, [B,2,N] points
-    assert sum(all(a["passed"] == "kw" for a in c["args"]) for c in knn) == 5                      # pwc3d_core.py:81: keyword-only
-    assert sum("same_as" in c["args"][1] for c in knn) == 5                                        # RPEFlow_core.py:331: (xyz1, xyz1)
-    fps = [c for c in trace.calls if c["fn"] == "furthest_point_sampling"][0]
-    assert fps["args"][0]["t"]["strides"][1:] == [1, 8192] and fps["site"] == "models/pwc3d_core.py:13"   # transposed view
-    strided = {(c["fn"], c["site"]) for c in trace.calls for a in c["args"] if a["kind"] == "tensor" and "t" in a
-               and tuple(a["t"]["strides"]) != torch.empty(a["t"]["shape"]).stride()}
-    assert {("PointConvNoSampling.forward", "models/pwc3d_core.py:141"), ("backwarp_3d", "models/RPEFlow_core.py:358"),
-            ("batch_indexing_channel_last", "models/pointconv.py:55"), ("batch_indexing_channel_first", "models/pwc3d_core.py:25")} <= strided
-
-
 @pytest.mark.parametrize("fn", sorted(EXPECTED_COUNTS))
 def test_replay_reference_calls(trace, parameters, fn):
     calls = [c for c in trace.calls if c["fn"] == fn]
@@ -127,5 +107,5 @@ def test_replay_reference_calls(trace, parameters, fn):
     for call in calls:
         worst = max(worst, replay(trace, call, parameters))
     sites = sorted({c["site"] for c in calls})
-    print("\n%s: %d calls from %s replayed; %s" % (fn, len(calls), ", ".join(sites),
+    print("\n%s / %s: %d calls from %s replayed; %s" % (trace.name, fn, len(calls), ", ".join(sites),
                                                    "bit for bit" if BOUNDS[fn] is None else "worst error %.2e of the output scale" % worst))

@@ -1,4 +1,4 @@
-"""The call-trace fixture (tests/golden/call_trace.{json,npz}): how a recorded argument becomes a tensor again.
+"""The call-trace fixtures (tests/golden/call_trace{,_stress}.{json,npz}): how a recorded argument becomes a tensor again.
 
 tests/golden/make_golden.py call_trace wraps the hot-path names of the imported reference while its model runs one forward
 and records every call the reference model itself makes: which function, from which reference line, which arguments went
@@ -65,14 +65,25 @@ def strided_tensor(values, strides, offset, device):
     return out
 
 
-class Trace:
-    """call_trace.json + call_trace.npz."""
+TRACES = ("call_trace", "call_trace_stress")  # tests/golden/make_golden.py TRACE_CASES
 
-    def __init__(self, path=HERE):
-        with open(os.path.join(path, "call_trace.json")) as f:
+
+class Trace:
+    """<name>.json + <name>.npz."""
+
+    def __init__(self, name="call_trace", path=HERE):
+        with open(os.path.join(path, name + ".json")) as f:
             self.meta = json.load(f)
-        self.arrays = np.load(os.path.join(path, "call_trace.npz"))
+        self.arrays = np.load(os.path.join(path, name + ".npz"))
         self.calls = self.meta["calls"]
+        self.name = name
+
+    def parameters(self, path=HERE):
+        """The seeded parameter fill the trace was recorded with, by state-dict key."""
+        from tests import inputs as I
+        keys = json.load(open(os.path.join(path, "state_dict_keys.json")))
+        shapes = [(k, tuple(shape)) for k, shape, _ in keys]
+        return I.model_params(shapes, **({"seed": I.STRESS_MODEL_SEED} if self.meta["case"].get("model_seed") == "stress" else {}))
 
     def values(self, t):
         """The logical values of tensor record ``t`` (numpy, recorded dtype)."""
